@@ -1,0 +1,266 @@
+"""CPU oracle for the batched Gobblet hot path -- TEST INFRASTRUCTURE ONLY.
+
+ctypes front end of ``oracle/gobblet_oracle.c`` (a plain-C restatement of the
+reference's ``board.py`` / ``gobblet.py`` observe+step / ``greedy_policy.py``).
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this package; nothing under
+``gobblet-rl_amd/`` does.  All arrays are numpy, C-contiguous.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgobblet_oracle.so")
+
+CELLS, ACTIONS, OBS = 27, 54, 117
+ILLEGAL_NOOP, ILLEGAL_TERMINATE = 0, 1
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (seconds). Returns the .so path."""
+    src = os.path.join(_HERE, "gobblet_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libgobblet_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _i8p, _i32p, _i64p, _u32p = (C.POINTER(C.c_int8), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_uint32))
+        L = _lib
+        L.gbo_is_legal.restype = C.c_int
+        L.gbo_is_legal.argtypes = [_i8p, C.c_int, C.c_int]
+        L.gbo_check_for_winner.restype = C.c_int
+        L.gbo_check_for_winner.argtypes = [_i8p]
+        L.gbo_check_game_over.restype = C.c_int
+        L.gbo_check_game_over.argtypes = [_i8p]
+        L.gbo_get_action.restype = C.c_int
+        L.gbo_get_action.argtypes = [_i8p, C.c_int, C.c_int, C.c_int]
+        L.gbo_play_turn.restype = None
+        L.gbo_play_turn.argtypes = [_i8p, C.c_int, C.c_int]
+        L.gbo_get_flatboard.restype = None
+        L.gbo_get_flatboard.argtypes = [_i8p, _i8p]
+        L.gbo_check_covered.restype = None
+        L.gbo_check_covered.argtypes = [_i8p, _i8p]
+        L.gbo_legal_mask.restype = None
+        L.gbo_legal_mask.argtypes = [_i8p, C.c_int, _i8p]
+        L.gbo_observation.restype = None
+        L.gbo_observation.argtypes = [_i8p, C.c_int, _i8p]
+        L.gbo_observe.restype = None
+        L.gbo_observe.argtypes = [_i8p, C.c_int, C.c_int, _i8p, _i8p]
+        L.gbo_step.restype = C.c_int
+        L.gbo_step.argtypes = [_i8p, _i8p, _i8p, C.c_int, C.c_int, _i8p]
+        L.gbo_philox4x32_10.restype = None
+        L.gbo_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
+        L.gbo_sample_action.restype = C.c_int
+        L.gbo_sample_action.argtypes = [_i8p, C.c_uint64, C.c_uint64, C.c_uint32]
+        L.gbo_batch_reset.restype = None
+        L.gbo_batch_reset.argtypes = [_i8p, _i8p, _i8p, _i8p, C.c_int64]
+        L.gbo_batch_legal_mask.restype = None
+        L.gbo_batch_legal_mask.argtypes = [_i8p, _i8p, _i8p, C.c_int64]
+        L.gbo_batch_winner.restype = None
+        L.gbo_batch_winner.argtypes = [_i8p, _i8p, C.c_int64]
+        L.gbo_batch_flatboard.restype = None
+        L.gbo_batch_flatboard.argtypes = [_i8p, _i8p, C.c_int64]
+        L.gbo_batch_covered.restype = None
+        L.gbo_batch_covered.argtypes = [_i8p, _i8p, C.c_int64]
+        L.gbo_batch_observe.restype = None
+        L.gbo_batch_observe.argtypes = [_i8p, _i8p, C.c_int, _i8p, C.c_int64]
+        L.gbo_batch_step.restype = None
+        L.gbo_batch_step.argtypes = [_i8p, _i8p, _i8p, _i32p, _i8p, _i8p, _i8p, _i8p, C.c_int64, C.c_int, C.c_int]
+        L.gbo_batch_step_mt.restype = None
+        L.gbo_batch_step_mt.argtypes = L.gbo_batch_step.argtypes + [C.c_int]
+        L.gbo_batch_sample.restype = None
+        L.gbo_batch_sample.argtypes = [_i8p, _i32p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32]
+        L.gbo_batch_rollout.restype = None
+        L.gbo_batch_rollout.argtypes = [_i8p, _i8p, _i8p, _i32p, _i8p, _i8p, _i8p, _i8p, C.c_int64, C.c_uint64,
+                                        C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, _i64p]
+        L.gbo_greedy_decode_obs.restype = C.c_int
+        L.gbo_greedy_decode_obs.argtypes = [_i8p, _i8p]
+        L.gbo_greedy.restype = None
+        L.gbo_greedy.argtypes = [_i8p, C.c_int, _i8p, C.c_int, _i8p, C.POINTER(C.c_int), _i8p, C.POINTER(C.c_int)]
+        L.gbo_batch_greedy.restype = None
+        L.gbo_batch_greedy.argtypes = [_i8p, _i8p, _i8p, _i8p, C.c_int, _i32p, _i8p, _i8p, C.c_int64]
+    return _lib
+
+
+def _p(a, ct=C.c_int8):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "oracle arrays must be C-contiguous"
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def _i8(a):
+    return np.ascontiguousarray(a, dtype=np.int8)
+
+
+# ---- single-board functions (mirror Board's method names, board.py) -------------------------
+
+def get_flatboard(squares):
+    s = _i8(squares); out = np.zeros(9, np.int8)
+    lib().gbo_get_flatboard(_p(s), _p(out)); return out
+
+
+def check_covered(squares):
+    s = _i8(squares); out = np.zeros(CELLS, np.int8)
+    lib().gbo_check_covered(_p(s), _p(out)); return out
+
+
+def is_legal(squares, action, agent_index=0):
+    s = _i8(squares)
+    r = lib().gbo_is_legal(_p(s), int(action), int(agent_index))
+    if r < 0:
+        raise Exception("PIECE HAS BEEN USED TWICE")  # board.py:95
+    return bool(r)
+
+
+def play_turn(squares, agent_index, action):
+    """Returns the new 27-vector (input is not modified)."""
+    s = _i8(squares).copy()
+    lib().gbo_play_turn(_p(s), int(agent_index), int(action)); return s
+
+
+def check_for_winner(squares):
+    return int(lib().gbo_check_for_winner(_p(_i8(squares))))
+
+
+def check_game_over(squares):
+    return bool(lib().gbo_check_game_over(_p(_i8(squares))))
+
+
+def get_action(squares, pos, piece_size, agent_index):
+    return int(lib().gbo_get_action(_p(_i8(squares)), int(pos), int(piece_size), int(agent_index)))
+
+
+def legal_mask(squares, agent_index):
+    s = _i8(squares); out = np.zeros(ACTIONS, np.int8)
+    lib().gbo_legal_mask(_p(s), int(agent_index), _p(out)); return out
+
+
+def observation(squares, agent_index):
+    s = _i8(squares); out = np.zeros((3, 3, 13), np.int8)
+    lib().gbo_observation(_p(s), int(agent_index), _p(out)); return out
+
+
+def observe(squares, agent_index, agent_selection):
+    s = _i8(squares); obs = np.zeros((3, 3, 13), np.int8); mask = np.zeros(ACTIONS, np.int8)
+    lib().gbo_observe(_p(s), int(agent_index), int(agent_selection), _p(obs), _p(mask))
+    return {"observation": obs, "action_mask": mask}
+
+
+def step(squares, to_move, done, action, illegal_mode=ILLEGAL_NOOP):
+    """One raw_env.step on one board. Returns (squares', to_move', done', winner, reward[2])."""
+    s = _i8(squares).copy()
+    tm = np.array([to_move], np.int8); dn = np.array([done], np.int8); rw = np.zeros(2, np.int8)
+    w = lib().gbo_step(_p(s), _p(tm), _p(dn), int(action), int(illegal_mode), _p(rw))
+    return s, int(tm[0]), int(dn[0]), int(w), rw
+
+
+def philox4x32_10(ctr, key):
+    c = np.ascontiguousarray(ctr, np.uint32); k = np.ascontiguousarray(key, np.uint32); o = np.zeros(4, np.uint32)
+    lib().gbo_philox4x32_10(_p(c, C.c_uint32), _p(k, C.c_uint32), _p(o, C.c_uint32)); return o
+
+
+def sample_action(mask, seed, env_id, ply):
+    return int(lib().gbo_sample_action(_p(_i8(mask)), int(seed), int(env_id), int(ply)))
+
+
+def greedy_decode_obs(obs):
+    o = _i8(obs); s = np.zeros(CELLS, np.int8)
+    agent = lib().gbo_greedy_decode_obs(_p(o), _p(s)); return s, int(agent)
+
+
+def greedy(squares, agent_index, mask, depth=2, prev3=None):
+    """Returns (chosen_before_fallback or None, cand_mask int8[54], fallback bool)."""
+    s = _i8(squares); m = _i8(mask); cm = np.zeros(ACTIONS, np.int8)
+    p3 = None
+    if prev3 is not None:
+        p3 = np.full(3, -1, np.int8); pv = list(prev3)[-3:]; p3[:len(pv)] = pv
+    ch = C.c_int(); fb = C.c_int()
+    lib().gbo_greedy(_p(s), int(agent_index), _p(m), int(depth), _p(p3), C.byref(ch), _p(cm), C.byref(fb))
+    return (None if ch.value < 0 else ch.value), cm, bool(fb.value)
+
+
+# ---- batched functions (same arrays as include/gobblet_hip.h) --------------------------------
+
+def batch_reset(n):
+    return np.zeros((n, CELLS), np.int8), np.zeros(n, np.int8), np.zeros(n, np.int8)
+
+
+def batch_legal_mask(state, to_move):
+    n = state.shape[0]; out = np.zeros((n, ACTIONS), np.int8)
+    lib().gbo_batch_legal_mask(_p(state), _p(to_move), _p(out), n); return out
+
+
+def batch_winner(state):
+    n = state.shape[0]; out = np.zeros(n, np.int8)
+    lib().gbo_batch_winner(_p(state), _p(out), n); return out
+
+
+def batch_flatboard(state):
+    n = state.shape[0]; out = np.zeros((n, 9), np.int8)
+    lib().gbo_batch_flatboard(_p(state), _p(out), n); return out
+
+
+def batch_covered(state):
+    n = state.shape[0]; out = np.zeros((n, CELLS), np.int8)
+    lib().gbo_batch_covered(_p(state), _p(out), n); return out
+
+
+def batch_observe(state, to_move, agent_sel=-1):
+    n = state.shape[0]; out = np.zeros((n, 3, 3, 13), np.int8)
+    lib().gbo_batch_observe(_p(state), _p(to_move), int(agent_sel), _p(out), n); return out
+
+
+def batch_step(state, to_move, done, actions, illegal_mode=ILLEGAL_NOOP, auto_reset=False, threads=1,
+               want_obs=True, want_mask=True):
+    """In-place lockstep step. Returns dict(winner, reward, mask, obs)."""
+    n = state.shape[0]
+    actions = np.ascontiguousarray(actions, np.int32)
+    winner = np.zeros(n, np.int8); reward = np.zeros((n, 2), np.int8)
+    mask = np.zeros((n, ACTIONS), np.int8) if want_mask else None
+    obs = np.zeros((n, 3, 3, 13), np.int8) if want_obs else None
+    lib().gbo_batch_step_mt(_p(state), _p(to_move), _p(done), _p(actions, C.c_int32), _p(winner), _p(reward),
+                            _p(mask), _p(obs), n, int(illegal_mode), int(bool(auto_reset)), int(threads))
+    return {"winner": winner, "reward": reward, "mask": mask, "obs": obs}
+
+
+def batch_sample(mask, seed, env_base, ply):
+    n = mask.shape[0]; out = np.zeros(n, np.int32)
+    lib().gbo_batch_sample(_p(mask), _p(out, C.c_int32), n, int(seed), int(env_base), int(ply)); return out
+
+
+def batch_rollout(state, to_move, done, seed, env_base, ply0, plies, illegal_mode=ILLEGAL_NOOP, threads=1,
+                  want_obs=True, want_mask=True):
+    """In-place fused masked-random rollout with auto-reset.
+    Returns dict(actions, winner, reward, mask, obs, counters[plies, games, p1_wins, p2_wins])."""
+    n = state.shape[0]
+    actions = np.zeros(n, np.int32); winner = np.zeros(n, np.int8); reward = np.zeros((n, 2), np.int8)
+    mask = np.zeros((n, ACTIONS), np.int8) if want_mask else None
+    obs = np.zeros((n, 3, 3, 13), np.int8) if want_obs else None
+    counters = np.zeros(4, np.int64)
+    lib().gbo_batch_rollout(_p(state), _p(to_move), _p(done), _p(actions, C.c_int32), _p(winner), _p(reward),
+                            _p(mask), _p(obs), n, int(seed), int(env_base), int(ply0), int(plies), int(illegal_mode),
+                            int(threads), _p(counters, C.c_int64))
+    return {"actions": actions, "winner": winner, "reward": reward, "mask": mask, "obs": obs, "counters": counters}
+
+
+def batch_greedy(state, to_move, mask=None, hist=None, depth=2):
+    """Returns (action int32[n] (-1 where fallback), cand_mask int8[n,54], fallback int8[n])."""
+    n = state.shape[0]
+    act = np.zeros(n, np.int32); cm = np.zeros((n, ACTIONS), np.int8); fb = np.zeros(n, np.int8)
+    lib().gbo_batch_greedy(_p(state), _p(to_move), _p(mask), _p(hist), int(depth), _p(act, C.c_int32), _p(cm),
+                           _p(fb), n)
+    return act, cm, fb

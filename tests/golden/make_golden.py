@@ -1,0 +1,368 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (the reference lives at /root/reference and
+never travels to the GPU box).  It imports the reference's own
+``gobblet_rl/game/board.py``, ``gobblet.py`` and ``greedy_policy.py`` and
+records inputs + outputs as plain data (.npz / .json).  No reference source is
+copied: the files written here hold arrays only.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+``gobblet.py`` imports gymnasium / pygame / pettingzoo, which are not
+installed here; SURVEY.md App. C: minimal in-memory stand-ins for those three
+third-party packages are registered in ``sys.modules`` first, so that the
+bodies of ``raw_env.observe/_legal_moves/step/reset`` that execute are the
+reference's own code.  Only ``AECEnv._accumulate_rewards`` and
+``agent_selector`` are stand-ins (restated from PettingZoo 1.22.3).
+"""
+import ast
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+
+
+# --------------------------------------------------------------------------------------
+def install_standins():
+    gymnasium = types.ModuleType("gymnasium")
+    spaces = types.ModuleType("gymnasium.spaces")
+
+    class _Space:
+        def __init__(self, *a, **k):
+            self.args, self.kwargs = a, k
+
+    spaces.Discrete = type("Discrete", (_Space,), {})
+    spaces.Box = type("Box", (_Space,), {})
+    spaces.Dict = type("Dict", (_Space,), {})
+    gymnasium.spaces = spaces
+    gymnasium.logger = types.SimpleNamespace(warn=lambda *a, **k: None)
+    pygame = types.ModuleType("pygame")
+    pettingzoo = types.ModuleType("pettingzoo")
+
+    class AECEnv:
+        def __init__(self):
+            pass
+
+        def _accumulate_rewards(self):
+            for agent, reward in self.rewards.items():
+                self._cumulative_rewards[agent] += reward
+
+        def close(self):
+            pass
+
+    pettingzoo.AECEnv = AECEnv
+    utils = types.ModuleType("pettingzoo.utils")
+
+    class agent_selector:
+        def __init__(self, agent_order):
+            self.reinit(agent_order)
+
+        def reinit(self, agent_order):
+            self.agent_order = agent_order
+            self._current_agent = 0
+            self.selected_agent = 0
+
+        def reset(self):
+            self.reinit(self.agent_order)
+            return self.next()
+
+        def next(self):
+            self._current_agent = (self._current_agent + 1) % len(self.agent_order)
+            self.selected_agent = self.agent_order[self._current_agent - 1]
+            return self.selected_agent
+
+    utils.agent_selector = agent_selector
+    utils.wrappers = types.SimpleNamespace()
+    conversions = types.ModuleType("pettingzoo.utils.conversions")
+    conversions.parallel_wrapper_fn = lambda f: f
+    utils.conversions = conversions
+    pettingzoo.utils = utils
+    for name, mod in [("gymnasium", gymnasium), ("gymnasium.spaces", spaces), ("pygame", pygame),
+                      ("pettingzoo", pettingzoo), ("pettingzoo.utils", utils),
+                      ("pettingzoo.utils.conversions", conversions)]:
+        sys.modules[name] = mod
+
+
+sys.path.insert(0, REF)
+install_standins()
+from gobblet_rl.game.board import Board  # noqa: E402
+from gobblet_rl.game.gobblet import raw_env  # noqa: E402
+from gobblet_rl.game.greedy_policy import GreedyGobbletPolicy  # noqa: E402
+
+
+def i8(a):
+    a = np.asarray(a)
+    assert np.all(a == np.round(a))
+    return a.astype(np.int8)
+
+
+# --------------------------------------------------------------------------------------
+def kat_collector():
+    """Literal arrays of tests/test_manual_policy_collector.py (upstream known-answer test)."""
+    src = open(os.path.join(REF, "tests/test_manual_policy_collector.py")).read()
+    tree = ast.parse(src)
+    found = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name):
+            name = node.targets[0].id
+            if name.startswith("output") and name != "output7":
+                v = node.value
+                if isinstance(v, ast.Call):  # np.array([...])
+                    v = v.args[0]
+                found[name] = ast.literal_eval(v)
+    kat = {
+        "source": "tests/test_manual_policy_collector.py:49-507",
+        "actions": [18, 36, 28, 46],
+        "illegal_action": 29,
+        "mask_after": {k: [int(bool(x)) for x in np.array(found[k]).reshape(-1)]
+                       for k in ["output0", "output1", "output2", "output3", "output4", "output5"]},
+        "legal_moves_output6": [int(x) for x in found["output6"]],
+        "board_output8": [int(x) for x in np.array(found["output8"]).reshape(-1)],
+    }
+    # replay through the reference and note which literals the reference itself reproduces
+    env = raw_env()
+    env.reset()
+    got = {"output0": env.observe(env.agent_selection)["action_mask"]}
+    for name, a in zip(["output1", "output2", "output3", "output4"], kat["actions"]):
+        env.step(a)
+        got[name] = env.observe(env.agent_selection)["action_mask"]
+    got["output5"] = got["output4"]
+    legal6 = env._legal_moves()
+    env.step(kat["illegal_action"])
+    board8 = i8(env.board.squares)
+    kat["reference_reproduces"] = {k: bool(np.array_equal(got[k], np.array(kat["mask_after"][k], np.int8)))
+                                   for k in kat["mask_after"]}
+    kat["reference_reproduces"]["output6"] = bool(legal6 == kat["legal_moves_output6"])
+    kat["reference_reproduces"]["output8"] = bool(np.array_equal(board8, np.array(kat["board_output8"], np.int8)))
+    kat["reference_mask_after"] = {k: [int(x) for x in got[k]] for k in got}
+    kat["reference_board_after_illegal"] = [int(x) for x in board8]
+    kat["reference_to_move_after_illegal"] = env.agents.index(env.agent_selection)
+    with open(os.path.join(OUT, "kat_collector.json"), "w") as f:
+        json.dump(kat, f, indent=1)
+    print("kat_collector.json", kat["reference_reproduces"])
+
+
+# --------------------------------------------------------------------------------------
+def random_games(n_games=96, seed=20240607, p_any=0.08):
+    """Seeded games through the reference raw_env (masked-random, with a few
+    arbitrary -- possibly illegal -- actions to pin the silent no-op)."""
+    rng = np.random.default_rng(seed)
+    rec = {k: [] for k in ["game", "ply", "mover", "action", "squares_before", "squares_after", "to_move_after",
+                           "mask_next", "mask_offturn", "winner", "done", "obs_p1", "obs_p2", "reward",
+                           "cum_reward", "legal_before"]}
+    for g in range(n_games):
+        env = raw_env()
+        env.reset()
+        ply = 0
+        while True:
+            mover = env.agents.index(env.agent_selection)
+            mask = env.observe(env.agent_selection)["action_mask"]
+            if rng.random() < p_any:
+                a = int(rng.integers(0, 54))
+            else:
+                a = int(rng.choice(np.flatnonzero(mask)))
+            before = i8(env.board.squares)
+            env.step(a)
+            nxt = env.agent_selection
+            other = env.agents[1 - env.agents.index(nxt)]
+            rec["game"].append(g); rec["ply"].append(ply); rec["mover"].append(mover); rec["action"].append(a)
+            rec["legal_before"].append(int(mask[a]))
+            rec["squares_before"].append(before)
+            rec["squares_after"].append(i8(env.board.squares))
+            rec["to_move_after"].append(env.agents.index(nxt))
+            rec["mask_next"].append(env.observe(nxt)["action_mask"])
+            rec["mask_offturn"].append(env.observe(other)["action_mask"])
+            rec["winner"].append(env.board.check_for_winner())
+            rec["done"].append(int(env.terminations["player_1"]))
+            rec["obs_p1"].append(env.observe("player_1")["observation"])
+            rec["obs_p2"].append(env.observe("player_2")["observation"])
+            rec["reward"].append([env.rewards["player_1"], env.rewards["player_2"]])
+            rec["cum_reward"].append([env._cumulative_rewards["player_1"], env._cumulative_rewards["player_2"]])
+            ply += 1
+            if env.terminations["player_1"] or ply >= 60:
+                break
+    out = {k: np.asarray(v) for k, v in rec.items()}
+    for k in ["squares_before", "squares_after", "mask_next", "mask_offturn", "obs_p1", "obs_p2"]:
+        out[k] = out[k].astype(np.int8)
+    for k in ["mover", "to_move_after", "winner", "done", "reward", "cum_reward", "legal_before"]:
+        out[k] = out[k].astype(np.int8)
+    out["game"] = out["game"].astype(np.int32); out["ply"] = out["ply"].astype(np.int32)
+    out["action"] = out["action"].astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, "random_games.npz"), **out)
+    n = len(out["action"])
+    print(f"random_games.npz: {n_games} games, {n} plies, illegal plies {int((out['legal_before'] == 0).sum())}, "
+          f"mover-loses terminals {int(((out['winner'] != 0) & (out['winner'] == np.where(out['mover'] == 0, -1, 1))).sum())}")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+def board_fn_vectors(squares_list):
+    """Board-level functions of board.py on a list of 27-vectors."""
+    rows = {k: [] for k in ["squares", "flatboard", "covered", "legal_p1", "legal_p2", "winner", "game_over",
+                            "get_action_p1", "get_action_p2", "obs_p1", "obs_p2"]}
+    env = raw_env()
+    env.reset()
+    for sq in squares_list:
+        b = Board()
+        b.squares = np.array(sq, dtype=np.float64)
+        rows["squares"].append(i8(sq))
+        rows["flatboard"].append(i8(b.get_flatboard()))
+        rows["covered"].append(i8(b.check_covered()))
+        rows["legal_p1"].append([int(b.is_legal(a, 0)) for a in range(54)])
+        rows["legal_p2"].append([int(b.is_legal(a, 1)) for a in range(54)])
+        rows["winner"].append(b.check_for_winner())
+        rows["game_over"].append(int(b.check_game_over()))
+        rows["get_action_p1"].append([[b.get_action(p, s, 0) for s in (1, 2, 3)] for p in range(9)])
+        rows["get_action_p2"].append([[b.get_action(p, s, 1) for s in (1, 2, 3)] for p in range(9)])
+        env.board = b
+        rows["obs_p1"].append(env.observe("player_1")["observation"])
+        rows["obs_p2"].append(env.observe("player_2")["observation"])
+    return {k: np.asarray(v).astype(np.int8) for k, v in rows.items()}
+
+
+def random_valid_board(rng):
+    """A random board obeying the placement invariants (each piece at most once,
+    on its own level, stacks strictly increasing) -- denser than self-play reaches."""
+    sq = np.zeros(27, np.int8)
+    for piece in range(1, 7):
+        for sign in (1, -1):
+            if rng.random() < 0.75:
+                level = (piece - 1) // 2
+                free = [p for p in range(9) if sq[9 * level + p] == 0]
+                p = int(rng.choice(free))
+                sq[9 * level + p] = sign * piece
+    return sq
+
+
+def edge_cases():
+    """SURVEY.md App. D quirks as explicit boards."""
+    E = {}
+
+    def put(pairs):
+        sq = np.zeros(27, np.int8)
+        for cell, v in pairs:
+            sq[cell] = v
+        return sq
+
+    # dual lines, both orders (last matching line decides)
+    E["dual_p1_line0_p2_line2"] = put([(18 + 0, 5), (18 + 1, 6), (9 + 2, 3), (9 + 6, -3), (9 + 7, -4), (18 + 8, -5)])
+    E["dual_p2_line0_p1_line2"] = -E["dual_p1_line0_p2_line2"]
+    # same line index for both is impossible; diagonal vs column
+    E["p1_diag_p2_col"] = put([(18 + 0, 5), (9 + 4, 3), (18 + 8, 6), (9 + 3, -3), (18 + 5, -5), (0 + 1, -1)])
+    # covered small under medium / large, covered medium under large
+    E["covered_stack"] = put([(0, 1), (9, -3), (18, 5), (1, -2), (18 + 1, -6), (2, 2), (9 + 2, 4)])
+    # all twelve pieces on the board
+    E["all_twelve"] = put([(0, 1), (1, 2), (2, -1), (3, -2), (9 + 0, 3), (9 + 4, 4), (9 + 5, -3), (9 + 6, -4),
+                           (18 + 0, 5), (18 + 7, 6), (18 + 8, -5), (18 + 4, -6)])
+    # self-gobble: own medium over own small
+    E["self_gobble"] = put([(4, 1), (9 + 4, 3)])
+    # uncovering hands the opponent a line: P1 large on pos 1 covers P2 medium; P2 has tops at 0 and 2
+    E["uncover_loss"] = put([(18 + 1, 5), (9 + 1, -3), (9 + 0, -4), (18 + 2, -5)])
+    E["empty"] = np.zeros(27, np.int8)
+    return E
+
+
+# --------------------------------------------------------------------------------------
+class _Capture:
+    """Stand-in for np.random.choice used only by the greedy harness: records the
+    candidate list the reference hands to it and returns its first element."""
+
+    def __init__(self):
+        self.calls = []
+
+    def __call__(self, a, *args, **kwargs):
+        lst = [int(x) for x in a]
+        self.calls.append(lst)
+        return np.int64(lst[0])
+
+
+def greedy_decision(obs, mask, depth):
+    """(chosen_before_fallback | -1, actions_depth1 list, returned) with empty history."""
+    cap = _Capture()
+    orig = np.random.choice
+    np.random.choice = cap
+    try:
+        pol = GreedyGobbletPolicy(depth=depth)
+        ret = int(pol.compute_action(obs, mask))
+        if cap.calls:  # fallback with chosen None (history is empty)
+            return -1, cap.calls[0], ret
+        agent = int(obs[..., 12].max())
+        pol2 = GreedyGobbletPolicy(depth=depth)
+        pol2.prev_actions[agent] = [ret]  # forces the fallback so the list becomes observable
+        cap.calls.clear()
+        pol2.compute_action(obs, mask)
+        assert len(cap.calls) == 1
+        return ret, cap.calls[0], ret
+    finally:
+        np.random.choice = orig
+
+
+def greedy_vectors(games, n_positions=320, seed=7):
+    rng = np.random.default_rng(seed)
+    idx = np.flatnonzero((games["done"] == 0) & (games["ply"] >= 1))
+    pick = rng.choice(idx, size=min(n_positions, len(idx)), replace=False)
+    positions = [(games["squares_after"][i].copy(), int(games["to_move_after"][i])) for i in pick]
+    # the immediate-win-overwritten quirk of SURVEY.md App. B: P1 has tops on 0,1 and can finish on 8? build one:
+    quirk = np.zeros(27, np.int8)
+    quirk[18 + 0] = 5; quirk[9 + 4] = 3   # P1 large at 0, P1 medium at 4 -> diagonal 0,4,8 open at 8
+    quirk[0 + 1] = -1; quirk[0 + 3] = -2  # two P2 smalls that threaten nothing
+    positions.append((quirk, 0))
+    positions.append((-quirk, 1))
+    # dense random valid non-terminal boards
+    tries = 0
+    while len(positions) < n_positions + 2 + 48 and tries < 10000:
+        tries += 1
+        sq = random_valid_board(rng)
+        b = Board(); b.squares = sq.astype(np.float64)
+        if b.check_for_winner() == 0:
+            positions.append((sq, int(rng.integers(0, 2))))
+    env = raw_env()
+    env.reset()
+    rows = {k: [] for k in ["squares", "to_move", "obs", "mask", "chosen_d1", "cands_d1", "chosen_d2", "cands_d2"]}
+    for n, (sq, tm) in enumerate(positions):
+        b = Board(); b.squares = sq.astype(np.float64)
+        env.board = b
+        env.agent_selection = env.agents[tm]
+        o = env.observe(env.agents[tm])
+        obs, mask = o["observation"], o["action_mask"]
+        rows["squares"].append(sq); rows["to_move"].append(tm); rows["obs"].append(obs); rows["mask"].append(mask)
+        for depth in (1, 2):
+            chosen, cands, _ = greedy_decision(obs, mask, depth)
+            cm = np.zeros(54, np.int8); cm[cands] = 1
+            assert cands == sorted(cands)
+            rows[f"chosen_d{depth}"].append(chosen); rows[f"cands_d{depth}"].append(cm)
+        if n % 50 == 0:
+            print("  greedy", n, "/", len(positions), flush=True)
+    out = {k: np.asarray(v).astype(np.int8) for k, v in rows.items()}
+    np.savez_compressed(os.path.join(OUT, "greedy.npz"), **out)
+    print(f"greedy.npz: {len(positions)} positions; depth2 fallback(None) {int((out['chosen_d2'] < 0).sum())}; "
+          f"quirk chosen d1={out['chosen_d1'][len(pick)]} d2={out['chosen_d2'][len(pick)]}")
+
+
+# --------------------------------------------------------------------------------------
+def main():
+    kat_collector()
+    games = random_games()
+    rng = np.random.default_rng(99)
+    E = edge_cases()
+    names = list(E)
+    boards = [E[k] for k in names] + [random_valid_board(rng) for _ in range(400)]
+    bf = board_fn_vectors(boards)
+    bf["edge_names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "board_functions.npz"), **bf)
+    print("board_functions.npz:", len(boards), "boards; winners", dict(zip(*np.unique(bf["winner"], return_counts=True))))
+    for k in names:
+        i = names.index(k)
+        print(f"  {k}: winner {bf['winner'][i]} flat {bf['flatboard'][i].tolist()}")
+    greedy_vectors(games)
+
+
+if __name__ == "__main__":
+    main()
