@@ -1,0 +1,109 @@
+"""ctypes binding of the HIP library (``csrc/libgobblet_hip.so``, C-ABI in ``include/gobblet_hip.h``).
+
+There is no CPU fallback: if the library cannot be built or loaded this module raises.
+``import torch`` happens first on purpose -- the PyTorch-ROCm wheel bundles the HIP runtime
+under the same SONAME (``libamdhip64.so.7``) the library links against, so importing torch
+first makes the process use ONE runtime and lets torch streams / tensors be handed across
+the ABI as plain pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import torch  # noqa: F401  (must precede loading the HIP library, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libgobblet_hip.so")
+SOURCES = [os.path.join(CSRC, "gobblet_hip.hip"), os.path.join(CSRC, "gobblet_device.h"),
+           os.path.join(_HERE, "..", "include", "gobblet_hip.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mcode-object-version=5"]
+
+OK, ERR_ARG, ERR_ALIGN, ERR_HIP = 0, -1, -2, -3
+ILLEGAL_NOOP, ILLEGAL_TERMINATE = 0, 1
+CELLS, ACTIONS, OBS_BYTES = 27, 54, 117
+
+# every symbol include/gobblet_hip.h declares: (name, restype, argtypes)
+_vp, _i64, _u64, _u32, _int = C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_int
+SIGNATURES = {
+    "gbl_layout_info": (_int, [C.POINTER(C.c_int32)]),
+    "gbl_last_error": (C.c_char_p, []),
+    "gbl_reset": (_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "gbl_legal_mask": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "gbl_is_legal": (_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "gbl_play_turn": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "gbl_winner": (_int, [_vp, _vp, _i64, _vp]),
+    "gbl_flatboard": (_int, [_vp, _vp, _i64, _vp]),
+    "gbl_covered": (_int, [_vp, _vp, _i64, _vp]),
+    "gbl_observe": (_int, [_vp, _vp, _int, _vp, _i64, _vp]),
+    "gbl_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
+    "gbl_sample": (_int, [_vp, _vp, _i64, _u64, _u64, _u32, _vp]),
+    "gbl_rollout": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u64, _u64, _u32, _u32, _int, _int, _vp, _vp]),
+    "gbl_decode_obs": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "gbl_greedy": (_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp]),
+}
+
+
+class GobbletHipError(RuntimeError):
+    pass
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(s) > t for s in SOURCES)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise GobbletHipError("hipcc not found: cannot build csrc/libgobblet_hip.so (there is no CPU fallback)")
+    cmd = [hipcc, *HIPCC_FLAGS, "-o", LIB_PATH, SOURCES[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library with typed entry points. Raises if it is missing and cannot be built."""
+    global _lib
+    if _lib is None:
+        path = build()
+        try:
+            L = C.CDLL(path)
+        except OSError as e:  # pragma: no cover
+            raise GobbletHipError(f"cannot load {path}: {e} (there is no CPU fallback)") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise GobbletHipError(f"{path} does not export {name}") from e
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != OK:
+        msg = lib().gbl_last_error().decode("utf-8", "replace")
+        raise GobbletHipError(f"{what or 'gobblet_hip'} failed (code {rc}): {msg}")
+
+
+def ptr(t) -> int | None:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

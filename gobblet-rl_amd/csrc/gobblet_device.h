@@ -1,0 +1,538 @@
+// gobblet_device.h -- device-side building blocks of the gfx950 Gobblet kernels.
+//
+// Execution shape: ONE wavefront (64 lanes) per workgroup, ONE board per lane,
+// a TILE of 64 consecutive boards per wavefront.  Rows of a tile are contiguous
+// in HBM (env-major int8 rows of 27 / 54 / 117 bytes), so a tile is moved with
+// full-width 16-byte-per-lane loads/stores (1 KiB per wave instruction) and
+// (un)packed to one-row-per-lane through LDS:
+//
+//   HBM tile --dwordx4--> LDS image --ds_read_b32 + v_alignbyte--> row in VGPRs
+//   row in VGPRs --v_alignbyte + ds_write_b32--> LDS image --dwordx4--> HBM tile
+//
+// Row sizes are odd (27, 54, 117 bytes) so lane l's row starts at byte l*ROWB,
+// which is dword-aligned only every 4th (2nd) lane; the byte shift is done in
+// registers with v_alignbyte_b32 so that every LDS access is an aligned dword
+// and every HBM access a full 16-byte vector.
+//
+// The game logic runs on three 27-bit planes per board (bit c = cell c of
+// Board.squares, c = 9*level + pos):  nz (cell occupied), neg (player_2's
+// piece), odd (piece number odd = first piece of its size).
+#pragma once
+#ifndef GBL_HOST_EMU  // tests/emu/ compiles this header for the host with shims for the few builtins used
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+
+namespace gbl {
+
+constexpr int kTile = 64;   // boards per wavefront
+constexpr int kCells = 27;  // Board.squares, board.py:33
+constexpr int kActions = 54;
+constexpr int kObs = 117;   // 3*3*13, gobblet.py:145
+
+__device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t nbytes)
+{
+    // ({hi,lo} >> 8*nbytes)[31:0], nbytes in 0..3
+    return __builtin_amdgcn_alignbyte(hi, lo, nbytes);
+}
+
+// Blocks are dealt round-robin over the 8 XCDs (block b and b+8 share one);
+// give every XCD a CONTIGUOUS range of tiles so that the 128-byte lines that
+// straddle two tiles are completed inside one L2 instead of being written
+// partially by two.  Speed only; any placement is correct.
+__device__ __forceinline__ int64_t xcd_tile(uint32_t bid, int64_t ntiles)
+{
+    int64_t chunk = (ntiles + 7) >> 3;
+    return (int64_t)(bid & 7u) * chunk + (bid >> 3);
+}
+
+// ---- tile <-> LDS image ---------------------------------------------------------------
+// g points at the tile's first byte (16-byte aligned); rows = valid boards in the tile.
+template <int ROWB>
+__device__ __forceinline__ void tile_in(const int8_t *__restrict__ g, uint32_t *lds, int lane, int rows)
+{
+    constexpr int NV = kTile * ROWB / 16;
+    if (rows == kTile) {
+        const uint4 *gv = reinterpret_cast<const uint4 *>(g);
+        uint4 *lv = reinterpret_cast<uint4 *>(lds);
+#pragma unroll
+        for (int i = 0; i < (NV + 63) / 64; ++i) {
+            int idx = lane + 64 * i;
+            if (idx < NV) lv[idx] = gv[idx];
+        }
+    } else {  // ragged last tile: byte granular
+        int bytes = rows * ROWB;
+        int8_t *lb = reinterpret_cast<int8_t *>(lds);
+        for (int i = lane; i < bytes; i += 64) lb[i] = g[i];
+    }
+}
+
+template <int ROWB>
+__device__ __forceinline__ void tile_out(int8_t *__restrict__ g, const uint32_t *lds, int lane, int rows)
+{
+    constexpr int NV = kTile * ROWB / 16;
+    if (rows == kTile) {
+        uint4 *gv = reinterpret_cast<uint4 *>(g);
+        const uint4 *lv = reinterpret_cast<const uint4 *>(lds);
+#pragma unroll
+        for (int i = 0; i < (NV + 63) / 64; ++i) {
+            int idx = lane + 64 * i;
+            if (idx < NV) gv[idx] = lv[idx];
+        }
+    } else {
+        int bytes = rows * ROWB;
+        const int8_t *lb = reinterpret_cast<const int8_t *>(lds);
+        for (int i = lane; i < bytes; i += 64) g[i] = lb[i];
+    }
+}
+
+// ---- LDS image <-> one row per lane ---------------------------------------------------
+// Lane l's row = image bytes [l*ROWB, (l+1)*ROWB).  r[] holds the row as
+// little-endian dwords; bytes past ROWB in the last dword are unspecified.
+// The image needs 4 readable bytes of slack after the tile.
+template <int ROWB>
+__device__ __forceinline__ void row_load(const uint32_t *lds, int lane, uint32_t (&r)[(ROWB + 3) / 4])
+{
+    constexpr int NW = (ROWB + 3) / 4;
+    uint32_t byteoff = (uint32_t)lane * ROWB;
+    uint32_t q0 = byteoff >> 2, sh = byteoff & 3u;
+    uint32_t x[NW + 1];
+#pragma unroll
+    for (int k = 0; k <= NW; ++k) x[k] = lds[q0 + k];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) r[k] = alignbyte(x[k + 1], x[k], sh);
+}
+
+// Each lane owns the image dwords whose FIRST byte lies in its row; the last
+// owned dword may end with up to 3 bytes of the next lane's row, fetched with
+// one DPP/shuffle of that lane's first dword.  64*ROWB is a multiple of 4, so
+// lane 63's last dword ends exactly at the tile end.
+template <int ROWB>
+__device__ __forceinline__ void row_stage(uint32_t *lds, int lane, const uint32_t (&d)[(ROWB + 3) / 4])
+{
+    constexpr int NW = (ROWB + 3) / 4;
+    constexpr int TAIL = ROWB % 4;
+    static_assert(TAIL != 0, "dword-multiple rows need no shifting");
+    uint32_t byteoff = (uint32_t)lane * ROWB;
+    uint32_t h = (4u - (byteoff & 3u)) & 3u;  // leading bytes that belong to the previous lane's last dword
+    uint32_t qfirst = (byteoff + 3u) >> 2;
+    uint32_t cnt = (ROWB - h + 3u) >> 2;      // NW or NW-1
+    uint32_t nd0 = __shfl_down(d[0], 1);
+    uint32_t e_last = (d[NW - 1] & ((1u << (8 * TAIL)) - 1u)) | (nd0 << (8 * TAIL));
+    uint32_t e_over = nd0 >> (8 * (4 - TAIL));
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        uint32_t lo = (k == NW - 1) ? e_last : d[k];
+        uint32_t hi = (k + 1 == NW - 1) ? e_last : (k + 1 == NW) ? e_over : d[k + 1];
+        uint32_t w = alignbyte(hi, lo, h);
+        if (k < NW - 1 || cnt == NW) lds[qfirst + k] = w;
+    }
+}
+
+// ---- bit planes ------------------------------------------------------------------------
+struct Planes {
+    uint32_t nz, neg, odd;  // 27 bits each; neg / odd are only meaningful where nz is set
+};
+
+// r[0..6] = the 27 state bytes (r[6] byte 3 ignored).  Exact per-byte tests in
+// SWAR, then v_dot4_u32_u8 with weights (1,2,4,8 | 16,32,64,128) gathers one
+// flag bit per byte of two dwords into 8 contiguous bits.
+__device__ __forceinline__ Planes make_planes(const uint32_t (&r)[7])
+{
+    Planes p{0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 7; j += 2) {
+        uint32_t anz = 0, ang = 0, aod = 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (j + u >= 7) break;
+            uint32_t x = r[j + u];
+            if (j + u == 6) x &= 0x00FFFFFFu;
+            uint32_t w = u ? 0x80402010u : 0x08040201u;
+            uint32_t t = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;  // 0x80 where byte != 0
+            anz = __builtin_amdgcn_udot4(t, w, anz, false);
+            ang = __builtin_amdgcn_udot4(x & 0x80808080u, w, ang, false);
+            aod = __builtin_amdgcn_udot4(x & 0x01010101u, w, aod, false);
+        }
+        p.nz |= (anz >> 7) << (4 * j);
+        p.neg |= (ang >> 7) << (4 * j);
+        p.odd |= aod << (4 * j);
+    }
+    return p;
+}
+
+// Board.check_for_winner, board.py:183-194, over the tops of get_flatboard
+// (board.py:159-177).  The reference walks the 8 lines in a fixed order with no
+// early exit, so the matching line with the HIGHEST index decides; one line
+// cannot match both colours, so comparing the two 8-bit match masks as
+// integers picks that line's colour.
+__device__ __forceinline__ int winner_of(const Planes &p)
+{
+    uint32_t pos = p.nz & ~p.neg, ngv = p.nz & p.neg;
+    uint32_t o1 = (p.nz >> 9) & 0x1FFu, o2 = (p.nz >> 18) & 0x1FFu;
+    uint32_t t1 = ((pos >> 18) & 0x1FFu) | (~o2 & (((pos >> 9) & 0x1FFu) | (~o1 & (pos & 0x1FFu))));
+    uint32_t t2 = ((ngv >> 18) & 0x1FFu) | (~o2 & (((ngv >> 9) & 0x1FFu) | (~o1 & (ngv & 0x1FFu))));
+    // board.py:135-153: (0,1,2) (3,4,5) (6,7,8) (0,3,6) (1,4,7) (2,5,8) (0,4,8) (2,4,6)
+    constexpr uint32_t L[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x111u, 0x054u};
+    uint32_t m1 = 0, m2 = 0;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        m1 |= ((t1 & L[l]) == L[l]) ? (1u << l) : 0u;
+        m2 |= ((t2 & L[l]) == L[l]) ? (1u << l) : 0u;
+    }
+    return m2 > m1 ? -1 : (m1 > m2 ? 1 : 0);
+}
+
+// 54-bit legal mask of agent `mover` (0 / 1): raw_env._legal_moves,
+// gobblet.py:223-228 = 54 x Board.is_legal, board.py:82-115.
+//   mask[9*piece + pos] = piece not covered (board.py:90-102, check_covered :203-220)
+//                         and size(piece) > size(top at pos) (board.py:106-115)
+__device__ __forceinline__ uint64_t legal54(const Planes &p, int mover)
+{
+    uint32_t o0 = p.nz & 0x1FFu, o1 = (p.nz >> 9) & 0x1FFu, o2 = (p.nz >> 18) & 0x1FFu;
+    uint32_t cov = (o0 & (o1 | o2)) | ((o1 & o2) << 9);  // covered cells (levels 0,1)
+    uint32_t mine = mover ? (p.nz & p.neg) : (p.nz & ~p.neg);
+    uint32_t bl = mine & cov;
+    uint32_t blo = bl & p.odd, ble = bl & ~p.odd;
+    uint32_t ok0 = ~(o0 | o1 | o2) & 0x1FFu, ok1 = ~(o1 | o2) & 0x1FFu, ok2 = ~o2 & 0x1FFu;
+    uint32_t g0 = (blo & 0x1FFu) ? 0u : ok0;      // piece 1
+    uint32_t g1 = (ble & 0x1FFu) ? 0u : ok0;      // piece 2
+    uint32_t g2 = (blo & 0x3FE00u) ? 0u : ok1;    // piece 3
+    uint32_t g3 = (ble & 0x3FE00u) ? 0u : ok1;    // piece 4
+    uint32_t lo = g0 | (g1 << 9) | (g2 << 18) | (g3 << 27);
+    uint32_t hi = (g3 >> 5) | (ok2 << 4) | (ok2 << 13);  // pieces 5, 6 are never covered
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Board.play_turn(mover, a), board.py:118-132, given that `a` is legal:
+// clear the cell holding the piece (if placed), write it at 9*level + pos.
+// Updates the planes and the 7 state dwords.
+__device__ __forceinline__ void apply_move(Planes &p, uint32_t (&r)[7], int mover, uint32_t a)
+{
+    uint32_t pi = (a * 57u) >> 9;  // a / 9 for a < 54
+    uint32_t q = a - 9u * pi;
+    uint32_t k = pi >> 1;
+    uint32_t first = (~pi) & 1u;   // piece number odd
+    uint32_t mine = mover ? (p.nz & p.neg) : (p.nz & ~p.neg);
+    uint32_t ploc = mine & (first ? p.odd : ~p.odd) & (0x1FFu << (9u * k));
+    uint32_t cnew = 9u * k + q, bit = 1u << cnew;
+    p.nz = (p.nz & ~ploc) | bit;
+    p.neg = (p.neg & ~ploc & ~bit) | (mover ? bit : 0u);
+    p.odd = (p.odd & ~ploc & ~bit) | (first ? bit : 0u);
+    uint32_t cold = ploc ? (uint32_t)__builtin_ctz(ploc) : 63u * 4u;
+    uint32_t val = (mover ? (0u - (pi + 1u)) : (pi + 1u)) & 0xFFu;
+    uint32_t mold = ~(0xFFu << (8u * (cold & 3u)));
+    uint32_t mnew = ~(0xFFu << (8u * (cnew & 3u)));
+    uint32_t vnew = val << (8u * (cnew & 3u));
+#pragma unroll
+    for (uint32_t j = 0; j < 7; ++j) {
+        uint32_t x = r[j];
+        x = (j == (cold >> 2)) ? (x & mold) : x;
+        x = (j == (cnew >> 2)) ? ((x & mnew) | vnew) : x;
+        r[j] = x;
+    }
+}
+
+// ---- row encoders ----------------------------------------------------------------------
+// 54 mask bits -> 54 bytes of 0/1 (14 dwords; bytes 54,55 are zero)
+__device__ __forceinline__ void mask_row(uint64_t m, uint32_t (&d)[14])
+{
+    uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+        uint32_t nib = ((j < 8 ? lo : hi) >> (4 * (j & 7))) & 0xFu;
+        d[j] = __umul24(nib, 0x00204081u) & 0x01010101u;  // bit i -> byte i
+    }
+}
+
+// raw_env.observe, gobblet.py:179-208: obs[pos][ch], int8[9][13], as 30 dwords.
+//   ch 0..5 : cell(level ch/2, pos) == +(ch+1) seen from the observer (own pieces)
+//   ch 6..11: cell(level (ch-6)/2, pos) == -(ch-5)                     (opponent's)
+//   ch 12   : the observer's agent index
+__device__ __forceinline__ void obs_row(const Planes &p, int observer, uint32_t (&d)[30])
+{
+    uint32_t pos = p.nz & ~p.neg, ngv = p.nz & p.neg;
+    uint32_t own = observer ? ngv : pos, opp = observer ? pos : ngv;
+    uint32_t A = own & p.odd, B = own & ~p.odd, C = opp & p.odd, D = opp & ~p.odd;
+    uint32_t ob = observer ? 1u : 0u;
+#pragma unroll
+    for (int j = 0; j < 30; ++j) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            int idx = 4 * j + b;
+            if (idx >= kObs) break;
+            int ps = idx / 13, ch = idx % 13;
+            uint32_t bitv;
+            if (ch == 12) {
+                bitv = ob;
+            } else {
+                int k = (ch % 6) / 2;
+                uint32_t src = (ch < 6) ? ((ch & 1) ? B : A) : ((ch & 1) ? D : C);
+                bitv = (src >> (9 * k + ps)) & 1u;
+            }
+            w |= bitv << (8 * b);
+        }
+        d[j] = w;
+    }
+}
+
+// Board.get_flatboard, board.py:159-177: signed piece number of the top piece per
+// square, as a 9-byte row in 3 dwords.
+__device__ __forceinline__ void flat_row(const Planes &p, const uint32_t (&r)[7], uint32_t (&d)[3])
+{
+    uint32_t o1 = (p.nz >> 9) & 0x1FFu, o2 = (p.nz >> 18) & 0x1FFu;
+    d[0] = d[1] = d[2] = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        uint32_t b0 = (r[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+        uint32_t b1 = (r[(9 + q) >> 2] >> (8 * ((9 + q) & 3))) & 0xFFu;
+        uint32_t b2 = (r[(18 + q) >> 2] >> (8 * ((18 + q) & 3))) & 0xFFu;
+        uint32_t v = ((o2 >> q) & 1u) ? b2 : (((o1 >> q) & 1u) ? b1 : b0);
+        d[q >> 2] |= v << (8 * (q & 3));
+    }
+}
+
+// Board.check_covered, board.py:203-220: 27 bytes of 0/1 in 7 dwords.
+__device__ __forceinline__ void covered_row(const Planes &p, uint32_t (&d)[7])
+{
+    uint32_t o0 = p.nz & 0x1FFu, o1 = (p.nz >> 9) & 0x1FFu, o2 = (p.nz >> 18) & 0x1FFu;
+    uint32_t cov = (o0 & (o1 | o2)) | ((o1 & o2) << 9);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) d[j] = __umul24((cov >> (4 * j)) & 0xFu, 0x00204081u) & 0x01010101u;
+}
+
+// ---- Philox4x32-10 (Salmon et al., SC'11); known answers are checked in tests/ ---------------
+__device__ __forceinline__ uint32_t philox_first(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                 uint32_t k1)
+{
+#pragma unroll
+    for (int rnd = 0; rnd < 10; ++rnd) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+// index of the k-th (0-based) set bit of w; k < popcount(w)
+__device__ __forceinline__ uint32_t kth_bit32(uint32_t w, uint32_t k)
+{
+    uint32_t pos = 0;
+#pragma unroll
+    for (int s = 16; s >= 1; s >>= 1) {
+        uint32_t c = __popc(w & ((1u << s) - 1u));
+        bool up = k >= c;
+        k = up ? k - c : k;
+        w = up ? (w >> s) : w;
+        pos += up ? s : 0;
+    }
+    return pos;
+}
+
+// masked-uniform draw (see gbl_sample in include/gobblet_hip.h); -1 if m == 0
+__device__ __forceinline__ int sample54(uint64_t m, uint64_t seed, uint64_t env_id, uint32_t ply)
+{
+    uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+    uint32_t nlo = __popc(lo), n = nlo + __popc(hi);
+    uint32_t r = philox_first((uint32_t)env_id, (uint32_t)(env_id >> 32), ply, 0u, (uint32_t)seed,
+                              (uint32_t)(seed >> 32));
+    uint32_t k = __umulhi(r, n);
+    int a = (k < nlo) ? (int)kth_bit32(lo, k) : 32 + (int)kth_bit32(hi, k - nlo);
+    return n ? a : -1;
+}
+
+// ---- one ply of one board: raw_env.step bookkeeping, gobblet.py:231-271 -------------------
+constexpr int kIllegalNoop = 0;       // GBL_ILLEGAL_NOOP
+constexpr int kIllegalTerminate = 1;  // GBL_ILLEGAL_TERMINATE
+
+struct Ply {
+    int winner;     // check_for_winner() after the move
+    int r0, r1;     // rewards of player_1 / player_2 for this step
+    bool terminal;  // the episode ended on this step
+};
+
+__device__ __forceinline__ Ply play_ply(Planes &p, uint32_t (&r)[7], int &mover, uint64_t legal, int action,
+                                        int illegal_mode)
+{
+    Ply y{0, 0, 0, false};
+    bool ok = (uint32_t)action < (uint32_t)kActions && ((legal >> (action & 63)) & 1ull);
+    if (!ok && illegal_mode == kIllegalTerminate) {
+        // gobblet.py:50-51, :114: mover -1, the other 0, everyone terminated, board untouched
+        y.r0 = mover ? 0 : -1;
+        y.r1 = mover ? -1 : 0;
+        y.terminal = true;
+        return y;
+    }
+    if (ok) apply_move(p, r, mover, (uint32_t)action);  // gobblet.py:244 (illegal: silent no-op, board.py:125-126)
+    mover ^= 1;                                          // gobblet.py:246,267
+    y.winner = winner_of(p);                             // gobblet.py:248-249
+    y.r0 = y.winner;                                     // gobblet.py:253-260
+    y.r1 = -y.winner;
+    y.terminal = y.winner != 0;                          // gobblet.py:263
+    return y;
+}
+
+// Lane body of gbl_step: raw_env.step + the state the next observe() is taken from.
+// In: r / p (planes of r) / mover / was_done / action.  Out: r, p (after the step), mover, dn, y.
+__device__ __forceinline__ void step_lane(uint32_t (&r)[7], Planes &p, int &mover, int was_done, int action,
+                                          int illegal_mode, int auto_reset, int &dn, Ply &y)
+{
+    y = Ply{0, 0, 0, false};
+    dn = was_done;
+    if (was_done) {
+        y.winner = winner_of(p);  // frozen board (reference: _was_dead_step, gobblet.py:232-236): standing result
+    } else {
+        y = play_ply(p, r, mover, legal54(p, mover), action, illegal_mode);
+        dn = y.terminal ? 1 : 0;
+        if (y.terminal && auto_reset) {  // raw_env.reset, gobblet.py:275-290
+            p = Planes{0u, 0u, 0u};
+            mover = 0;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) r[j] = 0;
+        }
+    }
+}
+
+// gobblet.py:209: the mask belongs to the agent to move; a frozen board has nobody to move
+__device__ __forceinline__ uint64_t next_mask(const Planes &p, int mover, int dn, int auto_reset)
+{
+    return (dn && !auto_reset) ? 0ull : legal54(p, mover);
+}
+
+// 54 mask bytes (14 dwords, row_load order) -> 54 bits
+__device__ __forceinline__ uint64_t mask_bits(const uint32_t (&d)[14])
+{
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 14; j += 2) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            uint32_t x = d[j + u];
+            if (j + u == 13) x &= 0x0000FFFFu;
+            uint32_t t = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+            acc = __builtin_amdgcn_udot4(t, u ? 0x80402010u : 0x08040201u, acc, false);
+        }
+        uint32_t bits8 = acc >> 7;
+        if (j < 8) lo |= bits8 << (4 * j);
+        else hi |= bits8 << (4 * (j - 8));
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// GreedyGobbletPolicy board decode, greedy_policy.py:43-71: 117 obs bytes -> 27 state bytes + agent index
+__device__ __forceinline__ int decode_obs_row(const uint32_t (&d)[30], uint32_t (&r)[7])
+{
+    auto ob = [&](int idx) -> int { return (int)(int8_t)((d[idx >> 2] >> (8 * (idx & 3))) & 0xFFu); };
+    int agent = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) agent = ob(13 * q + 12) > agent ? ob(13 * q + 12) : agent;  // obs[...,12].max()
+#pragma unroll
+    for (int j = 0; j < 7; ++j) r[j] = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            int i = 2 * k;
+            int bp = (i + 1) * ob(13 * q + i) + (i + 2) * ob(13 * q + i + 1);          // :44-49
+            int bo = (i + 1) * ob(13 * q + 6 + i) + (i + 2) * ob(13 * q + 6 + i + 1);  // :50-56
+            int v = bp > bo ? bp : -bo;                                                // :57
+            if (agent == 1) v = -v;                                                    // :67-68
+            int c = 9 * k + q;
+            r[c >> 2] |= ((uint32_t)v & 0xFFu) << (8 * (c & 3));
+        }
+    return agent;
+}
+
+// ---- GreedyGobbletPolicy.compute_action, greedy_policy.py:38-221 (depth 1 / 2) ----------------
+// planes-only form of apply_move (no byte row to maintain)
+__device__ __forceinline__ Planes moved(const Planes &p0, int mover, uint32_t a)
+{
+    Planes p = p0;
+    uint32_t pi = (a * 57u) >> 9, q = a - 9u * pi, k = pi >> 1, first = (~pi) & 1u;
+    uint32_t mine = mover ? (p.nz & p.neg) : (p.nz & ~p.neg);
+    uint32_t ploc = mine & (first ? p.odd : ~p.odd) & (0x1FFu << (9u * k));
+    uint32_t bit = 1u << (9u * k + q);
+    p.nz = (p.nz & ~ploc) | bit;
+    p.neg = (p.neg & ~ploc & ~bit) | (mover ? bit : 0u);
+    p.odd = (p.odd & ~ploc & ~bit) | (first ? bit : 0u);
+    return p;
+}
+
+struct GreedyResult {
+    int chosen;      // chosen_action just before the fallback test (:211), -1 = None
+    uint64_t cands;  // actions_depth1 as a 54-bit set
+    bool fallback;   // the reference would call np.random.choice(actions_depth1)
+};
+
+// One decision for the agent `me` on board p.  `mask` is the legal mask handed to the policy
+// (greedy_policy.py:76), prev3 the agent's last three actions packed one per byte (0xFF = none).
+// Sequential restatement of the reference's control flow over bit planes: the depth-1 loop
+// (:84-101), the depth-2 loop with its order-dependent pruning (:103-157) and the fallback test
+// (:211-214).
+__device__ __forceinline__ GreedyResult greedy_decide(const Planes &p, int me, uint64_t mask, int depth, uint32_t prev3)
+{
+    const int opp = 1 - me;
+    const int w_me = me ? -1 : 1, w_opp = -w_me;  // winner_values, :74
+    uint64_t cands = mask;                        // actions_depth1, :77-79
+    int ncands = __popcll(mask);
+    int chosen = -1;
+    uint64_t legal_me = legal54(p, me);           // board.is_legal(agent_index, a), :85 and :141
+    uint64_t res_zero = 0;                        // keys of `results` whose value is 0, insertion = ascending order
+    // depth 1, :84-101
+    for (uint64_t it = mask & legal_me; it;) {
+        int a = __builtin_ctzll(it);
+        it &= it - 1;
+        int r = winner_of(moved(p, me, (uint32_t)a));
+        if (r == 0) res_zero |= 1ull << a;
+        if (r == w_me) {
+            chosen = a;
+            break;
+        } else if (r == w_opp) {
+            if (ncands > 1) {
+                cands &= ~(1ull << a);
+                --ncands;
+            } else
+                break;
+        }
+    }
+    if (depth > 1) {  // :103-157
+        for (uint64_t it = res_zero; it;) {
+            int a = __builtin_ctzll(it);
+            it &= it - 1;
+            Planes d1 = moved(p, me, (uint32_t)a);
+            bool all_me = true, none_opp = true;
+            for (uint64_t it2 = legal54(d1, opp); it2;) {  // :112-116
+                int a2 = __builtin_ctzll(it2);
+                it2 &= it2 - 1;
+                int r2 = winner_of(moved(d1, opp, (uint32_t)a2));  // :120-126
+                all_me = all_me && (r2 == w_me);
+                none_opp = none_opp && (r2 != w_opp);
+                if (r2 == w_opp) {  // :129-143
+                    if (ncands > 1) {
+                        if ((cands >> a) & 1ull) {
+                            cands &= ~(1ull << a);
+                            --ncands;
+                        }
+                    } else
+                        break;
+                    if (((legal_me >> a2) & 1ull) && chosen < 0) chosen = a2;
+                }
+            }
+            if (all_me) {  // :146-151
+                chosen = a;
+                break;
+            }
+            if (none_opp) chosen = a;  // :153-157
+        }
+    }
+    bool fb = chosen < 0;  // :211-214
+    fb = fb || (chosen >= 0 && ((prev3 & 0xFFu) == (uint32_t)chosen || ((prev3 >> 8) & 0xFFu) == (uint32_t)chosen ||
+                                ((prev3 >> 16) & 0xFFu) == (uint32_t)chosen));
+    return GreedyResult{chosen, cands, fb};
+}
+
+}  // namespace gbl

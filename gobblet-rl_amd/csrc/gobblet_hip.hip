@@ -1,0 +1,604 @@
+// gobblet_hip.hip -- gfx950 kernels + the C-ABI of include/gobblet_hip.h.
+// Building blocks and the execution shape are described in gobblet_device.h.
+#include "gobblet_device.h"
+
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gobblet_hip.h"
+
+using namespace gbl;
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char *msg)
+{
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    return GBL_ERR_HIP;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+struct Geometry {
+    int64_t ntiles;
+    uint32_t grid;
+};
+
+inline Geometry geometry(int64_t n)
+{
+    Geometry g;
+    g.ntiles = (n + kTile - 1) / kTile;
+    int64_t chunk = (g.ntiles + 7) / 8;
+    g.grid = (uint32_t)(chunk * 8);
+    return g;
+}
+
+// LDS words for a tile image of ROWB-byte rows (+ slack for row_load's look-ahead dword)
+template <int ROWB>
+constexpr int image_words() { return kTile * ROWB / 4 + 4; }
+
+// -------------------------------------------------------------------------------------------
+// Per-lane state of one board inside a kernel.
+struct Lane {
+    int64_t tile, b;
+    int lane, rows;
+    bool valid;
+};
+
+__device__ __forceinline__ bool lane_setup(Lane &L, int64_t n, int64_t ntiles)
+{
+    L.tile = xcd_tile(blockIdx.x, ntiles);
+    if (L.tile >= ntiles) return false;
+    L.lane = threadIdx.x;
+    int64_t left = n - L.tile * kTile;
+    L.rows = left < kTile ? (int)left : kTile;
+    L.valid = L.lane < L.rows;
+    L.b = L.tile * kTile + L.lane;
+    return true;
+}
+
+__device__ __forceinline__ void load_state(const int8_t *state, uint32_t *img, const Lane &L, uint32_t (&r)[7])
+{
+    tile_in<kCells>(state + L.tile * (kTile * kCells), img, L.lane, L.rows);
+    __syncthreads();
+    row_load<kCells>(img, L.lane, r);
+    r[6] &= 0x00FFFFFFu;
+    if (!L.valid) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) r[j] = 0;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// Board-level kernels (one reference function each)
+
+__global__ __launch_bounds__(64) void k_legal_mask(const int8_t *__restrict__ state, const int8_t *__restrict__ to_move,
+                                                   int8_t *__restrict__ mask, int64_t n, int64_t ntiles)
+{
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    __shared__ uint32_t s_mask[image_words<kActions>()];
+    Lane L;
+    if (!lane_setup(L, n, ntiles)) return;
+    uint32_t r[7];
+    load_state(state, s_state, L, r);
+    Planes p = make_planes(r);
+    int mover = L.valid ? to_move[L.b] : 0;
+    uint32_t d[14];
+    mask_row(legal54(p, mover != 0), d);
+    row_stage<kActions>(s_mask, L.lane, d);
+    __syncthreads();
+    tile_out<kActions>(mask + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
+}
+
+__global__ __launch_bounds__(64) void k_is_legal(const int8_t *__restrict__ state, const int8_t *__restrict__ agent,
+                                                 const int32_t *__restrict__ actions, int8_t *__restrict__ out,
+                                                 int64_t n, int64_t ntiles)
+{
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    Lane L;
+    if (!lane_setup(L, n, ntiles)) return;
+    uint32_t r[7];
+    load_state(state, s_state, L, r);
+    if (!L.valid) return;
+    Planes p = make_planes(r);
+    int a = actions[L.b];
+    uint64_t m = legal54(p, agent[L.b] != 0);
+    bool ok = (uint32_t)a < (uint32_t)kActions && ((m >> (a & 63)) & 1ull);
+    out[L.b] = ok ? 1 : 0;
+}
+
+__global__ __launch_bounds__(64) void k_play_turn(int8_t *__restrict__ state, const int8_t *__restrict__ agent,
+                                                  const int32_t *__restrict__ actions, int64_t n, int64_t ntiles)
+{
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    Lane L;
+    if (!lane_setup(L, n, ntiles)) return;
+    uint32_t r[7];
+    load_state(state, s_state, L, r);
+    Planes p = make_planes(r);
+    int a = L.valid ? actions[L.b] : 0;
+    int mover = L.valid ? (agent[L.b] != 0) : 0;
+    uint64_t m = legal54(p, mover);
+    bool ok = L.valid && (uint32_t)a < (uint32_t)kActions && ((m >> (a & 63)) & 1ull);
+    if (ok) apply_move(p, r, mover, (uint32_t)a);
+    row_stage<kCells>(s_state, L.lane, r);
+    __syncthreads();
+    tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
+}
+
+__global__ __launch_bounds__(64) void k_winner(const int8_t *__restrict__ state, int8_t *__restrict__ winner, int64_t n,
+                                               int64_t ntiles)
+{
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    Lane L;
+    if (!lane_setup(L, n, ntiles)) return;
+    uint32_t r[7];
+    load_state(state, s_state, L, r);
+    if (!L.valid) return;
+    winner[L.b] = (int8_t)winner_of(make_planes(r));
+}
+
+__global__ __launch_bounds__(64) void k_flatboard(const int8_t *__restrict__ state, int8_t *__restrict__ flat, int64_t n,
+                                                  int64_t ntiles)
+{
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    __shared__ uint32_t s_flat[image_words<9>()];
+    Lane L;
+    if (!lane_setup(L, n, ntiles)) return;
+    uint32_t r[7];
+    load_state(state, s_state, L, r);
+    uint32_t d[3];
+    flat_row(make_planes(r), r, d);
+    row_stage<9>(s_flat, L.lane, d);
+    __syncthreads();
+    tile_out<9>(flat + L.tile * (kTile * 9), s_flat, L.lane, L.rows);
+}
+
+__global__ __launch_bounds__(64) void k_covered(const int8_t *__restrict__ state, int8_t *__restrict__ cov, int64_t n,
+                                                int64_t ntiles)
+{
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    Lane L;
+    if (!lane_setup(L, n, ntiles)) return;
+    uint32_t r[7];
+    load_state(state, s_state, L, r);
+    uint32_t d[7];
+    covered_row(make_planes(r), d);
+    __syncthreads();  // every lane has read its row before the image is reused
+    row_stage<kCells>(s_state, L.lane, d);
+    __syncthreads();
+    tile_out<kCells>(cov + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
+}
+
+__global__ __launch_bounds__(64) void k_observe(const int8_t *__restrict__ state, const int8_t *__restrict__ to_move,
+                                                int agent_sel, int8_t *__restrict__ obs, int64_t n, int64_t ntiles)
+{
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    __shared__ uint32_t s_obs[image_words<kObs>()];
+    Lane L;
+    if (!lane_setup(L, n, ntiles)) return;
+    uint32_t r[7];
+    load_state(state, s_state, L, r);
+    int who = agent_sel >= 0 ? agent_sel : (L.valid ? to_move[L.b] : 0);
+    uint32_t d[30];
+    obs_row(make_planes(r), who != 0, d);
+    row_stage<kObs>(s_obs, L.lane, d);
+    __syncthreads();
+    tile_out<kObs>(obs + L.tile * (kTile * kObs), s_obs, L.lane, L.rows);
+}
+
+// gbl_step: fused raw_env.step + observe(next mover) over a tile of boards.
+template <bool WITH_MASK, bool WITH_OBS>
+__global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t *__restrict__ to_move,
+                                             int8_t *__restrict__ done, const int32_t *__restrict__ actions,
+                                             int8_t *__restrict__ winner_out, int8_t *__restrict__ reward_out,
+                                             int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out, int64_t n,
+                                             int64_t ntiles, int illegal_mode, int auto_reset)
+{
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    __shared__ uint32_t s_mask[WITH_MASK ? image_words<kActions>() : 4];
+    __shared__ uint32_t s_obs[WITH_OBS ? image_words<kObs>() : 4];
+    Lane L;
+    if (!lane_setup(L, n, ntiles)) return;
+    uint32_t r[7];
+    load_state(state, s_state, L, r);
+    int mover = 0, was_done = 0, action = 0;
+    if (L.valid) {
+        mover = to_move[L.b] != 0;
+        was_done = auto_reset ? 0 : (done[L.b] != 0);
+        action = actions[L.b];
+    }
+    Planes p = make_planes(r);
+    Ply y;
+    int dn;
+    step_lane(r, p, mover, was_done, action, illegal_mode, auto_reset, dn, y);
+    row_stage<kCells>(s_state, L.lane, r);
+    if (WITH_MASK) {
+        uint32_t d[14];
+        mask_row(next_mask(p, mover, dn, auto_reset), d);
+        row_stage<kActions>(s_mask, L.lane, d);
+    }
+    if (WITH_OBS) {
+        uint32_t d[30];
+        obs_row(p, mover, d);
+        row_stage<kObs>(s_obs, L.lane, d);
+    }
+    __syncthreads();
+    tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
+    if (WITH_MASK) tile_out<kActions>(mask_out + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
+    if (WITH_OBS) tile_out<kObs>(obs_out + L.tile * (kTile * kObs), s_obs, L.lane, L.rows);
+    if (L.valid) {
+        to_move[L.b] = (int8_t)mover;
+        done[L.b] = (int8_t)dn;
+        if (winner_out) winner_out[L.b] = (int8_t)y.winner;
+        if (reward_out)
+            reinterpret_cast<uint16_t *>(reward_out)[L.b] = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
+    }
+}
+
+// gbl_rollout: `plies` masked-random plies per launch, state in registers between plies.
+template <bool EVERY_PLY>
+__global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8_t *__restrict__ to_move,
+                                                int8_t *__restrict__ done, int32_t *__restrict__ actions_out,
+                                                int8_t *__restrict__ winner_out, int8_t *__restrict__ reward_out,
+                                                int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out, int64_t n,
+                                                int64_t ntiles, uint64_t seed, uint64_t env_base, uint32_t ply0,
+                                                uint32_t plies, int illegal_mode, int64_t *__restrict__ counters)
+{
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    __shared__ uint32_t s_mask[image_words<kActions>()];
+    __shared__ uint32_t s_obs[image_words<kObs>()];
+    Lane L;
+    if (!lane_setup(L, n, ntiles)) return;
+    uint32_t r[7];
+    load_state(state, s_state, L, r);
+    int mover = L.valid ? (to_move[L.b] != 0) : 0;
+    Planes p = make_planes(r);
+    uint32_t games = 0, w1 = 0, w2 = 0;  // wave-uniform tallies (ballot + popcount)
+    Ply y{0, 0, 0, false};
+    int dn = 0, action = -1;
+    for (uint32_t t = 0; t < plies; ++t) {
+        uint64_t legal = legal54(p, mover);
+        action = sample54(legal, seed, env_base + (uint64_t)L.b, ply0 + t);
+        step_lane(r, p, mover, 0, action, illegal_mode, 1, dn, y);
+        games += __popcll(__ballot(L.valid && y.terminal));
+        w1 += __popcll(__ballot(L.valid && y.winner == 1));
+        w2 += __popcll(__ballot(L.valid && y.winner == -1));
+        if (EVERY_PLY || t + 1 == plies) {
+            __syncthreads();  // the previous ply's tile_out reads are issued before the images are rewritten
+            row_stage<kCells>(s_state, L.lane, r);
+            if (mask_out) {
+                uint32_t d[14];
+                mask_row(legal54(p, mover), d);
+                row_stage<kActions>(s_mask, L.lane, d);
+            }
+            if (obs_out) {
+                uint32_t d[30];
+                obs_row(p, mover, d);
+                row_stage<kObs>(s_obs, L.lane, d);
+            }
+            __syncthreads();
+            tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
+            if (mask_out) tile_out<kActions>(mask_out + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
+            if (obs_out) tile_out<kObs>(obs_out + L.tile * (kTile * kObs), s_obs, L.lane, L.rows);
+            if (L.valid) {
+                to_move[L.b] = (int8_t)mover;
+                done[L.b] = (int8_t)dn;
+                if (actions_out) actions_out[L.b] = action;
+                if (winner_out) winner_out[L.b] = (int8_t)y.winner;
+                if (reward_out)
+                    reinterpret_cast<uint16_t *>(reward_out)[L.b] = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
+            }
+        }
+    }
+    if (counters && L.lane == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(counters + 0), (unsigned long long)L.rows * plies);
+        atomicAdd(reinterpret_cast<unsigned long long *>(counters + 1), (unsigned long long)games);
+        atomicAdd(reinterpret_cast<unsigned long long *>(counters + 2), (unsigned long long)w1);
+        atomicAdd(reinterpret_cast<unsigned long long *>(counters + 3), (unsigned long long)w2);
+    }
+}
+
+// gbl_sample: mask rows -> one action per board
+__global__ __launch_bounds__(64) void k_sample(const int8_t *__restrict__ mask, int32_t *__restrict__ actions, int64_t n,
+                                               int64_t ntiles, uint64_t seed, uint64_t env_base, uint32_t ply)
+{
+    __shared__ uint32_t s_mask[image_words<kActions>()];
+    Lane L;
+    if (!lane_setup(L, n, ntiles)) return;
+    tile_in<kActions>(mask + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
+    __syncthreads();
+    uint32_t d[14];
+    row_load<kActions>(s_mask, L.lane, d);
+    if (!L.valid) return;
+    uint64_t m = mask_bits(d);
+    actions[L.b] = sample54(m, seed, env_base + (uint64_t)L.b, ply);
+}
+
+// gbl_decode_obs: greedy_policy.py:43-71
+__global__ __launch_bounds__(64) void k_decode_obs(const int8_t *__restrict__ obs, int8_t *__restrict__ state,
+                                                   int8_t *__restrict__ to_move, int64_t n, int64_t ntiles)
+{
+    __shared__ uint32_t s_obs[image_words<kObs>()];
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    Lane L;
+    if (!lane_setup(L, n, ntiles)) return;
+    tile_in<kObs>(obs + L.tile * (kTile * kObs), s_obs, L.lane, L.rows);
+    __syncthreads();
+    uint32_t d[30];
+    row_load<kObs>(s_obs, L.lane, d);
+    uint32_t r[7];
+    int agent = decode_obs_row(d, r);
+    row_stage<kCells>(s_state, L.lane, r);
+    __syncthreads();
+    tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
+    if (L.valid) to_move[L.b] = (int8_t)agent;
+}
+
+// gbl_greedy: one decision per board (first version: one board per lane, sequential search)
+__global__ __launch_bounds__(64) void k_greedy(const int8_t *__restrict__ state, const int8_t *__restrict__ to_move,
+                                               const int8_t *__restrict__ mask_in, const int8_t *__restrict__ hist,
+                                               int depth, int32_t *__restrict__ action_out,
+                                               int8_t *__restrict__ cand_out, int8_t *__restrict__ fallback_out,
+                                               int64_t n, int64_t ntiles)
+{
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    __shared__ uint32_t s_mask[image_words<kActions>()];
+    Lane L;
+    if (!lane_setup(L, n, ntiles)) return;
+    uint32_t r[7];
+    load_state(state, s_state, L, r);
+    Planes p = make_planes(r);
+    int me = L.valid ? (to_move[L.b] != 0) : 0;
+    uint64_t mask;
+    if (mask_in) {
+        tile_in<kActions>(mask_in + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
+        __syncthreads();
+        uint32_t d[14];
+        row_load<kActions>(s_mask, L.lane, d);
+        mask = mask_bits(d);
+        __syncthreads();
+    } else {
+        mask = legal54(p, me);
+    }
+    if (!L.valid) mask = 0;
+    uint32_t prev3 = 0x00FFFFFFu;
+    if (hist && L.valid) {
+        const int8_t *h = hist + (L.b * 2 + me) * 3;
+        prev3 = (uint32_t)(uint8_t)h[0] | ((uint32_t)(uint8_t)h[1] << 8) | ((uint32_t)(uint8_t)h[2] << 16);
+    }
+    GreedyResult g = greedy_decide(p, me, mask, depth, prev3);
+    if (cand_out) {
+        uint32_t d[14];
+        mask_row(g.cands, d);
+        row_stage<kActions>(s_mask, L.lane, d);
+        __syncthreads();
+        tile_out<kActions>(cand_out + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
+    }
+    if (L.valid) {
+        action_out[L.b] = g.fallback ? -1 : g.chosen;
+        if (fallback_out) fallback_out[L.b] = g.fallback ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+// ===========================================================================================
+// C-ABI
+
+#define GBL_CHECK_N(n)                                      \
+    do {                                                    \
+        if ((n) < 0) return fail(GBL_ERR_ARG, "n < 0");     \
+        if ((n) == 0) return GBL_OK;                        \
+    } while (0)
+#define GBL_NEED(p, name)                                                 \
+    do {                                                                  \
+        if (!(p)) return fail(GBL_ERR_ARG, name " must not be NULL");     \
+    } while (0)
+#define GBL_ALIGNED(p, name)                                                                   \
+    do {                                                                                       \
+        if ((p) && !aligned16(p)) return fail(GBL_ERR_ALIGN, name " must be 16-byte aligned"); \
+    } while (0)
+#define GBL_LAUNCHED(name)                                   \
+    do {                                                     \
+        hipError_t e_ = hipGetLastError();                   \
+        if (e_ != hipSuccess) return hip_fail(e_, name);     \
+        return GBL_OK;                                       \
+    } while (0)
+
+extern "C" {
+
+const char *gbl_last_error(void) { return g_err; }
+
+int gbl_layout_info(int32_t out[6])
+{
+    if (!out) return fail(GBL_ERR_ARG, "out must not be NULL");
+    out[0] = 1; out[1] = kCells; out[2] = kActions; out[3] = kObs; out[4] = kTile; out[5] = 16;
+    return GBL_OK;
+}
+
+int gbl_reset(int8_t *state, int8_t *to_move, int8_t *done, int8_t *winner, int64_t n, void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if ((e = hipMemsetAsync(state, 0, (size_t)n * kCells, s)) != hipSuccess) return hip_fail(e, "gbl_reset");
+    if ((e = hipMemsetAsync(to_move, 0, (size_t)n, s)) != hipSuccess) return hip_fail(e, "gbl_reset");
+    if ((e = hipMemsetAsync(done, 0, (size_t)n, s)) != hipSuccess) return hip_fail(e, "gbl_reset");
+    if (winner && (e = hipMemsetAsync(winner, 0, (size_t)n, s)) != hipSuccess) return hip_fail(e, "gbl_reset");
+    return GBL_OK;
+}
+
+int gbl_legal_mask(const int8_t *state, const int8_t *to_move, int8_t *mask, int64_t n, void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(mask, "mask");
+    GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask, "mask");
+    Geometry g = geometry(n);
+    hipLaunchKernelGGL(k_legal_mask, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, state, to_move, mask, n, g.ntiles);
+    GBL_LAUNCHED("gbl_legal_mask");
+}
+
+int gbl_is_legal(const int8_t *state, const int8_t *agent_index, const int32_t *actions, int8_t *out, int64_t n,
+                 void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(agent_index, "agent_index"); GBL_NEED(actions, "actions"); GBL_NEED(out, "out");
+    GBL_ALIGNED(state, "state");
+    Geometry g = geometry(n);
+    hipLaunchKernelGGL(k_is_legal, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, state, agent_index, actions, out, n,
+                       g.ntiles);
+    GBL_LAUNCHED("gbl_is_legal");
+}
+
+int gbl_play_turn(int8_t *state, const int8_t *agent_index, const int32_t *actions, int64_t n, void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(agent_index, "agent_index"); GBL_NEED(actions, "actions");
+    GBL_ALIGNED(state, "state");
+    Geometry g = geometry(n);
+    hipLaunchKernelGGL(k_play_turn, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, state, agent_index, actions, n,
+                       g.ntiles);
+    GBL_LAUNCHED("gbl_play_turn");
+}
+
+int gbl_winner(const int8_t *state, int8_t *winner, int64_t n, void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(winner, "winner");
+    GBL_ALIGNED(state, "state");
+    Geometry g = geometry(n);
+    hipLaunchKernelGGL(k_winner, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, state, winner, n, g.ntiles);
+    GBL_LAUNCHED("gbl_winner");
+}
+
+int gbl_flatboard(const int8_t *state, int8_t *flat, int64_t n, void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(flat, "flat");
+    GBL_ALIGNED(state, "state"); GBL_ALIGNED(flat, "flat");
+    Geometry g = geometry(n);
+    hipLaunchKernelGGL(k_flatboard, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, state, flat, n, g.ntiles);
+    GBL_LAUNCHED("gbl_flatboard");
+}
+
+int gbl_covered(const int8_t *state, int8_t *cov, int64_t n, void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(cov, "cov");
+    GBL_ALIGNED(state, "state"); GBL_ALIGNED(cov, "cov");
+    Geometry g = geometry(n);
+    hipLaunchKernelGGL(k_covered, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, state, cov, n, g.ntiles);
+    GBL_LAUNCHED("gbl_covered");
+}
+
+int gbl_observe(const int8_t *state, const int8_t *to_move, int agent_sel, int8_t *obs, int64_t n, void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(obs, "obs");
+    if (agent_sel < -1 || agent_sel > 1) return fail(GBL_ERR_ARG, "agent_sel must be -1, 0 or 1");
+    if (agent_sel < 0) GBL_NEED(to_move, "to_move (agent_sel == -1)");
+    GBL_ALIGNED(state, "state"); GBL_ALIGNED(obs, "obs");
+    Geometry g = geometry(n);
+    hipLaunchKernelGGL(k_observe, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, state, to_move, agent_sel, obs, n,
+                       g.ntiles);
+    GBL_LAUNCHED("gbl_observe");
+}
+
+int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out,
+             int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, int illegal_mode, int auto_reset,
+             void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done"); GBL_NEED(actions, "actions");
+    if (illegal_mode != GBL_ILLEGAL_NOOP && illegal_mode != GBL_ILLEGAL_TERMINATE)
+        return fail(GBL_ERR_ARG, "illegal_mode must be GBL_ILLEGAL_NOOP or GBL_ILLEGAL_TERMINATE");
+    GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask_out, "mask_out"); GBL_ALIGNED(obs_out, "obs_out");
+    if (reward_out && (reinterpret_cast<uintptr_t>(reward_out) & 1u))
+        return fail(GBL_ERR_ALIGN, "reward_out must be 2-byte aligned");
+    Geometry g = geometry(n);
+    hipStream_t s = (hipStream_t)stream;
+    auto_reset = auto_reset != 0;
+#define GBL_STEP(M, O)                                                                                              \
+    hipLaunchKernelGGL((k_step<M, O>), dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions, winner_out,     \
+                       reward_out, mask_out, obs_out, n, g.ntiles, illegal_mode, auto_reset)
+    if (mask_out && obs_out) GBL_STEP(true, true);
+    else if (mask_out) GBL_STEP(true, false);
+    else if (obs_out) GBL_STEP(false, true);
+    else GBL_STEP(false, false);
+#undef GBL_STEP
+    GBL_LAUNCHED("gbl_step");
+}
+
+int gbl_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply,
+               void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(mask, "mask"); GBL_NEED(actions, "actions");
+    GBL_ALIGNED(mask, "mask");
+    Geometry g = geometry(n);
+    hipLaunchKernelGGL(k_sample, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, mask, actions, n, g.ntiles, seed,
+                       env_base, ply);
+    GBL_LAUNCHED("gbl_sample");
+}
+
+int gbl_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_out, int8_t *winner_out,
+                int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, uint64_t seed, uint64_t env_base,
+                uint32_t ply0, uint32_t plies, int illegal_mode, int every_ply, int64_t *counters, void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done");
+    if (illegal_mode != GBL_ILLEGAL_NOOP && illegal_mode != GBL_ILLEGAL_TERMINATE)
+        return fail(GBL_ERR_ARG, "illegal_mode must be GBL_ILLEGAL_NOOP or GBL_ILLEGAL_TERMINATE");
+    if (plies == 0) return GBL_OK;
+    GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask_out, "mask_out"); GBL_ALIGNED(obs_out, "obs_out");
+    if (reward_out && (reinterpret_cast<uintptr_t>(reward_out) & 1u))
+        return fail(GBL_ERR_ALIGN, "reward_out must be 2-byte aligned");
+    if (counters && (reinterpret_cast<uintptr_t>(counters) & 7u))
+        return fail(GBL_ERR_ALIGN, "counters must be 8-byte aligned");
+    Geometry g = geometry(n);
+    hipStream_t s = (hipStream_t)stream;
+    if (every_ply)
+        hipLaunchKernelGGL(k_rollout<true>, dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions_out, winner_out,
+                           reward_out, mask_out, obs_out, n, g.ntiles, seed, env_base, ply0, plies, illegal_mode,
+                           counters);
+    else
+        hipLaunchKernelGGL(k_rollout<false>, dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions_out,
+                           winner_out, reward_out, mask_out, obs_out, n, g.ntiles, seed, env_base, ply0, plies,
+                           illegal_mode, counters);
+    GBL_LAUNCHED("gbl_rollout");
+}
+
+int gbl_decode_obs(const int8_t *obs, int8_t *state, int8_t *to_move, int64_t n, void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(obs, "obs"); GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move");
+    GBL_ALIGNED(obs, "obs"); GBL_ALIGNED(state, "state");
+    Geometry g = geometry(n);
+    hipLaunchKernelGGL(k_decode_obs, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, obs, state, to_move, n, g.ntiles);
+    GBL_LAUNCHED("gbl_decode_obs");
+}
+
+int gbl_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask, const int8_t *hist, int depth,
+               int32_t *action_out, int8_t *cand_mask_out, int8_t *fallback_out, int64_t n, void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(action_out, "action_out");
+    if (depth != 1 && depth != 2) return fail(GBL_ERR_ARG, "depth must be 1 or 2");
+    GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask, "mask"); GBL_ALIGNED(cand_mask_out, "cand_mask_out");
+    Geometry g = geometry(n);
+    hipLaunchKernelGGL(k_greedy, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, state, to_move, mask, hist, depth,
+                       action_out, cand_mask_out, fallback_out, n, g.ntiles);
+    GBL_LAUNCHED("gbl_greedy");
+}
+
+}  // extern "C"

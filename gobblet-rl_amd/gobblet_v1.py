@@ -1,0 +1,417 @@
+"""``gobblet_v1`` -- the reference's single-environment AEC surface (gobblet_rl/gobblet_v1.py:1-3 re-exports
+``env``, ``parallel_env``, ``raw_env`` of gobblet_rl/game/gobblet.py:110-123) over the HIP engine.
+
+``raw_env`` keeps the reference's attribute names and turn logic (gobblet.py:123-290); its ``board`` is a
+``Board`` with the reference's interface (board.py) whose methods run on the GPU through a 1-board
+``BatchedBoard``.  This is the plumbing configuration (BASELINE.json configs[0]); the throughput path is
+``BatchedGobblet``.  PettingZoo / gymnasium are used when importable; otherwise small structural stand-ins
+with the same attributes are used (they are third-party to the reference too).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .board import BatchedBoard
+
+try:  # pragma: no cover - not installed in the build image
+    from pettingzoo import AECEnv as _AECBase
+    from pettingzoo.utils import wrappers as _pz_wrappers
+    _HAVE_PZ = True
+except Exception:  # noqa: BLE001
+    _HAVE_PZ = False
+
+    class _AECBase:  # structural stand-in for pettingzoo.AECEnv (PettingZoo 1.22.3 semantics)
+        metadata: dict = {}
+
+        def __init__(self):
+            pass
+
+        @property
+        def unwrapped(self):
+            return self
+
+        def _clear_rewards(self):
+            for agent in self.rewards:
+                self.rewards[agent] = 0
+
+        def _accumulate_rewards(self):
+            for agent, reward in self.rewards.items():
+                self._cumulative_rewards[agent] += reward
+
+        def _deads_step_first(self):
+            _deads_order = [a for a in self.agents if (self.terminations[a] or self.truncations[a])]
+            if _deads_order:
+                self._skip_agent_selection = self.agent_selection
+                self.agent_selection = _deads_order[0]
+            return self.agent_selection
+
+        def _was_dead_step(self, action):
+            if action is not None:
+                raise ValueError("when an agent is dead, the only valid action is None")
+            agent = self.agent_selection
+            assert self.terminations[agent] or self.truncations[agent], \
+                "an agent that was not dead as attempted to be removed"
+            del self.terminations[agent], self.truncations[agent], self.rewards[agent]
+            del self._cumulative_rewards[agent], self.infos[agent]
+            self.agents.remove(agent)
+            _deads_order = [a for a in self.agents if (self.terminations[a] or self.truncations[a])]
+            if _deads_order:
+                if getattr(self, "_skip_agent_selection", None) is None:
+                    self._skip_agent_selection = self.agent_selection
+                self.agent_selection = _deads_order[0]
+            else:
+                if getattr(self, "_skip_agent_selection", None) is not None:
+                    self.agent_selection = self._skip_agent_selection
+                self._skip_agent_selection = None
+            self._clear_rewards()
+
+        def agent_iter(self, max_iter=2 ** 63):
+            it = 0
+            while self.agents and it < max_iter:
+                it += 1
+                yield self.agent_selection
+
+        def last(self, observe=True):
+            agent = self.agent_selection
+            observation = self.observe(agent) if observe else None
+            return (observation, self._cumulative_rewards[agent], self.terminations[agent],
+                    self.truncations[agent], self.infos[agent])
+
+        def close(self):
+            pass
+
+try:  # pragma: no cover
+    from gymnasium import spaces as _spaces
+except Exception:  # noqa: BLE001
+    class _Discrete:
+        def __init__(self, n):
+            self.n, self.shape, self.dtype = int(n), (), np.int64
+
+        def contains(self, x):
+            return isinstance(x, (int, np.integer)) and 0 <= int(x) < self.n
+
+        def sample(self, mask=None):
+            if mask is not None:
+                return int(np.random.choice(np.flatnonzero(mask)))
+            return int(np.random.randint(self.n))
+
+        def __repr__(self):
+            return f"Discrete({self.n})"
+
+    class _Box:
+        def __init__(self, low, high, shape, dtype):
+            self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and x.dtype == self.dtype and bool(((x >= self.low) & (x <= self.high)).all())
+
+        def __repr__(self):
+            return f"Box({self.low}, {self.high}, {self.shape}, {np.dtype(self.dtype).name})"
+
+    class _Dict:
+        def __init__(self, d):
+            self.spaces = dict(d)
+
+        def __getitem__(self, k):
+            return self.spaces[k]
+
+        def contains(self, x):
+            return isinstance(x, dict) and set(x) == set(self.spaces) and all(
+                self.spaces[k].contains(v) for k, v in x.items())
+
+        def __repr__(self):
+            return f"Dict({self.spaces})"
+
+    class _spaces:  # noqa: N801
+        Discrete, Box, Dict = _Discrete, _Box, _Dict
+
+
+class Board:
+    """One Gobblet board with the reference ``Board`` interface (board.py:4-242), evaluated on the GPU.
+
+    ``squares`` is a host numpy float64[27] exactly like the reference's (callers read it, assign whole
+    arrays and single cells: greedy_policy.py:71, manual_policy.py:60,194-196); it is uploaded to the
+    1-board ``BatchedBoard`` backend before every query.  ``backend`` exists so that the host logic can be
+    tested without a GPU by injecting a stand-in; the default is the HIP engine and there is no fallback.
+    """
+
+    def __init__(self, squares=None, device="cuda:0", backend=None):
+        self.squares = np.zeros(27)           # board.py:33
+        self.squares_preview = np.zeros(27)   # board.py:34
+        if squares is not None:
+            self.squares = np.array(squares, dtype=np.float64).reshape(27)
+        self._backend = backend if backend is not None else BatchedBoard(1, device)
+        self.winning_combinations = self._backend.winning_combinations  # board.py:135-153
+        self.calculate_winners = self._backend.calculate_winners
+        self.setup = self._backend.setup
+
+    def _sync(self):
+        sq = np.asarray(self.squares)
+        if sq.shape != (27,) or not np.all(sq == np.round(sq)) or np.abs(sq).max(initial=0) > 6:
+            raise ValueError("Board.squares must be 27 integers in [-6, 6]")
+        self._backend.squares = torch.from_numpy(sq.astype(np.int8))[None]
+        return self._backend
+
+    # decoders, board.py:42-79
+    get_action_from_pos_piece = staticmethod(BatchedBoard.get_action_from_pos_piece)
+    get_pos_from_action = staticmethod(BatchedBoard.get_pos_from_action)
+    get_piece_from_action = staticmethod(BatchedBoard.get_piece_from_action)
+    get_piece_size_from_action = BatchedBoard.get_piece_size_from_action
+    get_index_from_action = BatchedBoard.get_index_from_action
+
+    @staticmethod
+    def _agent(agent_index):
+        return 0 if agent_index == 0 else 1  # board.py:86: anything but 0 plays as player_2
+
+    def is_legal(self, action, agent_index=0):  # board.py:82-115
+        return bool(self._sync().is_legal(int(action), self._agent(agent_index))[0])
+
+    def play_turn(self, agent_index, action):  # board.py:118-132
+        if agent_index not in (0, 1):
+            raise ValueError("agent_index must be 0 or 1")
+        b = self._sync()
+        b.play_turn(int(agent_index), int(action))
+        self.squares = b.squares[0].cpu().numpy().astype(np.float64)
+
+    def get_action(self, pos, piece_size, agent_index):  # board.py:50-60
+        return int(self._sync().get_action(int(pos), int(piece_size), self._agent(agent_index))[0])
+
+    def get_flatboard(self):  # board.py:159-177
+        return self._sync().get_flatboard()[0].cpu().numpy().astype(np.float64)
+
+    def check_for_winner(self):  # board.py:183-194
+        return int(self._sync().check_for_winner()[0])
+
+    def check_game_over(self):  # board.py:196-201
+        return self.check_for_winner() in (1, -1)
+
+    def check_covered(self):  # board.py:203-220
+        return self._sync().check_covered()[0].cpu().numpy().astype(np.float64)
+
+    def legal_moves(self, agent_index):
+        return np.flatnonzero(self._sync().legal_mask(self._agent(agent_index))[0].cpu().numpy()).tolist()
+
+    def observation(self, agent_index):
+        return self._sync().observation(int(self._agent(agent_index)))[0].cpu().numpy()
+
+    def print(self):  # board.py:155-156
+        print(self.get_flatboard().reshape(3, 3).transpose())
+
+    def __str__(self):  # board.py:241-242
+        return str(np.asarray(self.squares).reshape(3, 3, 3))
+
+
+class _AgentSelector:  # pettingzoo.utils.agent_selector (round robin)
+    def __init__(self, agent_order):
+        self.reinit(agent_order)
+
+    def reinit(self, agent_order):
+        self.agent_order = agent_order
+        self._current_agent = 0
+        self.selected_agent = 0
+
+    def reset(self):
+        self.reinit(self.agent_order)
+        return self.next()
+
+    def next(self):
+        self._current_agent = (self._current_agent + 1) % len(self.agent_order)
+        self.selected_agent = self.agent_order[self._current_agent - 1]
+        return self.selected_agent
+
+
+class raw_env(_AECBase):  # noqa: N801  (reference spelling, gobblet.py:123)
+    metadata = {
+        "render_modes": ["text", "text_full"],  # pygame modes ("human", "rgb_array") are out of scope
+        "name": "gobblet_v1",
+        "is_parallelizable": True,
+        "render_fps": 60,
+        "has_manual_policy": False,
+    }
+
+    def __init__(self, render_mode=None, args=None, device="cuda:0", board_backend=None):
+        super().__init__()
+        self._device, self._board_backend = device, board_backend
+        self.board = Board(device=device, backend=board_backend)
+        self.board_size = 3
+        self.agents = ["player_1", "player_2"]          # gobblet.py:137
+        self.possible_agents = self.agents[:]
+        self.action_spaces = {i: _spaces.Discrete(54) for i in self.agents}  # gobblet.py:140
+        self.observation_spaces = {                      # gobblet.py:141-153
+            i: _spaces.Dict({
+                "observation": _spaces.Box(low=0, high=1, shape=(3, 3, 13), dtype=np.int8),
+                "action_mask": _spaces.Box(low=0, high=1, shape=(54,), dtype=np.int8),
+            }) for i in self.agents
+        }
+        self.rewards = {i: 0 for i in self.agents}
+        self.terminations = {i: False for i in self.agents}
+        self.truncations = {i: False for i in self.agents}
+        self.infos = {i: {"legal_moves": list(range(0, 9))} for i in self.agents}  # gobblet.py:158
+        self._agent_selector = _AgentSelector(self.agents)
+        self.agent_selection = self._agent_selector.reset()
+        self.render_mode = render_mode
+        self.debug = args.debug if hasattr(args, "debug") else False
+        self.screen = None
+
+    def observe(self, agent):  # gobblet.py:179-215
+        idx = self.possible_agents.index(agent)
+        observation = self.board.observation(idx)
+        legal_moves = self._legal_moves() if agent == self.agent_selection else []
+        action_mask = np.zeros(54, "int8")
+        for i in legal_moves:
+            action_mask[i] = 1
+        return {"observation": observation, "action_mask": action_mask}
+
+    def observation_space(self, agent):
+        return self.observation_spaces[agent]
+
+    def action_space(self, agent):
+        return self.action_spaces[agent]
+
+    def _legal_moves(self):  # gobblet.py:223-228
+        return self.board.legal_moves(self.possible_agents.index(self.agent_selection))
+
+    def step(self, action):  # gobblet.py:231-273
+        if self.terminations[self.agent_selection] or self.truncations[self.agent_selection]:
+            return self._was_dead_step(action)
+        self.board.play_turn(self.agents.index(self.agent_selection), action)  # illegal: silent no-op
+        next_agent = self._agent_selector.next()
+        if self.board.check_game_over():
+            winner = self.board.check_for_winner()
+            if winner == 1:
+                self.rewards[self.agents[0]] += 1
+                self.rewards[self.agents[1]] -= 1
+            elif winner == -1:
+                self.rewards[self.agents[1]] += 1
+                self.rewards[self.agents[0]] -= 1
+            self.terminations = {i: True for i in self.agents}
+        self._cumulative_rewards[self.agent_selection] = 0
+        self.agent_selection = next_agent
+        self._accumulate_rewards()
+        self.turn += 1
+        self.action = action
+        if self.render_mode in ["text", "text_full"]:
+            self.render()
+
+    def reset(self, seed=None, return_info=False, options=None):  # gobblet.py:275-290 (seed is ignored)
+        self.board = Board(device=self._device, backend=self._board_backend)
+        self.agents = self.possible_agents[:]
+        self.rewards = {i: 0 for i in self.agents}
+        self._cumulative_rewards = {i: 0 for i in self.agents}
+        self.terminations = {i: False for i in self.agents}
+        self.truncations = {i: False for i in self.agents}
+        self.infos = {i: {} for i in self.agents}
+        self._agent_selector.reinit(self.agents)
+        self._agent_selector.reset()
+        self.agent_selection = self._agent_selector.reset()
+        self.turn = 0
+        self.action = -1
+
+    def render(self):  # gobblet.py:292-429, text modes only
+        if self.render_mode is None:
+            import warnings
+            warnings.warn("You are calling render method without specifying any render mode.")
+            return
+        from .render import render_text
+        out = render_text(self, full=self.render_mode == "text_full")
+        print(out)
+        return out
+
+    def close(self):
+        pass
+
+
+class _EnvWrappers:
+    """``env()`` of the reference stacks TerminateIllegalWrapper(illegal_reward=-1) ->
+    AssertOutOfBoundsWrapper -> OrderEnforcingWrapper (gobblet.py:110-117).  Those wrappers are
+    PettingZoo's; when PettingZoo is not importable this class restates what they do to this
+    environment: an action outside Discrete(54) asserts; stepping / observing before reset raises;
+    an action whose cached mask bit is 0 gives the mover -1, everyone else 0, and terminates and
+    truncates every agent with the board untouched (gobblet.py:50-51)."""
+
+    def __init__(self, raw):
+        self.env = raw
+        self._has_reset = False
+        self._terminated = False
+        self._prev_obs = None
+
+    def __getattr__(self, name):
+        if name.startswith("_") and name not in ("_cumulative_rewards", "_legal_moves"):
+            raise AttributeError(name)
+        return getattr(self.env, name)
+
+    @property
+    def unwrapped(self):
+        return self.env
+
+    def reset(self, seed=None, return_info=False, options=None):
+        self._has_reset, self._terminated, self._prev_obs = True, False, None
+        self.env.reset(seed=seed, options=options)
+
+    def observe(self, agent):
+        if not self._has_reset:
+            raise AttributeError("reset() needs to be called before observe")
+        obs = self.env.observe(agent)
+        if agent == self.env.agent_selection:
+            self._prev_obs = obs
+        return obs
+
+    def last(self, observe=True):
+        agent = self.env.agent_selection
+        observation = self.observe(agent) if observe else None
+        e = self.env
+        return (observation, e._cumulative_rewards[agent], e.terminations[agent], e.truncations[agent],
+                e.infos[agent])
+
+    def agent_iter(self, max_iter=2 ** 63):
+        if not self._has_reset:
+            raise AttributeError("reset() needs to be called before agent_iter")
+        return self.env.agent_iter(max_iter)
+
+    def step(self, action):
+        if not self._has_reset:
+            raise AttributeError("reset() needs to be called before step")
+        e = self.env
+        agent = e.agent_selection
+        dead = e.terminations[agent] or e.truncations[agent]
+        assert (action is None and dead) or e.action_space(agent).contains(action), \
+            "action is not in action space"
+        if self._prev_obs is None:
+            self.observe(agent)
+        prev_mask = self._prev_obs["action_mask"]
+        self._prev_obs = None
+        if self._terminated and dead:
+            e._was_dead_step(action)
+        elif not dead and not prev_mask[action]:
+            e._cumulative_rewards[agent] = 0
+            e.terminations = {d: True for d in e.agents}
+            e.truncations = {d: True for d in e.agents}
+            e.rewards = {d: 0 for d in e.truncations}
+            e.rewards[agent] = float(-1)
+            e._accumulate_rewards()
+            e._deads_step_first()
+            self._terminated = True
+        else:
+            e.step(action)
+
+    def render(self):
+        return self.env.render()
+
+    def close(self):
+        self.env.close()
+
+
+def env(render_mode=None, args=None, device="cuda:0", board_backend=None):  # gobblet.py:110-117
+    e = raw_env(render_mode=render_mode, args=args, device=device, board_backend=board_backend)
+    if _HAVE_PZ:  # pragma: no cover
+        e = _pz_wrappers.TerminateIllegalWrapper(e, illegal_reward=-1)
+        e = _pz_wrappers.AssertOutOfBoundsWrapper(e)
+        return _pz_wrappers.OrderEnforcingWrapper(e)
+    return _EnvWrappers(e)
+
+
+def parallel_env(*a, **k):  # gobblet.py:120; skipped upstream too (tests/test_gobblet_env.py:37-43)
+    raise NotImplementedError("gobblet is an AEC environment; use BatchedGobblet for lockstep stepping")

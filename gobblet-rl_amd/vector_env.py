@@ -1,0 +1,125 @@
+"""``BatchedGobblet`` -- lockstep vectorised Gobblet over N boards on one MI355X.
+
+One ``step(actions)`` is one ``raw_env.step`` (gobblet.py:231-271) plus the ``observe`` of the
+agent that moves next (gobblet.py:179-215) on every board, fused in one HIP kernel
+(``gbl_step``).  All state and all outputs live in HBM as torch tensors; nothing comes back to
+the host unless the caller asks.
+
+Tensors (attributes, all on ``device``)
+    squares  int8 (N, 27)        Board.squares of every board
+    to_move  int8 (N,)           index of agent_selection (0 = player_1)
+    done     int8 (N,)           terminations (auto_reset: "episode ended on the last step")
+    winner   int8 (N,)           check_for_winner() after the last step
+    rewards  int8 (N, 2)         rewards of (player_1, player_2) for the last step
+    action_mask int8 (N, 54)     legal mask of the agent to move
+    observation int8 (N,3,3,13)  observation of the agent to move
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native as nat
+from .board import BatchedBoard, _as_i32
+
+
+class BatchedGobblet:
+    metadata = {"name": "gobblet_v1_batched", "num_actions": nat.ACTIONS, "observation_shape": (3, 3, 13)}
+
+    def __init__(self, num_envs: int, device="cuda:0", illegal_mode: str | int = "noop", auto_reset: bool = False,
+                 with_observation: bool = True, seed: int = 0, env_base: int = 0):
+        """illegal_mode: "noop" = raw_env semantics (silent no-op, the turn passes);
+        "terminate" = env() semantics (TerminateIllegalWrapper: mover -1, episode ends).
+        env_base: global index of this shard's board 0 (keys the sampler so results do not
+        depend on how boards are sharded over GPUs)."""
+        self.board = BatchedBoard(num_envs, device)
+        self.device = self.board.device
+        self.num_envs = self.board.num_envs
+        self._lib = nat.lib()
+        modes = {"noop": nat.ILLEGAL_NOOP, "terminate": nat.ILLEGAL_TERMINATE, 0: 0, 1: 1}
+        if illegal_mode not in modes:
+            raise ValueError("illegal_mode must be 'noop' or 'terminate'")
+        self.illegal_mode = modes[illegal_mode]
+        self.auto_reset = bool(auto_reset)
+        self.seed, self.env_base = int(seed), int(env_base)
+        n, dev = self.num_envs, self.device
+        self.to_move = torch.zeros(n, dtype=torch.int8, device=dev)
+        self.done = torch.zeros(n, dtype=torch.int8, device=dev)
+        self.winner = torch.zeros(n, dtype=torch.int8, device=dev)
+        self.rewards = torch.zeros((n, 2), dtype=torch.int8, device=dev)
+        self.action_mask = torch.empty((n, nat.ACTIONS), dtype=torch.int8, device=dev)
+        self.observation = torch.empty((n, 3, 3, 13), dtype=torch.int8, device=dev) if with_observation else None
+        self.actions = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.counters = torch.zeros(4, dtype=torch.int64, device=dev)  # plies, games, p1 wins, p2 wins (rollout)
+        self.ply = 0  # lockstep ply counter (keys the sampler)
+        self.reset()
+
+    @property
+    def squares(self) -> torch.Tensor:
+        return self.board.squares
+
+    def _stream(self):
+        return nat.current_stream(self.device)
+
+    # -- gobblet.py:275-290 --------------------------------------------------------------------------
+    def reset(self, seed=None, options=None):
+        """All boards empty, player_1 to move.  Like the reference, ``seed`` does not affect the
+        (deterministic) environment; if given it re-keys the action sampler."""
+        if seed is not None:
+            self.seed = int(seed)
+        n = self.num_envs
+        nat.check(self._lib.gbl_reset(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
+                                      self.winner.data_ptr(), n, self._stream()), "gbl_reset")
+        self.rewards.zero_()
+        self.ply = 0
+        self.refresh()
+        return self.observe()
+
+    def refresh(self):
+        """Recompute action_mask / observation from squares + to_move (after assigning state)."""
+        n = self.num_envs
+        nat.check(self._lib.gbl_legal_mask(self.squares.data_ptr(), self.to_move.data_ptr(),
+                                           self.action_mask.data_ptr(), n, self._stream()), "gbl_legal_mask")
+        if not self.auto_reset:
+            self.action_mask.mul_((self.done == 0).to(torch.int8)[:, None])
+        if self.observation is not None:
+            nat.check(self._lib.gbl_observe(self.squares.data_ptr(), self.to_move.data_ptr(), -1,
+                                            self.observation.data_ptr(), n, self._stream()), "gbl_observe")
+
+    def observe(self):
+        """{"observation", "action_mask"} of the agent to move on every board (gobblet.py:215)."""
+        return {"observation": self.observation, "action_mask": self.action_mask}
+
+    # -- gobblet.py:231-271 + 179-215 ------------------------------------------------------------------
+    def step(self, actions):
+        """Apply ``actions`` (int (N,)) for the agents to move.  Returns
+        (obs dict, rewards (N,2), done (N,), winner (N,)) -- views of the attribute tensors."""
+        n = self.num_envs
+        a = _as_i32(actions, n, self.device, "actions")
+        nat.check(self._lib.gbl_step(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
+                                     a.data_ptr(), self.winner.data_ptr(), self.rewards.data_ptr(),
+                                     self.action_mask.data_ptr(), nat.ptr(self.observation), n, self.illegal_mode,
+                                     int(self.auto_reset), self._stream()), "gbl_step")
+        self.ply += 1
+        return self.observe(), self.rewards, self.done, self.winner
+
+    # -- masked-uniform sampling (examples/example_basic.py:58-61) ----------------------------------------
+    def sample_actions(self, out: torch.Tensor | None = None) -> torch.Tensor:
+        """One uniformly random legal action per board from the current action_mask, keyed by
+        (seed, env_base + b, ply)."""
+        out = self.actions if out is None else out
+        nat.check(self._lib.gbl_sample(self.action_mask.data_ptr(), out.data_ptr(), self.num_envs, self.seed,
+                                       self.env_base, self.ply, self._stream()), "gbl_sample")
+        return out
+
+    def rollout(self, plies: int, every_ply: bool = False):
+        """``plies`` masked-random plies with auto-reset in ONE kernel launch (state stays in
+        registers).  every_ply=True stores mask / observation / winner / rewards after every ply,
+        False only after the last.  Accumulates ``counters``."""
+        n = self.num_envs
+        nat.check(self._lib.gbl_rollout(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
+                                        self.actions.data_ptr(), self.winner.data_ptr(), self.rewards.data_ptr(),
+                                        self.action_mask.data_ptr(), nat.ptr(self.observation), n, self.seed,
+                                        self.env_base, self.ply, int(plies), self.illegal_mode, int(bool(every_ply)),
+                                        self.counters.data_ptr(), self._stream()), "gbl_rollout")
+        self.ply += int(plies)
+        return self.observe(), self.rewards, self.done, self.winner

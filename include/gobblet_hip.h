@@ -1,0 +1,148 @@
+/*
+ * gobblet_hip.h -- C-ABI of the MI355X (gfx950) batched Gobblet hot path.
+ *
+ * The reference (elliottower/gobblet-rl) is pure Python and has no FFI seam;
+ * the seam this library sits behind is the `Board` object interface consumed
+ * by gobblet_rl/game/gobblet.py, greedy_policy.py and manual_policy.py
+ * (SURVEY.md section 8b).  Every entry point below is the lockstep, N-board
+ * form of one reference function and cites it.  INTEGRATION.md shows the
+ * ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers owned by the caller (e.g. torch-ROCm
+ *     tensors' data_ptr()); the library allocates nothing and keeps no state.
+ *   - Every buffer that holds per-board ROWS (state, mask, obs, flat, cov)
+ *     must be 16-byte aligned at board 0 (hipMalloc / torch allocations are).
+ *   - `stream` is a hipStream_t (NULL = default stream).  Calls only enqueue.
+ *   - Return value: 0 = OK, negative = GBL_ERR_*; gbl_last_error() gives the
+ *     thread-local message.  No C++ exception crosses the ABI.
+ *   - Kernels never trap on bad data: an action outside [0,54) is an illegal
+ *     action (handled per `illegal_mode`).
+ *
+ * Data layout in HBM (env-major, int8)
+ *   state   int8 [n][27]      Board.squares per board: squares[9*level + pos]
+ *                             (board.py:6-33); 0 empty, +piece player_1,
+ *                             -piece player_2, piece in 1..6.
+ *   to_move int8 [n]          index of agent_selection (0 = player_1)
+ *   done    int8 [n]          terminations (both agents at once, gobblet.py:263)
+ *   winner  int8 [n]          check_for_winner(): -1 / 0 / +1
+ *   reward  int8 [n][2]       rewards of (player_1, player_2) for this step
+ *   mask    int8 [n][54]      action_mask of the agent to move
+ *   obs     int8 [n][3][3][13] observation of the agent to move
+ *   actions int32[n]
+ * Contract on `state`: a cell of level k holds 0 or +-(2k+1) or +-(2k+2) --
+ * what legal play from reset can produce.  For such states every function is
+ * bit-identical to the reference.
+ */
+#ifndef GOBBLET_HIP_H
+#define GOBBLET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GBL_OK 0
+#define GBL_ERR_ARG (-1)   /* null / negative / out-of-range argument */
+#define GBL_ERR_ALIGN (-2) /* a row buffer is not 16-byte aligned */
+#define GBL_ERR_HIP (-3)   /* a HIP runtime call failed; see gbl_last_error() */
+
+#define GBL_CELLS 27
+#define GBL_ACTIONS 54
+#define GBL_OBS_BYTES 117
+
+/* illegal_mode */
+#define GBL_ILLEGAL_NOOP 0      /* raw_env.step: silent no-op, the turn still passes (gobblet.py:244-246, board.py:125-126) */
+#define GBL_ILLEGAL_TERMINATE 1 /* env(): TerminateIllegalWrapper(illegal_reward=-1) (gobblet.py:114, :50-51) */
+
+/* Version / layout query: writes {abi_version, cells, actions, obs_bytes, tile_boards, row_alignment}. */
+int gbl_layout_info(int32_t out[6]);
+
+/* Message of the last error on this thread ("" if none). */
+const char *gbl_last_error(void);
+
+/* raw_env.reset(), gobblet.py:275-290: new Board() (zeros, board.py:33),
+ * agent_selection = player_1, terminations False.  winner may be NULL. */
+int gbl_reset(int8_t *state, int8_t *to_move, int8_t *done, int8_t *winner, int64_t n, void *stream);
+
+/* raw_env._legal_moves() + mask fill, gobblet.py:223-228,211-213
+ * (54 x Board.is_legal, board.py:82-115) for agent to_move[b]. */
+int gbl_legal_mask(const int8_t *state, const int8_t *to_move, int8_t *mask, int64_t n, void *stream);
+
+/* Board.is_legal(action, agent_index), board.py:82-115, one action per board.
+ * agent_index: device int8[n]; out: int8[n] (1 legal / 0 illegal or out of range). */
+int gbl_is_legal(const int8_t *state, const int8_t *agent_index, const int32_t *actions, int8_t *out, int64_t n,
+                 void *stream);
+
+/* Board.play_turn(agent_index, action), board.py:118-132: in-place, silent no-op when illegal. */
+int gbl_play_turn(int8_t *state, const int8_t *agent_index, const int32_t *actions, int64_t n, void *stream);
+
+/* Board.check_for_winner(), board.py:183-194 (lines board.py:135-153; the last matching line decides). */
+int gbl_winner(const int8_t *state, int8_t *winner, int64_t n, void *stream);
+
+/* Board.get_flatboard(), board.py:159-177: flat int8[n][9], signed piece number of the top piece. */
+int gbl_flatboard(const int8_t *state, int8_t *flat, int64_t n, void *stream);
+
+/* Board.check_covered(), board.py:203-220: cov int8[n][27]. */
+int gbl_covered(const int8_t *state, int8_t *cov, int64_t n, void *stream);
+
+/* raw_env.observe(agent)["observation"], gobblet.py:179-208.
+ * agent_sel = 0 / 1: observe every board as that agent; -1: as to_move[b]
+ * (to_move may be NULL unless agent_sel == -1). */
+int gbl_observe(const int8_t *state, const int8_t *to_move, int agent_sel, int8_t *obs, int64_t n, void *stream);
+
+/* One lockstep raw_env.step(actions[b]) + observe(next mover) per board,
+ * gobblet.py:231-271 + :179-215, fused.  In place on state / to_move / done.
+ *   done[b] != 0 on entry: the board is frozen (reference: _was_dead_step,
+ *     gobblet.py:232-236); its mask is written as zeros, obs as observed.
+ *   auto_reset != 0: `done` on entry is ignored; a board that terminates on
+ *     this step reports winner / reward / done = 1 and is reset in place
+ *     (zeros, player_1 to move); mask / obs are those of the fresh board.
+ *   winner_out / reward_out / mask_out / obs_out may each be NULL. */
+int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out,
+             int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, int illegal_mode, int auto_reset,
+             void *stream);
+
+/* Masked-uniform action sampling -- the rule behind "masked-random actions"
+ * (examples/example_basic.py:58-61, random_admissible_policy_rllib.py:23-30:
+ * uniform over legal actions) -- with a counter-based RNG so CPU and GPU draw
+ * the same action: r = Philox4x32-10(ctr = (env_lo, env_hi, ply, 0),
+ * key = (seed_lo, seed_hi))[0]; k = (r * nlegal) >> 32; the k-th legal action
+ * in ascending order (-1 if the mask is empty).  env id = env_base + b. */
+int gbl_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply,
+               void *stream);
+
+/* Fused masked-random rollout: `plies` lockstep plies in ONE
+ * launch; per ply and board: legal mask -> gbl_sample rule with ply index
+ * ply0 + t -> gbl_step with auto-reset.  State stays in registers between
+ * plies.  every_ply != 0: mask / obs / winner / reward / actions / done are
+ * stored after EVERY ply (the traffic a consumer of each ply's outputs
+ * causes); 0: only after the last ply.  counters: device int64[4], atomically
+ * incremented by {plies played, games finished, player_1 wins, player_2 wins}
+ * (may be NULL).  actions_out / winner_out / reward_out / mask_out / obs_out
+ * may be NULL. */
+int gbl_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_out, int8_t *winner_out,
+                int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, uint64_t seed, uint64_t env_base,
+                uint32_t ply0, uint32_t plies, int illegal_mode, int every_ply, int64_t *counters, void *stream);
+
+/* GreedyGobbletPolicy.compute_action board decode, greedy_policy.py:43-71:
+ * obs int8[n][3][3][13] -> state int8[n][27], to_move int8[n] (channel 12). */
+int gbl_decode_obs(const int8_t *obs, int8_t *state, int8_t *to_move, int64_t n, void *stream);
+
+/* GreedyGobbletPolicy.compute_action, greedy_policy.py:38-221, depth 1 or 2
+ * (depth-3 branch :160-208 is out of scope), for the agent
+ * to move on each board.
+ *   mask     : legal mask handed to the policy (NULL = derive from state)
+ *   hist     : int8[n][2][3] last three actions per agent, -1 = none (NULL = empty)
+ *   action_out   int32[n] : chosen action; -1 where the reference falls back
+ *                           to np.random.choice(actions_depth1) (:211-217)
+ *   cand_mask_out int8[n][54] : membership of actions_depth1 at :211 (may be NULL)
+ *   fallback_out  int8[n]     : 1 where the fallback fires (may be NULL) */
+int gbl_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask, const int8_t *hist, int depth,
+               int32_t *action_out, int8_t *cand_mask_out, int8_t *fallback_out, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOBBLET_HIP_H */

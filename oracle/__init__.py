@@ -81,6 +81,9 @@ def lib() -> C.CDLL:
         L.gbo_batch_step.argtypes = [_i8p, _i8p, _i8p, _i32p, _i8p, _i8p, _i8p, _i8p, C.c_int64, C.c_int, C.c_int]
         L.gbo_batch_step_mt.restype = None
         L.gbo_batch_step_mt.argtypes = L.gbo_batch_step.argtypes + [C.c_int]
+        L.gbo_batch_sample_step_mt.restype = None
+        L.gbo_batch_sample_step_mt.argtypes = [_i8p, _i8p, _i8p, _i32p, _i8p, _i8p, _i8p, _i8p, C.c_int64, C.c_uint64,
+                                               C.c_uint64, C.c_uint32, C.c_int, C.c_int]
         L.gbo_batch_sample.restype = None
         L.gbo_batch_sample.argtypes = [_i8p, _i32p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32]
         L.gbo_batch_rollout.restype = None
@@ -240,6 +243,15 @@ def batch_step(state, to_move, done, actions, illegal_mode=ILLEGAL_NOOP, auto_re
 def batch_sample(mask, seed, env_base, ply):
     n = mask.shape[0]; out = np.zeros(n, np.int32)
     lib().gbo_batch_sample(_p(mask), _p(out, C.c_int32), n, int(seed), int(env_base), int(ply)); return out
+
+
+def batch_sample_step(state, to_move, done, actions, winner, reward, mask, obs, seed, env_base, ply,
+                      illegal_mode=ILLEGAL_NOOP, threads=1):
+    """One ply of the benchmark pipeline, in place on caller-owned arrays: sample from `mask`, then the
+    fused step with auto-reset writing `mask` / `obs` (threaded over board shards)."""
+    lib().gbo_batch_sample_step_mt(_p(state), _p(to_move), _p(done), _p(actions, C.c_int32), _p(winner), _p(reward),
+                                   _p(mask), _p(obs), state.shape[0], int(seed), int(env_base), int(ply),
+                                   int(illegal_mode), int(threads))
 
 
 def batch_rollout(state, to_move, done, seed, env_base, ply0, plies, illegal_mode=ILLEGAL_NOOP, threads=1,

@@ -482,6 +482,52 @@ void gbo_batch_step_mt(int8_t *state, int8_t *to_move, int8_t *done, const int32
         for (int t = 0; t < used; ++t) pthread_join(tid[t], NULL);
 }
 
+/* cpu_baseline leg of bench.py: one lockstep ply of the benchmark pipeline per
+ * call -- sample an action from the mask buffer (what gbl_sample does), then
+ * the fused step with auto-reset writing mask / obs (what gbl_step does) --
+ * boards split into contiguous shards, one per thread. */
+typedef struct {
+    step_job_t st;
+    int32_t *actions_rw;
+    uint64_t seed, env_base;
+    uint32_t ply;
+} ply_job_t;
+
+static void *ply_worker(void *arg)
+{
+    ply_job_t *j = (ply_job_t *)arg;
+    for (int64_t b = j->st.b0; b < j->st.b1; ++b)
+        j->actions_rw[b] = gbo_sample_action(j->st.mask + b * GBO_ACTIONS, j->seed, j->env_base + (uint64_t)b, j->ply);
+    return step_worker(&j->st);
+}
+
+void gbo_batch_sample_step_mt(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions, int8_t *winner,
+                              int8_t *reward, int8_t *mask, int8_t *obs, int64_t n, uint64_t seed, uint64_t env_base,
+                              uint32_t ply, int illegal_mode, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    ply_job_t jobs[256];
+    pthread_t tid[256];
+    int64_t per = (n + threads - 1) / threads;
+    int used = 0;
+    for (int t = 0; t < threads; ++t) {
+        int64_t b0 = (int64_t)t * per, b1 = b0 + per;
+        if (b0 >= n) break;
+        if (b1 > n) b1 = n;
+        ply_job_t *j = &jobs[used];
+        j->st.state = state; j->st.to_move = to_move; j->st.done = done; j->st.actions = actions;
+        j->st.winner = winner; j->st.reward = reward; j->st.mask = mask; j->st.obs = obs;
+        j->st.b0 = b0; j->st.b1 = b1; j->st.illegal_mode = illegal_mode; j->st.auto_reset = 1;
+        j->actions_rw = actions; j->seed = seed; j->env_base = env_base; j->ply = ply;
+        if (threads == 1) ply_worker(j);
+        else pthread_create(&tid[used], NULL, ply_worker, j);
+        ++used;
+    }
+    if (threads > 1)
+        for (int t = 0; t < used; ++t) pthread_join(tid[t], NULL);
+}
+
 /* ------------------------------------------------------------------------- */
 /* GreedyGobbletPolicy.compute_action, greedy_policy.py:38-221, depth 1 or 2. */
 

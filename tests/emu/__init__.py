@@ -1,0 +1,107 @@
+"""Host emulation of the device header (TEST INFRASTRUCTURE, see emu_device.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libgobblet_emu.so")
+_SRCS = [os.path.join(_HERE, "emu_device.cpp"),
+         os.path.join(_HERE, "..", "..", "gobblet-rl_amd", "csrc", "gobblet_device.h")]
+
+
+def build():
+    if not os.path.exists(_LIB) or any(os.path.getmtime(_LIB) < os.path.getmtime(s) for s in _SRCS):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unknown-pragmas", "-fPIC", "-shared",
+                               "-o", _LIB, _SRCS[0]])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return C.c_void_p(a.ctypes.data)
+
+
+def legal_mask(state, to_move):
+    n = len(state); out = np.full((n, 54), 77, np.int8)
+    lib().emu_legal_mask(_p(state), _p(to_move), _p(out), C.c_int64(n)); return out
+
+
+def is_legal(state, agent, actions):
+    n = len(state); out = np.full(n, 77, np.int8); actions = np.ascontiguousarray(actions, np.int32)
+    lib().emu_is_legal(_p(state), _p(agent), _p(actions), _p(out), C.c_int64(n)); return out
+
+
+def play_turn(state, agent, actions):
+    actions = np.ascontiguousarray(actions, np.int32)
+    lib().emu_play_turn(_p(state), _p(agent), _p(actions), C.c_int64(len(state)))
+
+
+def winner(state):
+    n = len(state); out = np.full(n, 77, np.int8)
+    lib().emu_winner(_p(state), _p(out), C.c_int64(n)); return out
+
+
+def flatboard(state):
+    n = len(state); out = np.full((n, 9), 77, np.int8)
+    lib().emu_flatboard(_p(state), _p(out), C.c_int64(n)); return out
+
+
+def covered(state):
+    n = len(state); out = np.full((n, 27), 77, np.int8)
+    lib().emu_covered(_p(state), _p(out), C.c_int64(n)); return out
+
+
+def observe(state, to_move, agent_sel=-1):
+    n = len(state); out = np.full((n, 3, 3, 13), 77, np.int8)
+    lib().emu_observe(_p(state), _p(to_move), C.c_int(agent_sel), _p(out), C.c_int64(n)); return out
+
+
+def step(state, to_move, done, actions, illegal_mode=0, auto_reset=False):
+    n = len(state); actions = np.ascontiguousarray(actions, np.int32)
+    w = np.full(n, 77, np.int8); rw = np.full((n, 2), 77, np.int8)
+    mask = np.full((n, 54), 77, np.int8); obs = np.full((n, 3, 3, 13), 77, np.int8)
+    lib().emu_step(_p(state), _p(to_move), _p(done), _p(actions), _p(w), _p(rw), _p(mask), _p(obs), C.c_int64(n),
+                   C.c_int(illegal_mode), C.c_int(int(auto_reset)))
+    return {"winner": w, "reward": rw, "mask": mask, "obs": obs}
+
+
+def sample(mask, seed, env_base, ply):
+    n = len(mask); out = np.full(n, 77, np.int32)
+    lib().emu_sample(_p(mask), _p(out), C.c_int64(n), C.c_uint64(seed), C.c_uint64(env_base), C.c_uint32(ply))
+    return out
+
+
+def decode_obs(obs):
+    n = len(obs); st = np.full((n, 27), 77, np.int8); tm = np.full(n, 77, np.int8)
+    lib().emu_decode_obs(_p(obs), _p(st), _p(tm), C.c_int64(n)); return st, tm
+
+
+def rollout(state, to_move, done, seed, env_base, ply0, plies, illegal_mode=0):
+    n = len(state)
+    a = np.full(n, 77, np.int32); w = np.full(n, 77, np.int8); rw = np.full((n, 2), 77, np.int8)
+    mask = np.full((n, 54), 77, np.int8); obs = np.full((n, 3, 3, 13), 77, np.int8); cnt = np.zeros(4, np.int64)
+    lib().emu_rollout(_p(state), _p(to_move), _p(done), _p(a), _p(w), _p(rw), _p(mask), _p(obs), C.c_int64(n),
+                      C.c_uint64(seed), C.c_uint64(env_base), C.c_uint32(ply0), C.c_uint32(plies),
+                      C.c_int(illegal_mode), _p(cnt))
+    return {"actions": a, "winner": w, "reward": rw, "mask": mask, "obs": obs, "counters": cnt}
+
+
+def greedy(state, to_move, mask=None, hist=None, depth=2):
+    n = len(state)
+    act = np.full(n, 77, np.int32); cm = np.full((n, 54), 77, np.int8); fb = np.full(n, 77, np.int8)
+    lib().emu_greedy(_p(state), _p(to_move), _p(mask), _p(hist), C.c_int(depth), _p(act), _p(cm), _p(fb), C.c_int64(n))
+    return act, cm, fb

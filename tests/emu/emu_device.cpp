@@ -1,0 +1,369 @@
+// emu_device.cpp -- TEST INFRASTRUCTURE: compiles gobblet-rl_amd/csrc/gobblet_device.h for the
+// HOST, with shims for the handful of AMDGPU builtins it uses, and walks the same
+// tile -> LDS image -> row-per-lane -> lane body -> LDS image -> tile sequence the gfx950
+// kernels run (64 "lanes" executed one after the other between the points where the kernels
+// synchronise).  It lets the CPU test suite check the device code's bit logic and its
+// staging index arithmetic against the oracle without a GPU.  It is NOT a product path and
+// nothing under gobblet-rl_amd/ references it.
+#define GBL_HOST_EMU
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+
+#define __device__
+#define __forceinline__ inline
+struct uint4 { uint32_t x, y, z, w; };
+
+static inline uint32_t emu_alignbyte(uint32_t hi, uint32_t lo, uint32_t n)
+{
+    uint64_t v = ((uint64_t)hi << 32) | lo;
+    return (uint32_t)(v >> (8 * (n & 3u)));
+}
+static inline uint32_t emu_udot4(uint32_t a, uint32_t b, uint32_t c, bool)
+{
+    for (int i = 0; i < 4; ++i) c += ((a >> (8 * i)) & 0xFFu) * ((b >> (8 * i)) & 0xFFu);
+    return c;
+}
+static inline uint32_t emu_umul24(uint32_t a, uint32_t b) { return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (b & 0xFFFFFFu)); }
+static inline uint32_t emu_umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+static uint32_t g_next_d0[64];  // what lane l receives from __shfl_down(d[0], 1)
+#define __builtin_amdgcn_alignbyte emu_alignbyte
+#define __builtin_amdgcn_udot4 emu_udot4
+#define __umul24 emu_umul24
+#define __umulhi emu_umulhi
+#define __popc __builtin_popcount
+#define __popcll __builtin_popcountll
+#define __shfl_down(v, delta) (g_next_d0[lane])
+
+#include "../../gobblet-rl_amd/csrc/gobblet_device.h"
+
+using namespace gbl;
+
+namespace {
+
+template <int ROWB>
+struct Image {
+    std::vector<uint32_t> w;
+    Image() : w(kTile * ROWB / 4 + 4, 0xDEADBEEFu) {}
+    uint32_t *p() { return w.data(); }
+};
+
+struct TileCtx {
+    int64_t tile;
+    int rows;
+};
+
+template <int ROWB, int NW>
+void stage_all(uint32_t *img, uint32_t (*rows)[NW])
+{
+    for (int l = 0; l < 64; ++l) g_next_d0[l] = rows[l < 63 ? l + 1 : l][0];
+    for (int l = 0; l < 64; ++l) row_stage<ROWB>(img, l, rows[l]);
+}
+
+template <int ROWB>
+void in_all(const int8_t *g, uint32_t *img, int rows)
+{
+    for (int l = 0; l < 64; ++l) tile_in<ROWB>(g, img, l, rows);
+}
+
+template <int ROWB>
+void out_all(int8_t *g, const uint32_t *img, int rows)
+{
+    for (int l = 0; l < 64; ++l) tile_out<ROWB>(g, img, l, rows);
+}
+
+void load_rows(const int8_t *state, const TileCtx &t, uint32_t (*r)[7])
+{
+    Image<kCells> img;
+    in_all<kCells>(state + t.tile * (kTile * kCells), img.p(), t.rows);
+    for (int l = 0; l < 64; ++l) {
+        row_load<kCells>(img.p(), l, r[l]);
+        r[l][6] &= 0x00FFFFFFu;
+        if (l >= t.rows)
+            for (int j = 0; j < 7; ++j) r[l][j] = 0;
+    }
+}
+
+template <typename F>
+void for_tiles(int64_t n, F f)
+{
+    int64_t ntiles = (n + kTile - 1) / kTile;
+    int64_t chunk = (ntiles + 7) / 8;
+    for (uint32_t bid = 0; bid < (uint32_t)(chunk * 8); ++bid) {  // same block -> tile map as the kernels
+        int64_t tile = xcd_tile(bid, ntiles);
+        if (tile >= ntiles) continue;
+        int64_t left = n - tile * kTile;
+        f(TileCtx{tile, left < kTile ? (int)left : kTile});
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+void emu_legal_mask(const int8_t *state, const int8_t *to_move, int8_t *mask, int64_t n)
+{
+    for_tiles(n, [&](TileCtx t) {
+        uint32_t r[64][7], d[64][14];
+        load_rows(state, t, r);
+        for (int l = 0; l < 64; ++l) {
+            int mover = l < t.rows ? to_move[t.tile * 64 + l] : 0;
+            mask_row(legal54(make_planes(r[l]), mover != 0), d[l]);
+        }
+        Image<kActions> img;
+        stage_all<kActions, 14>(img.p(), d);
+        out_all<kActions>(mask + t.tile * (kTile * kActions), img.p(), t.rows);
+    });
+}
+
+void emu_is_legal(const int8_t *state, const int8_t *agent, const int32_t *actions, int8_t *out, int64_t n)
+{
+    for_tiles(n, [&](TileCtx t) {
+        uint32_t r[64][7];
+        load_rows(state, t, r);
+        for (int l = 0; l < t.rows; ++l) {
+            int64_t b = t.tile * 64 + l;
+            int a = actions[b];
+            uint64_t m = legal54(make_planes(r[l]), agent[b] != 0);
+            out[b] = ((uint32_t)a < 54u && ((m >> (a & 63)) & 1ull)) ? 1 : 0;
+        }
+    });
+}
+
+void emu_play_turn(int8_t *state, const int8_t *agent, const int32_t *actions, int64_t n)
+{
+    for_tiles(n, [&](TileCtx t) {
+        uint32_t r[64][7];
+        load_rows(state, t, r);
+        for (int l = 0; l < 64; ++l) {
+            bool valid = l < t.rows;
+            int64_t b = t.tile * 64 + l;
+            Planes p = make_planes(r[l]);
+            int a = valid ? actions[b] : 0;
+            int mover = valid ? (agent[b] != 0) : 0;
+            uint64_t m = legal54(p, mover);
+            if (valid && (uint32_t)a < 54u && ((m >> (a & 63)) & 1ull)) apply_move(p, r[l], mover, (uint32_t)a);
+        }
+        Image<kCells> img;
+        stage_all<kCells, 7>(img.p(), r);
+        out_all<kCells>(state + t.tile * (kTile * kCells), img.p(), t.rows);
+    });
+}
+
+void emu_winner(const int8_t *state, int8_t *winner, int64_t n)
+{
+    for_tiles(n, [&](TileCtx t) {
+        uint32_t r[64][7];
+        load_rows(state, t, r);
+        for (int l = 0; l < t.rows; ++l) winner[t.tile * 64 + l] = (int8_t)winner_of(make_planes(r[l]));
+    });
+}
+
+void emu_flatboard(const int8_t *state, int8_t *flat, int64_t n)
+{
+    for_tiles(n, [&](TileCtx t) {
+        uint32_t r[64][7], d[64][3];
+        load_rows(state, t, r);
+        for (int l = 0; l < 64; ++l) flat_row(make_planes(r[l]), r[l], d[l]);
+        Image<9> img;
+        stage_all<9, 3>(img.p(), d);
+        out_all<9>(flat + t.tile * (kTile * 9), img.p(), t.rows);
+    });
+}
+
+void emu_covered(const int8_t *state, int8_t *cov, int64_t n)
+{
+    for_tiles(n, [&](TileCtx t) {
+        uint32_t r[64][7], d[64][7];
+        load_rows(state, t, r);
+        for (int l = 0; l < 64; ++l) covered_row(make_planes(r[l]), d[l]);
+        Image<kCells> img;
+        stage_all<kCells, 7>(img.p(), d);
+        out_all<kCells>(cov + t.tile * (kTile * kCells), img.p(), t.rows);
+    });
+}
+
+void emu_observe(const int8_t *state, const int8_t *to_move, int agent_sel, int8_t *obs, int64_t n)
+{
+    for_tiles(n, [&](TileCtx t) {
+        uint32_t r[64][7], d[64][30];
+        load_rows(state, t, r);
+        for (int l = 0; l < 64; ++l) {
+            int who = agent_sel >= 0 ? agent_sel : (l < t.rows ? to_move[t.tile * 64 + l] : 0);
+            obs_row(make_planes(r[l]), who != 0, d[l]);
+        }
+        Image<kObs> img;
+        stage_all<kObs, 30>(img.p(), d);
+        out_all<kObs>(obs + t.tile * (kTile * kObs), img.p(), t.rows);
+    });
+}
+
+void emu_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out,
+              int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, int illegal_mode, int auto_reset)
+{
+    for_tiles(n, [&](TileCtx t) {
+        uint32_t r[64][7], dm[64][14], dobs[64][30];
+        load_rows(state, t, r);
+        for (int l = 0; l < 64; ++l) {
+            bool valid = l < t.rows;
+            int64_t b = t.tile * 64 + l;
+            int mover = 0, was_done = 0, action = 0;
+            if (valid) {
+                mover = to_move[b] != 0;
+                was_done = auto_reset ? 0 : (done[b] != 0);
+                action = actions[b];
+            }
+            Planes p = make_planes(r[l]);
+            Ply y;
+            int dn;
+            step_lane(r[l], p, mover, was_done, action, illegal_mode, auto_reset, dn, y);
+            mask_row(next_mask(p, mover, dn, auto_reset), dm[l]);
+            obs_row(p, mover, dobs[l]);
+            if (valid) {
+                to_move[b] = (int8_t)mover;
+                done[b] = (int8_t)dn;
+                if (winner_out) winner_out[b] = (int8_t)y.winner;
+                if (reward_out) { reward_out[2 * b] = (int8_t)y.r0; reward_out[2 * b + 1] = (int8_t)y.r1; }
+            }
+        }
+        Image<kCells> is;
+        stage_all<kCells, 7>(is.p(), r);
+        out_all<kCells>(state + t.tile * (kTile * kCells), is.p(), t.rows);
+        if (mask_out) {
+            Image<kActions> im;
+            stage_all<kActions, 14>(im.p(), dm);
+            out_all<kActions>(mask_out + t.tile * (kTile * kActions), im.p(), t.rows);
+        }
+        if (obs_out) {
+            Image<kObs> io;
+            stage_all<kObs, 30>(io.p(), dobs);
+            out_all<kObs>(obs_out + t.tile * (kTile * kObs), io.p(), t.rows);
+        }
+    });
+}
+
+void emu_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_out, int8_t *winner_out,
+                 int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, uint64_t seed, uint64_t env_base,
+                 uint32_t ply0, uint32_t plies, int illegal_mode, int64_t *counters)
+{
+    for_tiles(n, [&](TileCtx t) {
+        uint32_t r[64][7], dm[64][14], dobs[64][30];
+        load_rows(state, t, r);
+        for (int l = 0; l < 64; ++l) {
+            bool valid = l < t.rows;
+            int64_t b = t.tile * 64 + l;
+            int mover = valid ? (to_move[b] != 0) : 0;
+            Planes p = make_planes(r[l]);
+            Ply y{0, 0, 0, false};
+            int dn = 0, action = -1;
+            for (uint32_t k = 0; k < plies; ++k) {
+                uint64_t legal = legal54(p, mover);
+                action = sample54(legal, seed, env_base + (uint64_t)b, ply0 + k);
+                step_lane(r[l], p, mover, 0, action, illegal_mode, 1, dn, y);
+                if (valid && counters) {
+                    counters[0] += 1;
+                    counters[1] += y.terminal;
+                    counters[2] += y.winner == 1;
+                    counters[3] += y.winner == -1;
+                }
+            }
+            mask_row(legal54(p, mover), dm[l]);
+            obs_row(p, mover, dobs[l]);
+            if (valid) {
+                to_move[b] = (int8_t)mover;
+                done[b] = (int8_t)dn;
+                if (actions_out) actions_out[b] = action;
+                if (winner_out) winner_out[b] = (int8_t)y.winner;
+                if (reward_out) { reward_out[2 * b] = (int8_t)y.r0; reward_out[2 * b + 1] = (int8_t)y.r1; }
+            }
+        }
+        Image<kCells> is;
+        stage_all<kCells, 7>(is.p(), r);
+        out_all<kCells>(state + t.tile * (kTile * kCells), is.p(), t.rows);
+        if (mask_out) {
+            Image<kActions> im;
+            stage_all<kActions, 14>(im.p(), dm);
+            out_all<kActions>(mask_out + t.tile * (kTile * kActions), im.p(), t.rows);
+        }
+        if (obs_out) {
+            Image<kObs> io;
+            stage_all<kObs, 30>(io.p(), dobs);
+            out_all<kObs>(obs_out + t.tile * (kTile * kObs), io.p(), t.rows);
+        }
+    });
+}
+
+void emu_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply)
+{
+    for_tiles(n, [&](TileCtx t) {
+        Image<kActions> img;
+        in_all<kActions>(mask + t.tile * (kTile * kActions), img.p(), t.rows);
+        for (int l = 0; l < t.rows; ++l) {
+            uint32_t d[14];
+            row_load<kActions>(img.p(), l, d);
+            int64_t b = t.tile * 64 + l;
+            actions[b] = sample54(mask_bits(d), seed, env_base + (uint64_t)b, ply);
+        }
+    });
+}
+
+void emu_decode_obs(const int8_t *obs, int8_t *state, int8_t *to_move, int64_t n)
+{
+    for_tiles(n, [&](TileCtx t) {
+        Image<kObs> img;
+        in_all<kObs>(obs + t.tile * (kTile * kObs), img.p(), t.rows);
+        uint32_t r[64][7];
+        for (int l = 0; l < 64; ++l) {
+            uint32_t d[30];
+            row_load<kObs>(img.p(), l, d);
+            int agent = decode_obs_row(d, r[l]);
+            if (l < t.rows) to_move[t.tile * 64 + l] = (int8_t)agent;
+        }
+        Image<kCells> is;
+        stage_all<kCells, 7>(is.p(), r);
+        out_all<kCells>(state + t.tile * (kTile * kCells), is.p(), t.rows);
+    });
+}
+
+void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_in, const int8_t *hist, int depth,
+                int32_t *action_out, int8_t *cand_out, int8_t *fallback_out, int64_t n)
+{
+    for_tiles(n, [&](TileCtx t) {
+        uint32_t r[64][7], dc[64][14];
+        load_rows(state, t, r);
+        Image<kActions> im;
+        if (mask_in) in_all<kActions>(mask_in + t.tile * (kTile * kActions), im.p(), t.rows);
+        for (int l = 0; l < 64; ++l) {
+            bool valid = l < t.rows;
+            int64_t b = t.tile * 64 + l;
+            Planes p = make_planes(r[l]);
+            int me = valid ? (to_move[b] != 0) : 0;
+            uint64_t mask;
+            if (mask_in) {
+                uint32_t d[14];
+                row_load<kActions>(im.p(), l, d);
+                mask = mask_bits(d);
+            } else
+                mask = legal54(p, me);
+            if (!valid) mask = 0;
+            uint32_t prev3 = 0x00FFFFFFu;
+            if (hist && valid) {
+                const int8_t *h = hist + (b * 2 + me) * 3;
+                prev3 = (uint32_t)(uint8_t)h[0] | ((uint32_t)(uint8_t)h[1] << 8) | ((uint32_t)(uint8_t)h[2] << 16);
+            }
+            GreedyResult g = greedy_decide(p, me, mask, depth, prev3);
+            mask_row(g.cands, dc[l]);
+            if (valid) {
+                action_out[b] = g.fallback ? -1 : g.chosen;
+                if (fallback_out) fallback_out[b] = g.fallback ? 1 : 0;
+            }
+        }
+        if (cand_out) {
+            Image<kActions> ic;
+            stage_all<kActions, 14>(ic.p(), dc);
+            out_all<kActions>(cand_out + t.tile * (kTile * kActions), ic.p(), t.rows);
+        }
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+"""CPU-side checks of the product's host code: the C-ABI library builds, loads and exports every
+symbol include/gobblet_hip.h declares (no compute call is made without a GPU); argument checks
+that do not need a device; the single-env AEC facade's turn logic against the golden trajectories
+(with a test-only oracle backend standing in for the GPU board)."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import gobblet_rl_amd as G
+from gobblet_rl_amd import _native as nat
+from tests.oracle_backend import OracleBoardBackend
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_all_exported():
+    hdr = open(os.path.join(ROOT, "include", "gobblet_hip.h")).read()
+    declared = set(re.findall(r"\b(gbl_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(nat.SIGNATURES), (declared ^ set(nat.SIGNATURES))
+    L = nat.lib()  # builds with hipcc if needed, loads, resolves every symbol
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_layout_info_and_host_side_argument_errors():
+    L = nat.lib()
+    info = (C.c_int32 * 6)()
+    assert L.gbl_layout_info(info) == 0 and list(info) == [1, 27, 54, 117, 64, 16]
+    assert L.gbl_layout_info(None) == nat.ERR_ARG and b"NULL" in L.gbl_last_error()
+    # n == 0 is a no-op, n < 0 and NULL pointers are argument errors -- all decided before any HIP call
+    assert L.gbl_winner(None, None, 0, None) == 0
+    assert L.gbl_winner(None, None, -1, None) == nat.ERR_ARG
+    assert L.gbl_winner(None, None, 5, None) == nat.ERR_ARG
+    assert L.gbl_legal_mask(16, 16, 24, 5, None) == nat.ERR_ALIGN  # mask pointer not 16-byte aligned
+    assert L.gbl_step(16, 16, 16, 16, None, None, None, None, 5, 7, 0, None) == nat.ERR_ARG  # bad illegal_mode
+    assert L.gbl_greedy(16, 16, None, None, 3, 16, None, None, 5, None) == nat.ERR_ARG       # depth 3 out of scope
+    assert L.gbl_observe(16, None, -1, 16, 5, None) == nat.ERR_ARG                           # needs to_move
+    with pytest.raises(nat.GobbletHipError):
+        nat.check(nat.ERR_ARG, "x")
+
+
+def test_no_cpu_fallback():
+    with pytest.raises(G.GobbletHipError):
+        G.BatchedBoard(8, device="cpu")
+    with pytest.raises(G.GobbletHipError):
+        G.BatchedGobblet(8, device="cpu")
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "gobblet-rl_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+(oracle|tests)\b", src, re.M), f
+                assert "gobblet_oracle" not in src and "libgobblet_emu" not in src, f
+
+
+# ---- the AEC facade's host logic (gobblet.py:123-290), oracle backend -----------------------------------
+
+def make_raw():
+    return G.gobblet_v1.raw_env(board_backend=OracleBoardBackend(1))
+
+
+def test_reset_starting():  # reference tests/test_gobblet_env.py:23-28
+    e = make_raw()
+    e.reset()
+    assert (e.board.squares == np.zeros(27)).all()
+    assert e.agent_selection == "player_1" and e.turn == 0 and e.action == -1 and e.infos == {"player_1": {}, "player_2": {}}
+
+
+def test_upstream_kat_through_raw_env(golden_dir):  # reference tests/test_manual_policy_collector.py
+    kat = json.load(open(os.path.join(golden_dir, "kat_collector.json")))
+    e = make_raw()
+    e.reset()
+    assert e.observe("player_1")["action_mask"].tolist() == kat["mask_after"]["output0"]
+    for name, a in zip(["output1", "output2", "output3", "output4"], kat["actions"]):
+        e.step(a)
+        assert e.observe(e.agent_selection)["action_mask"].tolist() == kat["mask_after"][name]
+    assert e._legal_moves() == kat["legal_moves_output6"]
+    e.step(kat["illegal_action"])
+    assert e.board.squares.astype(int).tolist() == kat["board_output8"]
+    assert e.agent_selection == "player_2"  # the turn passes on an illegal move (gobblet.py:244-246)
+
+
+def test_raw_env_replays_golden_games(golden_dir):
+    g = np.load(os.path.join(golden_dir, "random_games.npz"))
+    e = make_raw()
+    idx = np.flatnonzero(g["game"] < 12)
+    for i in idx:
+        if g["ply"][i] == 0:
+            e.reset()
+        assert e.agents.index(e.agent_selection) == g["mover"][i]
+        e.step(int(g["action"][i]))
+        assert np.array_equal(e.board.squares, g["squares_after"][i])
+        nxt = e.agent_selection
+        other = e.agents[1 - e.agents.index(nxt)]
+        o = e.observe(nxt)
+        assert o["observation"].dtype == np.int8 and o["observation"].shape == (3, 3, 13)
+        assert np.array_equal(o["action_mask"], g["mask_next"][i])
+        assert np.array_equal(e.observe(other)["action_mask"], g["mask_offturn"][i])
+        assert np.array_equal(e.observe("player_1")["observation"], g["obs_p1"][i])
+        assert np.array_equal(e.observe("player_2")["observation"], g["obs_p2"][i])
+        assert [e.rewards["player_1"], e.rewards["player_2"]] == g["reward"][i].tolist()
+        assert [e._cumulative_rewards["player_1"], e._cumulative_rewards["player_2"]] == g["cum_reward"][i].tolist()
+        assert e.terminations["player_1"] == bool(g["done"][i]) == e.terminations["player_2"]
+        assert e.observation_space(nxt).contains(o) and e.turn == g["ply"][i] + 1
+
+
+def test_aec_loop_like_example_basic():
+    """The loop of examples/example_basic.py:50-67 over env(): masked-random play to termination."""
+    rng = np.random.default_rng(0)
+    e = G.gobblet_v1.env(board_backend=OracleBoardBackend(1))
+    with pytest.raises(AttributeError):
+        e.step(0)  # OrderEnforcing: step before reset
+    for game in range(5):
+        e.reset()
+        totals = {"player_1": 0, "player_2": 0}
+        steps = 0
+        for agent in e.agent_iter():
+            observation, reward, termination, truncation, info = e.last()
+            totals[agent] += reward
+            if termination or truncation:
+                e.step(None)
+            else:
+                mask = observation["action_mask"]
+                e.step(int(rng.choice(np.arange(len(mask)), p=mask / np.sum(mask))))
+                steps += 1
+        assert sorted(totals.values()) == [-1, 1] and steps >= 5 and e.agents == []
+
+
+def test_env_illegal_move_terminates_with_minus_one():
+    e = G.gobblet_v1.env(board_backend=OracleBoardBackend(1))
+    e.reset()
+    for a in (18, 36):
+        e.last()
+        e.step(a)
+    obs, *_ = e.last()
+    assert obs["action_mask"][18] == 0  # piece 3 is covered now
+    before = e.unwrapped.board.squares.copy()
+    e.step(18)
+    assert np.array_equal(e.unwrapped.board.squares, before)
+    assert e.terminations == {"player_1": True, "player_2": True} == e.truncations
+    assert e.rewards == {"player_1": -1.0, "player_2": 0}
+    with pytest.raises(AssertionError):
+        G.gobblet_v1.env(board_backend=OracleBoardBackend(1)).reset() or e.step(54)
+
+
+def test_text_render_smoke(capsys):
+    e = G.gobblet_v1.raw_env(render_mode="text_full", board_backend=OracleBoardBackend(1))
+    e.reset()
+    e.step(18)
+    out = capsys.readouterr().out
+    assert "[TOP]" in out and "[LARGE]" in out and "+3" in out

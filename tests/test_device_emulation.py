@@ -1,0 +1,153 @@
+"""CPU check of the DEVICE code: gobblet-rl_amd/csrc/gobblet_device.h compiled for the host
+(tests/emu) against the oracle, on the golden vectors and on seeded self-play states.
+The GPU parity tests (tests/test_gpu_parity.py, -m gpu) run the same comparisons through the
+real kernels and the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from tests import emu
+
+
+def selfplay_states(n, plies, seed, p_illegal=0.05):
+    """n boards advanced by the oracle's fused rollout to varied game phases."""
+    rng = np.random.default_rng(seed)
+    state, tm, dn = oracle.batch_reset(n)
+    # stagger: board b plays (b % plies) plies so that all phases are present
+    for t in range(plies):
+        m = oracle.batch_legal_mask(state, tm)
+        a = oracle.batch_sample(m, seed, 0, t)
+        live = (np.arange(n) % plies) > t
+        a = np.where(live, a, -1).astype(np.int32)  # -1: out of range -> illegal no-op... keep those boards as is
+        s2, t2, d2 = state.copy(), tm.copy(), dn.copy()
+        oracle.batch_step(s2, t2, d2, a)
+        state[live], tm[live], dn[live] = s2[live], t2[live], d2[live]
+    return state, tm, dn, rng
+
+
+@pytest.fixture(scope="module")
+def boards(golden_dir):
+    return np.load(os.path.join(golden_dir, "board_functions.npz"))
+
+
+@pytest.fixture(scope="module")
+def games(golden_dir):
+    return np.load(os.path.join(golden_dir, "random_games.npz"))
+
+
+@pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 408])
+def test_board_functions_vs_golden(boards, n):
+    sq = np.ascontiguousarray(boards["squares"][:n])
+    assert np.array_equal(emu.flatboard(sq), boards["flatboard"][:n])
+    assert np.array_equal(emu.covered(sq), boards["covered"][:n])
+    assert np.array_equal(emu.winner(sq), boards["winner"][:n])
+    z, o = np.zeros(n, np.int8), np.ones(n, np.int8)
+    assert np.array_equal(emu.legal_mask(sq, z), boards["legal_p1"][:n])
+    assert np.array_equal(emu.legal_mask(sq, o), boards["legal_p2"][:n])
+    assert np.array_equal(emu.observe(sq, z, 0), boards["obs_p1"][:n])
+    assert np.array_equal(emu.observe(sq, z, 1), boards["obs_p2"][:n])
+    assert np.array_equal(emu.observe(sq, o, -1), boards["obs_p2"][:n])
+
+
+def test_step_vs_golden_games(games):
+    g = games
+    state = g["squares_before"].copy(); tm = g["mover"].copy(); dn = np.zeros(len(tm), np.int8)
+    out = emu.step(state, tm, dn, g["action"])
+    assert np.array_equal(state, g["squares_after"]) and np.array_equal(tm, g["to_move_after"])
+    assert np.array_equal(out["winner"], g["winner"]) and np.array_equal(dn, g["done"])
+    assert np.array_equal(out["reward"], g["reward"])
+    live = g["done"] == 0
+    assert np.array_equal(out["mask"][live], g["mask_next"][live]) and (out["mask"][~live] == 0).all()
+    obs_next = np.where(g["to_move_after"][:, None, None, None] == 0, g["obs_p1"], g["obs_p2"])
+    assert np.array_equal(out["obs"], obs_next)
+
+
+@pytest.mark.parametrize("n,illegal_mode,auto_reset", [(4096, 0, False), (1000, 0, True), (777, 1, False), (130, 1, True)])
+def test_step_vs_oracle_selfplay(n, illegal_mode, auto_reset):
+    state, tm, dn, rng = selfplay_states(n, 24, seed=n)
+    for t in range(6):
+        m = oracle.batch_legal_mask(state, tm)
+        a = oracle.batch_sample(m, 5, 0, 100 + t)
+        wild = rng.random(n) < 0.15
+        a = np.where(wild, rng.integers(-3, 58, n), a).astype(np.int32)
+        s1, t1, d1 = state.copy(), tm.copy(), dn.copy()
+        s2, t2, d2 = state.copy(), tm.copy(), dn.copy()
+        o1 = oracle.batch_step(s1, t1, d1, a, illegal_mode=illegal_mode, auto_reset=auto_reset)
+        o2 = emu.step(s2, t2, d2, a, illegal_mode=illegal_mode, auto_reset=auto_reset)
+        assert np.array_equal(s1, s2) and np.array_equal(t1, t2) and np.array_equal(d1, d2)
+        for k in o1:
+            assert np.array_equal(o1[k], o2[k]), k
+        state, tm, dn = s1, t1, d1
+    assert dn.sum() > 0 or auto_reset
+
+
+def test_board_api_vs_oracle_selfplay():
+    n = 2000
+    state, tm, dn, rng = selfplay_states(n, 30, seed=11)
+    assert np.array_equal(emu.legal_mask(state, tm), oracle.batch_legal_mask(state, tm))
+    assert np.array_equal(emu.legal_mask(state, 1 - tm), oracle.batch_legal_mask(state, (1 - tm).astype(np.int8)))
+    assert np.array_equal(emu.winner(state), oracle.batch_winner(state))
+    assert np.array_equal(emu.flatboard(state), oracle.batch_flatboard(state))
+    assert np.array_equal(emu.covered(state), oracle.batch_covered(state))
+    assert np.array_equal(emu.observe(state, tm, -1), oracle.batch_observe(state, tm, -1))
+    a = rng.integers(-2, 56, n).astype(np.int32)
+    ag = rng.integers(0, 2, n).astype(np.int8)
+    exp = np.array([(0 <= a[i] < 54) and oracle.is_legal(state[i], a[i], ag[i]) for i in range(n)], np.int8)
+    assert np.array_equal(emu.is_legal(state, ag, a), exp)
+    s2 = state.copy()
+    emu.play_turn(s2, ag, a)
+    exp_s = np.stack([oracle.play_turn(state[i], ag[i], a[i]) if 0 <= a[i] < 54 else state[i] for i in range(n)])
+    assert np.array_equal(s2, exp_s)
+
+
+def test_sampler_and_decode():
+    n = 1500
+    state, tm, dn, rng = selfplay_states(n, 20, seed=4)
+    m = oracle.batch_legal_mask(state, tm)
+    m[::97] = 0  # empty masks -> -1
+    assert np.array_equal(emu.sample(m, 9, 12345678901234, 7), oracle.batch_sample(m, 9, 12345678901234, 7))
+    obs = oracle.batch_observe(state, tm, -1)
+    st, who = emu.decode_obs(obs)
+    assert np.array_equal(st, state) and np.array_equal(who, tm)
+
+
+@pytest.mark.parametrize("n,plies", [(700, 1), (1000, 37)])
+def test_rollout_vs_oracle(n, plies):
+    s1, t1, d1 = oracle.batch_reset(n)
+    s2, t2, d2 = oracle.batch_reset(n)
+    o1 = oracle.batch_rollout(s1, t1, d1, 42, 5000, 3, plies)
+    o2 = emu.rollout(s2, t2, d2, 42, 5000, 3, plies)
+    assert np.array_equal(s1, s2) and np.array_equal(t1, t2) and np.array_equal(d1, d2)
+    for k in o1:
+        assert np.array_equal(o1[k], o2[k]), k
+
+
+@pytest.mark.parametrize("depth", [1, 2])
+def test_greedy_vs_golden_and_oracle(golden_dir, depth):
+    g = np.load(os.path.join(golden_dir, "greedy.npz"))
+    sq = np.ascontiguousarray(g["squares"]); tm = np.ascontiguousarray(g["to_move"])
+    act, cm, fb = emu.greedy(sq, tm, depth=depth)
+    assert np.array_equal(act, g[f"chosen_d{depth}"].astype(np.int32))
+    assert np.array_equal(cm, g[f"cands_d{depth}"]) and np.array_equal(fb, (act < 0).astype(np.int8))
+    act2, cm2, fb2 = emu.greedy(sq, tm, mask=np.ascontiguousarray(g["mask"]), depth=depth)
+    assert np.array_equal(act2, act) and np.array_equal(cm2, cm)
+    # history guard: the chosen action among the agent's last three -> fallback, action -1
+    hist = np.full((len(sq), 2, 3), -1, np.int8)
+    hist[np.arange(len(sq)), tm, 1] = act.astype(np.int8)  # (-1 = "none" where nothing was chosen)
+    act3, cm3, fb3 = emu.greedy(sq, tm, hist=hist, depth=depth)
+    assert (fb3 == 1).all() and (act3 == -1).all() and np.array_equal(cm3, cm)
+    o = oracle.batch_greedy(sq, tm, hist=hist, depth=depth)
+    assert np.array_equal(o[0], act3) and np.array_equal(o[1], cm3) and np.array_equal(o[2], fb3)
+
+
+def test_greedy_vs_oracle_selfplay():
+    state, tm, dn, rng = selfplay_states(600, 26, seed=8)
+    live = oracle.batch_winner(state) == 0
+    state, tm = np.ascontiguousarray(state[live]), np.ascontiguousarray(tm[live])
+    for depth in (1, 2):
+        e = emu.greedy(state, tm, depth=depth)
+        o = oracle.batch_greedy(state, tm, depth=depth)
+        for x, y in zip(e, o):
+            assert np.array_equal(x, y)

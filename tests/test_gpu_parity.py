@@ -1,0 +1,308 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the Python host code and the C-ABI, against
+the oracle on the same seeded inputs, against the committed golden vectors, and -- at
+BASELINE.json's full sizes -- through size-independent properties.  Bit-exact everywhere (all
+arithmetic is integer / byte work)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gobblet_rl_amd as g
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    g._native.lib()
+    return g
+
+
+def t(a, dtype=None):
+    x = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return x if dtype is None else x.to(dtype)
+
+
+def npy(x):
+    return x.cpu().numpy()
+
+
+def selfplay(n, plies, seed):
+    """n boards in staggered game phases, via the oracle."""
+    state, tm, dn = oracle.batch_reset(n)
+    for k in range(plies):
+        m = oracle.batch_legal_mask(state, tm)
+        a = oracle.batch_sample(m, seed, 0, k)
+        live = (np.arange(n) % plies) > k
+        s2, t2, d2 = state.copy(), tm.copy(), dn.copy()
+        oracle.batch_step(s2, t2, d2, a, threads=8)
+        state[live], tm[live], dn[live] = s2[live], t2[live], d2[live]
+    return state, tm, dn
+
+
+def vec_env(G, n, state, tm, dn, **kw):
+    env = G.BatchedGobblet(n, DEV, **kw)
+    env.board.squares = t(state)
+    env.to_move.copy_(t(tm)); env.done.copy_(t(dn))
+    env.refresh()
+    return env
+
+
+# ---- Board-level functions vs the golden vectors (reference outputs) ---------------------------------
+@pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 408])
+def test_board_functions_vs_golden(G, golden_dir, n):
+    g = np.load(os.path.join(golden_dir, "board_functions.npz"))
+    b = G.BatchedBoard(n, DEV, squares=t(g["squares"][:n]))
+    assert np.array_equal(npy(b.get_flatboard()), g["flatboard"][:n])
+    assert np.array_equal(npy(b.check_covered()), g["covered"][:n])
+    assert np.array_equal(npy(b.check_for_winner()), g["winner"][:n])
+    assert np.array_equal(npy(b.check_game_over()), g["game_over"][:n].astype(bool))
+    assert np.array_equal(npy(b.legal_mask(0)), g["legal_p1"][:n])
+    assert np.array_equal(npy(b.legal_mask(1)), g["legal_p2"][:n])
+    assert np.array_equal(npy(b.observation(0)), g["obs_p1"][:n])
+    assert np.array_equal(npy(b.observation(1)), g["obs_p2"][:n])
+    for a in (0, 13, 26, 40, 53):
+        assert np.array_equal(npy(b.is_legal(a, 0)), g["legal_p1"][:n, a].astype(bool))
+        assert np.array_equal(npy(b.is_legal(a, 1)), g["legal_p2"][:n, a].astype(bool))
+    for p in (0, 4, 8):
+        for s in (1, 2, 3):
+            assert np.array_equal(npy(b.get_action(p, s, 0)), g["get_action_p1"][:n, p, s - 1])
+            assert np.array_equal(npy(b.get_action(p, s, 1)), g["get_action_p2"][:n, p, s - 1])
+
+
+def test_upstream_kat(G, golden_dir):
+    """reference tests/test_manual_policy_collector.py: 18, 36, 28, 46 then illegal 29."""
+    kat = json.load(open(os.path.join(golden_dir, "kat_collector.json")))
+    env = G.BatchedGobblet(1, DEV)
+    assert npy(env.action_mask)[0].tolist() == kat["mask_after"]["output0"]
+    assert (npy(env.squares) == 0).all()  # tests/test_gobblet_env.py:23-28
+    for name, a in zip(["output1", "output2", "output3", "output4"], kat["actions"]):
+        obs, rew, done, win = env.step([a])
+        assert npy(obs["action_mask"])[0].tolist() == kat["mask_after"][name]
+        assert int(done[0]) == 0 and int(win[0]) == 0
+    assert np.flatnonzero(npy(env.action_mask)[0]).tolist() == kat["legal_moves_output6"]
+    env.step([kat["illegal_action"]])
+    assert npy(env.squares)[0].tolist() == kat["board_output8"]
+    assert int(env.to_move[0]) == kat["reference_to_move_after_illegal"]
+
+
+def test_step_vs_golden_games(G, golden_dir):
+    g = np.load(os.path.join(golden_dir, "random_games.npz"))
+    n = len(g["action"])
+    env = vec_env(G, n, g["squares_before"], g["mover"], np.zeros(n, np.int8))
+    obs, rew, done, win = env.step(t(g["action"]))
+    assert np.array_equal(npy(env.squares), g["squares_after"])
+    assert np.array_equal(npy(env.to_move), g["to_move_after"])
+    assert np.array_equal(npy(win), g["winner"]) and np.array_equal(npy(done), g["done"])
+    assert np.array_equal(npy(rew), g["reward"])
+    live = g["done"] == 0
+    m = npy(obs["action_mask"])
+    assert np.array_equal(m[live], g["mask_next"][live]) and (m[~live] == 0).all()
+    obs_next = np.where(g["to_move_after"][:, None, None, None] == 0, g["obs_p1"], g["obs_p2"])
+    assert np.array_equal(npy(obs["observation"]), obs_next)
+
+
+# ---- fused step vs the oracle, all modes, ragged and large sizes ---------------------------------------
+@pytest.mark.parametrize("n,illegal,auto_reset,with_obs", [
+    (4096, "noop", False, True), (4096, "noop", True, True), (4099, "terminate", False, True),
+    (1000, "terminate", True, False), (37, "noop", False, False), (262144, "noop", True, True)])
+def test_step_vs_oracle(G, n, illegal, auto_reset, with_obs):
+    rng = np.random.default_rng(n)
+    state, tm, dn = selfplay(n, 24, seed=n % 1000)
+    env = vec_env(G, n, state, tm, dn, illegal_mode=illegal, auto_reset=auto_reset, with_observation=with_obs)
+    imode = {"noop": 0, "terminate": 1}[illegal]
+    for k in range(4 if n > 100000 else 8):
+        m = oracle.batch_legal_mask(state, tm)
+        a = oracle.batch_sample(m, 5, 0, 100 + k)
+        wild = rng.random(n) < 0.12
+        a = np.where(wild, rng.integers(-3, 58, n), a).astype(np.int32)
+        o = oracle.batch_step(state, tm, dn, a, illegal_mode=imode, auto_reset=auto_reset, threads=8)
+        obs, rew, done, win = env.step(t(a))
+        assert np.array_equal(npy(env.squares), state), k
+        assert np.array_equal(npy(env.to_move), tm) and np.array_equal(npy(done), dn)
+        assert np.array_equal(npy(win), o["winner"]) and np.array_equal(npy(rew), o["reward"])
+        assert np.array_equal(npy(obs["action_mask"]), o["mask"])
+        if with_obs:
+            assert np.array_equal(npy(obs["observation"]), o["obs"])
+        else:
+            assert obs["observation"] is None
+
+
+def test_step_optional_outputs_null(G):
+    """winner / reward / mask / obs pointers may be NULL (MASK_ONLY and bare variants)."""
+    from gobblet_rl_amd import _native as nat
+    n = 1000
+    state, tm, dn = selfplay(n, 20, seed=3)
+    a = oracle.batch_sample(oracle.batch_legal_mask(state, tm), 1, 0, 0)
+    exp_s, exp_t, exp_d = state.copy(), tm.copy(), dn.copy()
+    oracle.batch_step(exp_s, exp_t, exp_d, a)
+    s, tmv, d, av = t(state), t(tm), t(dn), t(a)
+    nat.check(nat.lib().gbl_step(s.data_ptr(), tmv.data_ptr(), d.data_ptr(), av.data_ptr(), None, None, None, None,
+                                 n, 0, 0, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(npy(s), exp_s) and np.array_equal(npy(tmv), exp_t) and np.array_equal(npy(d), exp_d)
+
+
+def test_board_api_vs_oracle(G):
+    n = 5000
+    rng = np.random.default_rng(1)
+    state, tm, dn = selfplay(n, 30, seed=11)
+    b = G.BatchedBoard(n, DEV, squares=t(state))
+    assert np.array_equal(npy(b.legal_mask(t(tm))), oracle.batch_legal_mask(state, tm))
+    assert np.array_equal(npy(b.check_for_winner()), oracle.batch_winner(state))
+    assert np.array_equal(npy(b.get_flatboard()), oracle.batch_flatboard(state))
+    assert np.array_equal(npy(b.check_covered()), oracle.batch_covered(state))
+    assert np.array_equal(npy(b.observation(t(tm))), oracle.batch_observe(state, tm, -1))
+    a = rng.integers(-2, 56, n).astype(np.int32)
+    ag = rng.integers(0, 2, n).astype(np.int8)
+    exp = np.array([(0 <= a[i] < 54) and oracle.is_legal(state[i], a[i], ag[i]) for i in range(n)])
+    assert np.array_equal(npy(b.is_legal(t(a), t(ag))), exp)
+    b.play_turn(t(ag), t(a))
+    exp_s = np.stack([oracle.play_turn(state[i], ag[i], a[i]) if 0 <= a[i] < 54 else state[i] for i in range(n)])
+    assert np.array_equal(npy(b.squares), exp_s)
+
+
+def test_sampler_and_rollout_vs_oracle(G):
+    n, plies, seed, base = 4096 + 17, 48, 9, 123456789012
+    env = G.BatchedGobblet(n, DEV, auto_reset=True, seed=seed, env_base=base)
+    s, tm, dn = oracle.batch_reset(n)
+    # separate kernels: sample -> step, ply by ply
+    for k in range(12):
+        a = env.sample_actions()
+        m = oracle.batch_legal_mask(s, tm)
+        exp_a = oracle.batch_sample(m, seed, base, k)
+        assert np.array_equal(npy(a), exp_a)
+        env.step(a)
+        oracle.batch_step(s, tm, dn, exp_a, auto_reset=True)
+        assert np.array_equal(npy(env.squares), s)
+    # fused rollout continues the same stream (ply index carries on)
+    for every in (False, True):
+        o = oracle.batch_rollout(s, tm, dn, seed, base, env.ply, plies, threads=8)
+        before = npy(env.counters).copy()
+        obs, rew, done, win = env.rollout(plies, every_ply=every)
+        assert np.array_equal(npy(env.squares), s) and np.array_equal(npy(env.to_move), tm)
+        assert np.array_equal(npy(done), dn) and np.array_equal(npy(win), o["winner"])
+        assert np.array_equal(npy(rew), o["reward"]) and np.array_equal(npy(env.actions), o["actions"])
+        assert np.array_equal(npy(obs["action_mask"]), o["mask"])
+        assert np.array_equal(npy(obs["observation"]), o["obs"])
+        assert np.array_equal(npy(env.counters) - before, o["counters"])
+
+
+def test_decode_obs_and_greedy_vs_golden(G, golden_dir):
+    from gobblet_rl_amd import _native as nat
+    g = np.load(os.path.join(golden_dir, "greedy.npz"))
+    n = len(g["squares"])
+    L = nat.lib()
+    obs = t(g["obs"]); st = torch.empty((n, 27), dtype=torch.int8, device=DEV); who = torch.empty(n, dtype=torch.int8, device=DEV)
+    nat.check(L.gbl_decode_obs(obs.data_ptr(), st.data_ptr(), who.data_ptr(), n, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(npy(st), g["squares"]) and np.array_equal(npy(who), g["to_move"])
+    for depth in (1, 2):
+        act = torch.empty(n, dtype=torch.int32, device=DEV); cm = torch.empty((n, 54), dtype=torch.int8, device=DEV)
+        fb = torch.empty(n, dtype=torch.int8, device=DEV)
+        for mask in (None, t(g["mask"])):
+            nat.check(L.gbl_greedy(st.data_ptr(), who.data_ptr(), nat.ptr(mask), None, depth, act.data_ptr(),
+                                   cm.data_ptr(), fb.data_ptr(), n, None))
+            torch.cuda.synchronize()
+            assert np.array_equal(npy(act), g[f"chosen_d{depth}"].astype(np.int32))
+            assert np.array_equal(npy(cm), g[f"cands_d{depth}"])
+            assert np.array_equal(npy(fb), (g[f"chosen_d{depth}"] < 0).astype(np.int8))
+    assert int(g["chosen_d1"][320]) == 8 and int(npy(act)[320]) == 7  # App. B quirk: depth 2 overwrites the win
+
+
+def test_greedy_vs_oracle_selfplay(G):
+    from gobblet_rl_amd import _native as nat
+    state, tm, dn = selfplay(3000, 26, seed=8)
+    live = oracle.batch_winner(state) == 0
+    state, tm = np.ascontiguousarray(state[live]), np.ascontiguousarray(tm[live])
+    n = len(state)
+    rng = np.random.default_rng(2)
+    hist = rng.integers(-1, 54, (n, 2, 3)).astype(np.int8)
+    L = nat.lib()
+    st, who, h = t(state), t(tm), t(hist)
+    for depth in (1, 2):
+        act = torch.empty(n, dtype=torch.int32, device=DEV); cm = torch.empty((n, 54), dtype=torch.int8, device=DEV)
+        fb = torch.empty(n, dtype=torch.int8, device=DEV)
+        nat.check(L.gbl_greedy(st.data_ptr(), who.data_ptr(), None, h.data_ptr(), depth, act.data_ptr(), cm.data_ptr(),
+                               fb.data_ptr(), n, None))
+        torch.cuda.synchronize()
+        o = oracle.batch_greedy(state, tm, hist=hist, depth=depth)
+        assert np.array_equal(npy(act), o[0]) and np.array_equal(npy(cm), o[1]) and np.array_equal(npy(fb), o[2])
+
+
+# ---- full size (2^20 boards): one step against the oracle + invariants of a long rollout -----------------
+def test_full_size_step_and_rollout_properties(G):
+    n = 1 << 20
+    env = G.BatchedGobblet(n, DEV, auto_reset=True, seed=0)
+    env.rollout(64)                       # warm-up plies of the benchmark workload
+    state, tm = npy(env.squares), npy(env.to_move)
+    # invariants of reachable states: every piece at most once, on its own level
+    for k in range(3):
+        lvl = state[:, 9 * k:9 * k + 9].astype(np.int16)
+        assert np.isin(np.abs(lvl), [0, 2 * k + 1, 2 * k + 2]).all()
+        for v in (2 * k + 1, 2 * k + 2, -(2 * k + 1), -(2 * k + 2)):
+            assert ((lvl == v).sum(1) <= 1).all()
+    assert (oracle.batch_winner(state) == 0).all()          # terminated boards were reset
+    assert np.array_equal(npy(env.action_mask), oracle.batch_legal_mask(state, tm))
+    c = npy(env.counters)
+    assert c[0] == n * 64 and c[1] == c[2] + c[3] and 0.3 < c[2] / c[1] < 0.7
+    # one more lockstep ply through sample + step, checked in full against the oracle
+    a = npy(env.sample_actions())
+    dn = np.zeros(n, np.int8)
+    o = oracle.batch_step(state, tm, dn, a, auto_reset=True, threads=16)
+    obs, rew, done, win = env.step(env.actions)
+    assert np.array_equal(npy(env.squares), state) and np.array_equal(npy(done), dn)
+    assert np.array_equal(npy(obs["action_mask"]), o["mask"]) and np.array_equal(npy(obs["observation"]), o["obs"])
+    assert np.array_equal(npy(win), o["winner"])
+    # determinism: the same seed replays the same trajectory; sharding does not change it
+    e1 = G.BatchedGobblet(4096, DEV, auto_reset=True, seed=7, env_base=0)
+    e2 = G.BatchedGobblet(2048, DEV, auto_reset=True, seed=7, env_base=2048)
+    e1.rollout(50); e2.rollout(50)
+    assert np.array_equal(npy(e1.squares)[2048:], npy(e2.squares))
+
+
+def test_error_behaviour(G):
+    from gobblet_rl_amd import _native as nat
+    L = nat.lib()
+    x = torch.zeros(64 * 27 + 16, dtype=torch.int8, device=DEV)
+    out = torch.zeros(64, dtype=torch.int8, device=DEV)
+    assert L.gbl_winner(x.data_ptr() + 1, out.data_ptr(), 8, None) == nat.ERR_ALIGN
+    assert b"aligned" in L.gbl_last_error()
+    with pytest.raises(ValueError):
+        G.BatchedGobblet(8, DEV).step(torch.zeros(9, dtype=torch.int32, device=DEV))
+    with pytest.raises(ValueError):
+        G.BatchedGobblet(8, DEV, illegal_mode="bogus")
+
+
+# ---- the single-env AEC surface on the real engine (BASELINE.json configs[0] plumbing) -------------------
+def test_aec_facade_on_gpu(G, golden_dir):
+    g = np.load(os.path.join(golden_dir, "random_games.npz"))
+    e = G.gobblet_v1.raw_env(device=DEV)
+    for i in np.flatnonzero(g["game"] < 6):
+        if g["ply"][i] == 0:
+            e.reset()
+        e.step(int(g["action"][i]))
+        assert np.array_equal(e.board.squares, g["squares_after"][i])
+        o = e.observe(e.agent_selection)
+        assert np.array_equal(o["action_mask"], g["mask_next"][i])
+        assert np.array_equal(e.observe("player_1")["observation"], g["obs_p1"][i])
+        assert [e.rewards["player_1"], e.rewards["player_2"]] == g["reward"][i].tolist()
+    rng = np.random.default_rng(0)
+    env = G.gobblet_v1.env(device=DEV)
+    env.reset()
+    totals = {"player_1": 0, "player_2": 0}
+    for agent in env.agent_iter():  # examples/example_basic.py:50-67
+        observation, reward, termination, truncation, info = env.last()
+        totals[agent] += reward
+        if termination or truncation:
+            env.step(None)
+        else:
+            mask = observation["action_mask"]
+            env.step(int(rng.choice(np.arange(len(mask)), p=mask / np.sum(mask))))
+    assert sorted(totals.values()) == [-1, 1]
