@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the batched Gobblet hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--boards B] [--mode step|rollout]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--boards B] [--mode fused|step] [--graph 0|1]
 
 One "step" = one lockstep ply of the benchmark pipeline over this rank's shard of boards:
-    mode step    (default): gbl_sample (masked-uniform action from the mask buffer) + gbl_step
-                 (fused raw_env.step + observe: state, mask, obs, winner, reward, done written) --
-                 two launches per ply, every ply's mask and observation materialised in HBM.
-    mode rollout: gbl_rollout with every_ply=1 -- the same per-ply outputs, K plies in ONE launch
-                 (state stays in registers between plies).
+    mode fused (default): gbl_rollout(plies=1) -- masked-uniform sampling + raw_env.step + observe
+                 fused into ONE launch per ply; state, action, mask, obs, winner, reward, done of
+                 every ply are materialised in HBM (a consumer can read them after each launch).
+    mode step  : gbl_sample (action from the mask buffer) + gbl_step (externally supplied
+                 actions: the drop-in form of raw_env.step + observe) -- two launches per ply.
+By default the K timed plies are replayed as one hipGraph (captured and instantiated before the
+timed region; every kernel node carries its own ply index); --graph 0 launches eagerly.
 Workload: 2^20 boards per GPU, all reset, 64 warm-up plies of masked-random
 play with auto-reset (stationary mix of game phases), then K timed plies; synthetic data, RNG
 keyed (seed=0, global board id, ply) so results do not depend on the number of GPUs.  Boards shard
@@ -42,10 +44,23 @@ def parse():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--boards", type=int, default=1 << 20, help="boards per GPU")
-    ap.add_argument("--mode", choices=["step", "rollout"], default="step")
+    ap.add_argument("--mode", choices=["step", "fused"], default="fused")
+    ap.add_argument("--graph", type=int, default=1, help="1: replay the K timed plies as one hipGraph; 0: eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
+
+
+def host_cores():
+    """Cores this process may actually use: the affinity mask, cut down to the cgroup CPU quota."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, min(cores, 64))
 
 
 def cpu_baseline(boards, warmup, target_s):
@@ -54,7 +69,7 @@ def cpu_baseline(boards, warmup, target_s):
     import numpy as np
 
     import oracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     n = min(boards, 1 << 18)
     s, tm, dn = oracle.batch_reset(n)
     oracle.batch_rollout(s, tm, dn, 0, 0, 0, warmup, threads=cores, want_obs=False, want_mask=False)
@@ -109,44 +124,59 @@ def main():
     boards = args.boards
     env = G.BatchedGobblet(boards, dev, illegal_mode="noop", auto_reset=True, seed=0, env_base=rank * boards)
     K, W = args.steps, args.warmup
+    lib, nat = G._native.lib(), G._native
+    P = dict(sq=env.squares.data_ptr(), tm=env.to_move.data_ptr(), dn=env.done.data_ptr(),
+             ac=env.actions.data_ptr(), wi=env.winner.data_ptr(), rw=env.rewards.data_ptr(),
+             mk=env.action_mask.data_ptr(), ob=env.observation.data_ptr())
 
-    def one_ply():
-        env.sample_actions()
-        env.step(env.actions)
+    def enqueue_ply(ply, stream, ev=None):
+        """One ply of the pipeline on `stream`; ev = (start, stop) events bracketing the dominant kernel."""
+        if args.mode == "step":
+            lib.gbl_sample(P["mk"], P["ac"], boards, env.seed, env.env_base, ply, stream)
+            if ev:
+                ev[0].record()
+            rc = lib.gbl_step(P["sq"], P["tm"], P["dn"], P["ac"], P["wi"], P["rw"], P["mk"], P["ob"], boards, 0, 1,
+                              stream)
+        else:
+            if ev:
+                ev[0].record()
+            rc = lib.gbl_rollout(P["sq"], P["tm"], P["dn"], P["ac"], P["wi"], P["rw"], P["mk"], P["ob"], boards,
+                                 env.seed, env.env_base, ply, 1, 0, None, stream)
+        if ev:
+            ev[1].record()
+        return rc
 
     # warm-up plies (untimed): decorrelate game phases, warm caches / code objects
-    if args.mode == "step":
-        for _ in range(W):
-            one_ply()
-    else:
-        if W:
-            env.rollout(W, every_ply=True)
+    for k in range(W):
+        nat.check(enqueue_ply(k, nat.current_stream(dev)), "warm-up")
     torch.cuda.synchronize(dev)
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(K if args.mode == "step" else 1)]
+    graph = None
+    if args.graph:
+        # the K timed plies as ONE hipGraph (every kernel node carries its own ply index);
+        # capture + instantiate happen here, outside the timed region; the replay is timed
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            cs = nat.current_stream(dev)
+            for k in range(K):
+                nat.check(enqueue_ply(W + k, cs), "capture")
+        torch.cuda.synchronize(dev)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))]
+    else:
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    if args.mode == "step":
-        lib, nat = G._native.lib(), G._native
-        stream = nat.current_stream(dev)
-        p = dict(sq=env.squares.data_ptr(), tm=env.to_move.data_ptr(), dn=env.done.data_ptr(),
-                 ac=env.actions.data_ptr(), wi=env.winner.data_ptr(), rw=env.rewards.data_ptr(),
-                 mk=env.action_mask.data_ptr(), ob=env.observation.data_ptr())
-        for k in range(K):
-            lib.gbl_sample(p["mk"], p["ac"], boards, env.seed, env.env_base, env.ply, stream)
-            ev[k][0].record()
-            rc = lib.gbl_step(p["sq"], p["tm"], p["dn"], p["ac"], p["wi"], p["rw"], p["mk"], p["ob"], boards, 0, 1,
-                              stream)
-            ev[k][1].record()
-            env.ply += 1
-        nat.check(rc, "gbl_step")
-    else:
+    if graph is not None:
         ev[0][0].record()
-        env.rollout(K, every_ply=True)
+        graph.replay()
         ev[0][1].record()
+    else:
+        stream = nat.current_stream(dev)
+        for k in range(K):
+            rc = enqueue_ply(W + k, stream, ev[k])
+        nat.check(rc, "timed plies")
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -158,9 +188,16 @@ def main():
         elapsed = float(tt.item())
 
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    launches = len(kernel_ms)
-    mean_kernel_s = sum(kernel_ms) / launches / 1e3
-    units_per_launch = boards * (1 if args.mode == "step" else K)
+    if graph is not None:
+        # events bracket the whole replay: K dominant-kernel launches (+ K sampler launches in step
+        # mode, which are subtracted pro rata by their share of algorithmic bytes: 58 of 292)
+        share = 1.0 if args.mode == "fused" else ALGO_BYTES_FULL / (ALGO_BYTES_FULL + 58.0)
+        mean_kernel_s = kernel_ms[0] * share / K / 1e3
+        launches = K
+    else:
+        launches = len(kernel_ms)
+        mean_kernel_s = sum(kernel_ms) / launches / 1e3
+    units_per_launch = boards
     achieved = ALGO_BYTES_FULL * units_per_launch / mean_kernel_s / 1e9
 
     if rank == 0:
@@ -190,19 +227,20 @@ def main():
             "config": {"workload": f"{boards} boards per GPU x {world} GPU(s), masked-random actions, auto-reset, "
                                    f"FULL outputs (state+mask+obs+winner+reward+done) every ply",
                        "boards_per_gpu": boards, "total_boards": boards * world, "mode": args.mode,
-                       "launches_per_step": 2 if args.mode == "step" else round(1.0 / K, 6),
+                       "launches_per_step": 2 if args.mode == "step" else 1,
                        "sharding": f"contiguous board ranges, {world} shard(s), no collective on the step path"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_step<mask,obs>" if args.mode == "step" else "k_rollout<every_ply>",
+                         "kernel": "k_step<mask,obs>" if args.mode == "step" else "k_rollout<mask,obs> (plies=1)",
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_FULL,
                          "env_steps_per_launch": units_per_launch,
-                         "mean_launch_us": mean_kernel_s * 1e6, "launches_timed": launches},
+                         "mean_launch_us": mean_kernel_s * 1e6, "launches_timed": launches,
+                         "timing": ("HIP events around the graph replay / K (includes kernel boundaries)"
+                                    if graph is not None else "HIP event pair around every launch")},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(boards, W, args.cpu_seconds)
-        c = env.counters.cpu().tolist()
-        out["config"]["games_finished_rank0"] = int(c[1])
+        out["config"]["launch"] = "hipGraph replay of K plies" if graph is not None else "eager"
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -17,7 +17,8 @@ import torch  # noqa: F401  (must precede loading the HIP library, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libgobblet_hip.so")
+# GOBBLET_HIP_LIB: load a differently built library of the same ABI (kernel A/B experiments)
+LIB_PATH = os.environ.get("GOBBLET_HIP_LIB") or os.path.join(CSRC, "libgobblet_hip.so")
 SOURCES = [os.path.join(CSRC, "gobblet_hip.hip"), os.path.join(CSRC, "gobblet_device.h"),
            os.path.join(_HERE, "..", "include", "gobblet_hip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mcode-object-version=5"]
@@ -25,6 +26,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 OK, ERR_ARG, ERR_ALIGN, ERR_HIP = 0, -1, -2, -3
 ILLEGAL_NOOP, ILLEGAL_TERMINATE = 0, 1
 CELLS, ACTIONS, OBS_BYTES = 27, 54, 117
+COUNTER_STRIPES, COUNTER_STRIDE = 64, 16
 
 # every symbol include/gobblet_hip.h declares: (name, restype, argtypes)
 _vp, _i64, _u64, _u32, _int = C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_int
@@ -41,7 +43,7 @@ SIGNATURES = {
     "gbl_observe": (_int, [_vp, _vp, _int, _vp, _i64, _vp]),
     "gbl_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
     "gbl_sample": (_int, [_vp, _vp, _i64, _u64, _u64, _u32, _vp]),
-    "gbl_rollout": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u64, _u64, _u32, _u32, _int, _int, _vp, _vp]),
+    "gbl_rollout": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u64, _u64, _u32, _u32, _int, _vp, _vp]),
     "gbl_decode_obs": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "gbl_greedy": (_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp]),
 }
@@ -52,6 +54,8 @@ class GobbletHipError(RuntimeError):
 
 
 def needs_build() -> bool:
+    if os.environ.get("GOBBLET_HIP_LIB"):
+        return not os.path.exists(LIB_PATH)
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)

@@ -48,18 +48,41 @@ __device__ __forceinline__ int64_t xcd_tile(uint32_t bid, int64_t ntiles)
 
 // ---- tile <-> LDS image ---------------------------------------------------------------
 // g points at the tile's first byte (16-byte aligned); rows = valid boards in the tile.
+// Full tiles move as 16-byte vectors, lane l handling vectors l, l+64, ... : every wave
+// instruction covers 1 KiB of contiguous HBM.  All loads of a tile are issued before the first
+// dependent LDS write (and all LDS reads before the first store) so they overlap.
+#ifndef GBL_NT_STORES
+#define GBL_NT_STORES 1  // non-temporal hint on the mask / obs tile stores (write-once streams; 0 = plain stores, A/B knob)
+#endif
+
+__device__ __forceinline__ void store16(uint4 *dst, const uint4 &v, bool nt)
+{
+#if GBL_NT_STORES && !defined(GBL_HOST_EMU)
+    if (nt) {
+        typedef uint32_t __attribute__((ext_vector_type(4))) v4u;
+        v4u t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<v4u *>(dst));
+        return;
+    }
+#endif
+    (void)nt;
+    *dst = v;
+}
+
 template <int ROWB>
 __device__ __forceinline__ void tile_in(const int8_t *__restrict__ g, uint32_t *lds, int lane, int rows)
 {
-    constexpr int NV = kTile * ROWB / 16;
+    constexpr int NV = kTile * ROWB / 16, FULL = NV / 64, REM = NV % 64;
     if (rows == kTile) {
         const uint4 *gv = reinterpret_cast<const uint4 *>(g);
         uint4 *lv = reinterpret_cast<uint4 *>(lds);
+        uint4 v[FULL + 1];
 #pragma unroll
-        for (int i = 0; i < (NV + 63) / 64; ++i) {
-            int idx = lane + 64 * i;
-            if (idx < NV) lv[idx] = gv[idx];
-        }
+        for (int i = 0; i < FULL; ++i) v[i] = gv[lane + 64 * i];
+        if (REM && lane < REM) v[FULL] = gv[lane + 64 * FULL];
+#pragma unroll
+        for (int i = 0; i < FULL; ++i) lv[lane + 64 * i] = v[i];
+        if (REM && lane < REM) lv[lane + 64 * FULL] = v[FULL];
     } else {  // ragged last tile: byte granular
         int bytes = rows * ROWB;
         int8_t *lb = reinterpret_cast<int8_t *>(lds);
@@ -68,22 +91,37 @@ __device__ __forceinline__ void tile_in(const int8_t *__restrict__ g, uint32_t *
 }
 
 template <int ROWB>
-__device__ __forceinline__ void tile_out(int8_t *__restrict__ g, const uint32_t *lds, int lane, int rows)
+__device__ __forceinline__ void tile_out(int8_t *__restrict__ g, const uint32_t *lds, int lane, int rows,
+                                         bool nt = false)
 {
-    constexpr int NV = kTile * ROWB / 16;
+    constexpr int NV = kTile * ROWB / 16, FULL = NV / 64, REM = NV % 64;
     if (rows == kTile) {
         uint4 *gv = reinterpret_cast<uint4 *>(g);
         const uint4 *lv = reinterpret_cast<const uint4 *>(lds);
+        uint4 v[FULL + 1];
 #pragma unroll
-        for (int i = 0; i < (NV + 63) / 64; ++i) {
-            int idx = lane + 64 * i;
-            if (idx < NV) gv[idx] = lv[idx];
-        }
+        for (int i = 0; i < FULL; ++i) v[i] = lv[lane + 64 * i];
+        if (REM && lane < REM) v[FULL] = lv[lane + 64 * FULL];
+#pragma unroll
+        for (int i = 0; i < FULL; ++i) store16(&gv[lane + 64 * i], v[i], nt);
+        if (REM && lane < REM) store16(&gv[lane + 64 * FULL], v[FULL], nt);
     } else {
         int bytes = rows * ROWB;
         const int8_t *lb = reinterpret_cast<const int8_t *>(lds);
         for (int i = lane; i < bytes; i += 64) g[i] = lb[i];
     }
+}
+
+// Orders this wave's LDS accesses across lanes.  A workgroup is ONE wavefront, whose LDS
+// instructions execute in issue order, so no s_barrier and no vmcnt drain is needed (a
+// __syncthreads() would also wait for every outstanding global store); the fence only keeps the
+// compiler from moving LDS accesses across this point.
+__device__ __forceinline__ void wave_lds_fence()
+{
+#ifndef GBL_HOST_EMU
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
 }
 
 // ---- LDS image <-> one row per lane ---------------------------------------------------
@@ -274,6 +312,40 @@ __device__ __forceinline__ void obs_row(const Planes &p, int observer, uint32_t 
             w |= bitv << (8 * b);
         }
         d[j] = w;
+    }
+}
+
+// The same observation written SPARSELY into a tile's LDS image: an observation has at most 12
+// ones among channels 0..11 (one per piece on the board) plus the 9 bytes of channel 12, so instead
+// of building 30 dwords per board (obs_row: ~2 VALU per byte) the wave zero-fills the image with
+// 16-byte stores and every lane then drops single bytes at  lane*117 + 13*pos + ch  -- one
+// predicated ds_write_b8 per piece.  Relies on the state contract (a piece number occurs at most
+// once), like everything else.  Call obs_image_zero, fence, obs_scatter, fence, tile_out.
+__device__ __forceinline__ void obs_image_zero(uint32_t *img, int lane)
+{
+    constexpr int NV = kTile * kObs / 16, FULL = NV / 64, REM = NV % 64;
+    uint4 *lv = reinterpret_cast<uint4 *>(img);
+    const uint4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < FULL; ++i) lv[lane + 64 * i] = z;
+    if (REM && lane < REM) lv[lane + 64 * FULL] = z;
+}
+
+__device__ __forceinline__ void obs_scatter(uint32_t *img, int lane, const Planes &p, int observer)
+{
+    uint8_t *row = reinterpret_cast<uint8_t *>(img) + lane * kObs;
+    uint32_t pos = p.nz & ~p.neg, ngv = p.nz & p.neg;
+    uint32_t own = observer ? ngv : pos, opp = observer ? pos : ngv;
+    uint32_t X[4] = {own & p.odd, own & ~p.odd, opp & p.odd, opp & ~p.odd};  // A B C D
+#pragma unroll
+    for (int ch = 0; ch < 12; ++ch) {
+        int k = (ch % 6) / 2;
+        uint32_t grp = (X[(ch < 6 ? 0 : 2) + (ch & 1)] >> (9 * k)) & 0x1FFu;
+        if (grp) row[13 * __builtin_ctz(grp) + ch] = 1;
+    }
+    if (observer) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) row[13 * q + 12] = 1;
     }
 }
 

@@ -68,7 +68,7 @@ __device__ __forceinline__ bool lane_setup(Lane &L, int64_t n, int64_t ntiles)
 __device__ __forceinline__ void load_state(const int8_t *state, uint32_t *img, const Lane &L, uint32_t (&r)[7])
 {
     tile_in<kCells>(state + L.tile * (kTile * kCells), img, L.lane, L.rows);
-    __syncthreads();
+    wave_lds_fence();
     row_load<kCells>(img, L.lane, r);
     r[6] &= 0x00FFFFFFu;
     if (!L.valid) {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64) void k_legal_mask(const int8_t *__restrict__ st
     uint32_t d[14];
     mask_row(legal54(p, mover != 0), d);
     row_stage<kActions>(s_mask, L.lane, d);
-    __syncthreads();
+    wave_lds_fence();
     tile_out<kActions>(mask + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
 }
 
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64) void k_play_turn(int8_t *__restrict__ state, co
     bool ok = L.valid && (uint32_t)a < (uint32_t)kActions && ((m >> (a & 63)) & 1ull);
     if (ok) apply_move(p, r, mover, (uint32_t)a);
     row_stage<kCells>(s_state, L.lane, r);
-    __syncthreads();
+    wave_lds_fence();
     tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
 }
 
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64) void k_flatboard(const int8_t *__restrict__ sta
     uint32_t d[3];
     flat_row(make_planes(r), r, d);
     row_stage<9>(s_flat, L.lane, d);
-    __syncthreads();
+    wave_lds_fence();
     tile_out<9>(flat + L.tile * (kTile * 9), s_flat, L.lane, L.rows);
 }
 
@@ -172,9 +172,9 @@ __global__ __launch_bounds__(64) void k_covered(const int8_t *__restrict__ state
     load_state(state, s_state, L, r);
     uint32_t d[7];
     covered_row(make_planes(r), d);
-    __syncthreads();  // every lane has read its row before the image is reused
+    wave_lds_fence();  // every lane has read its row before the image is reused
     row_stage<kCells>(s_state, L.lane, d);
-    __syncthreads();
+    wave_lds_fence();
     tile_out<kCells>(cov + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
 }
 
@@ -188,11 +188,44 @@ __global__ __launch_bounds__(64) void k_observe(const int8_t *__restrict__ state
     uint32_t r[7];
     load_state(state, s_state, L, r);
     int who = agent_sel >= 0 ? agent_sel : (L.valid ? to_move[L.b] : 0);
-    uint32_t d[30];
-    obs_row(make_planes(r), who != 0, d);
-    row_stage<kObs>(s_obs, L.lane, d);
-    __syncthreads();
+    obs_image_zero(s_obs, L.lane);
+    wave_lds_fence();
+    obs_scatter(s_obs, L.lane, make_planes(r), who != 0);
+    wave_lds_fence();
     tile_out<kObs>(obs + L.tile * (kTile * kObs), s_obs, L.lane, L.rows);
+}
+
+// Rows of a tile -> HBM through ONE LDS image that is reused: first the 117-byte observation rows,
+// then (image free again -- the LDS reads of tile_out are issued before the next writes) the mask
+// rows and the state rows side by side.  7.5 KB of LDS per wave instead of 12.7 KB: more resident
+// waves per CU to cover the store latency.
+constexpr int kOutImageWords = image_words<kObs>() > image_words<kActions>() + image_words<kCells>()
+                                   ? image_words<kObs>()
+                                   : image_words<kActions>() + image_words<kCells>();
+
+template <bool WITH_MASK, bool WITH_OBS>
+__device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, const uint32_t (&r)[7], uint64_t mask,
+                                           const Planes &p, int observer, int8_t *__restrict__ state,
+                                           int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out)
+{
+    if (WITH_OBS) {
+        obs_image_zero(img, L.lane);
+        wave_lds_fence();
+        obs_scatter(img, L.lane, p, observer);
+        wave_lds_fence();
+        tile_out<kObs>(obs_out + L.tile * (kTile * kObs), img, L.lane, L.rows, true);
+        wave_lds_fence();
+    }
+    uint32_t *img_mask = img, *img_state = img + image_words<kActions>();
+    row_stage<kCells>(img_state, L.lane, r);
+    if (WITH_MASK) {
+        uint32_t d[14];
+        mask_row(mask, d);
+        row_stage<kActions>(img_mask, L.lane, d);
+    }
+    wave_lds_fence();
+    tile_out<kCells>(state + L.tile * (kTile * kCells), img_state, L.lane, L.rows);
+    if (WITH_MASK) tile_out<kActions>(mask_out + L.tile * (kTile * kActions), img_mask, L.lane, L.rows, true);
 }
 
 // gbl_step: fused raw_env.step + observe(next mover) over a tile of boards.
@@ -203,13 +236,11 @@ __global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t 
                                              int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out, int64_t n,
                                              int64_t ntiles, int illegal_mode, int auto_reset)
 {
-    __shared__ uint32_t s_state[image_words<kCells>()];
-    __shared__ uint32_t s_mask[WITH_MASK ? image_words<kActions>() : 4];
-    __shared__ uint32_t s_obs[WITH_OBS ? image_words<kObs>() : 4];
+    __shared__ uint32_t s_img[kOutImageWords];
     Lane L;
     if (!lane_setup(L, n, ntiles)) return;
     uint32_t r[7];
-    load_state(state, s_state, L, r);
+    load_state(state, s_img, L, r);
     int mover = 0, was_done = 0, action = 0;
     if (L.valid) {
         mover = to_move[L.b] != 0;
@@ -220,21 +251,9 @@ __global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t 
     Ply y;
     int dn;
     step_lane(r, p, mover, was_done, action, illegal_mode, auto_reset, dn, y);
-    row_stage<kCells>(s_state, L.lane, r);
-    if (WITH_MASK) {
-        uint32_t d[14];
-        mask_row(next_mask(p, mover, dn, auto_reset), d);
-        row_stage<kActions>(s_mask, L.lane, d);
-    }
-    if (WITH_OBS) {
-        uint32_t d[30];
-        obs_row(p, mover, d);
-        row_stage<kObs>(s_obs, L.lane, d);
-    }
-    __syncthreads();
-    tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
-    if (WITH_MASK) tile_out<kActions>(mask_out + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
-    if (WITH_OBS) tile_out<kObs>(obs_out + L.tile * (kTile * kObs), s_obs, L.lane, L.rows);
+    wave_lds_fence();  // every lane holds its row: the image may be reused
+    store_rows<WITH_MASK, WITH_OBS>(s_img, L, r, WITH_MASK ? next_mask(p, mover, dn, auto_reset) : 0ull, p, mover,
+                                    state, mask_out, obs_out);
     if (L.valid) {
         to_move[L.b] = (int8_t)mover;
         done[L.b] = (int8_t)dn;
@@ -244,8 +263,10 @@ __global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t 
     }
 }
 
-// gbl_rollout: `plies` masked-random plies per launch, state in registers between plies.
-template <bool EVERY_PLY>
+// gbl_rollout: `plies` masked-random plies (sample + step + auto-reset) per launch; the board lives
+// in registers between plies and the outputs of the LAST ply are stored.  plies = 1 is the fused
+// "sample + step" ply of the benchmark pipeline.
+template <bool WITH_MASK, bool WITH_OBS>
 __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8_t *__restrict__ to_move,
                                                 int8_t *__restrict__ done, int32_t *__restrict__ actions_out,
                                                 int8_t *__restrict__ winner_out, int8_t *__restrict__ reward_out,
@@ -253,57 +274,45 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
                                                 int64_t ntiles, uint64_t seed, uint64_t env_base, uint32_t ply0,
                                                 uint32_t plies, int illegal_mode, int64_t *__restrict__ counters)
 {
-    __shared__ uint32_t s_state[image_words<kCells>()];
-    __shared__ uint32_t s_mask[image_words<kActions>()];
-    __shared__ uint32_t s_obs[image_words<kObs>()];
+    __shared__ uint32_t s_img[kOutImageWords];
     Lane L;
     if (!lane_setup(L, n, ntiles)) return;
     uint32_t r[7];
-    load_state(state, s_state, L, r);
+    load_state(state, s_img, L, r);
     int mover = L.valid ? (to_move[L.b] != 0) : 0;
     Planes p = make_planes(r);
     uint32_t games = 0, w1 = 0, w2 = 0;  // wave-uniform tallies (ballot + popcount)
     Ply y{0, 0, 0, false};
     int dn = 0, action = -1;
     for (uint32_t t = 0; t < plies; ++t) {
-        uint64_t legal = legal54(p, mover);
-        action = sample54(legal, seed, env_base + (uint64_t)L.b, ply0 + t);
+        action = sample54(legal54(p, mover), seed, env_base + (uint64_t)L.b, ply0 + t);
         step_lane(r, p, mover, 0, action, illegal_mode, 1, dn, y);
-        games += __popcll(__ballot(L.valid && y.terminal));
-        w1 += __popcll(__ballot(L.valid && y.winner == 1));
-        w2 += __popcll(__ballot(L.valid && y.winner == -1));
-        if (EVERY_PLY || t + 1 == plies) {
-            __syncthreads();  // the previous ply's tile_out reads are issued before the images are rewritten
-            row_stage<kCells>(s_state, L.lane, r);
-            if (mask_out) {
-                uint32_t d[14];
-                mask_row(legal54(p, mover), d);
-                row_stage<kActions>(s_mask, L.lane, d);
-            }
-            if (obs_out) {
-                uint32_t d[30];
-                obs_row(p, mover, d);
-                row_stage<kObs>(s_obs, L.lane, d);
-            }
-            __syncthreads();
-            tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
-            if (mask_out) tile_out<kActions>(mask_out + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
-            if (obs_out) tile_out<kObs>(obs_out + L.tile * (kTile * kObs), s_obs, L.lane, L.rows);
-            if (L.valid) {
-                to_move[L.b] = (int8_t)mover;
-                done[L.b] = (int8_t)dn;
-                if (actions_out) actions_out[L.b] = action;
-                if (winner_out) winner_out[L.b] = (int8_t)y.winner;
-                if (reward_out)
-                    reinterpret_cast<uint16_t *>(reward_out)[L.b] = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
-            }
+        if (counters) {
+            games += __popcll(__ballot(L.valid && y.terminal));
+            w1 += __popcll(__ballot(L.valid && y.winner == 1));
+            w2 += __popcll(__ballot(L.valid && y.winner == -1));
         }
     }
+    wave_lds_fence();
+    store_rows<WITH_MASK, WITH_OBS>(s_img, L, r, WITH_MASK ? legal54(p, mover) : 0ull, p, mover, state, mask_out,
+                                    obs_out);
+    if (L.valid) {
+        to_move[L.b] = (int8_t)mover;
+        done[L.b] = (int8_t)dn;
+        if (actions_out) actions_out[L.b] = action;
+        if (winner_out) winner_out[L.b] = (int8_t)y.winner;
+        if (reward_out)
+            reinterpret_cast<uint16_t *>(reward_out)[L.b] = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
+    }
+    // Tallies: one stripe (its own 128-byte line) per tile mod GBL_COUNTER_STRIPES, so that the
+    // device-scope atomics of concurrently finishing waves go to different lines.
     if (counters && L.lane == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(counters + 0), (unsigned long long)L.rows * plies);
-        atomicAdd(reinterpret_cast<unsigned long long *>(counters + 1), (unsigned long long)games);
-        atomicAdd(reinterpret_cast<unsigned long long *>(counters + 2), (unsigned long long)w1);
-        atomicAdd(reinterpret_cast<unsigned long long *>(counters + 3), (unsigned long long)w2);
+        unsigned long long *c = reinterpret_cast<unsigned long long *>(counters) +
+                                (size_t)(L.tile % GBL_COUNTER_STRIPES) * GBL_COUNTER_STRIDE;
+        atomicAdd(c + 0, (unsigned long long)L.rows * plies);
+        if (games) atomicAdd(c + 1, (unsigned long long)games);
+        if (w1) atomicAdd(c + 2, (unsigned long long)w1);
+        if (w2) atomicAdd(c + 3, (unsigned long long)w2);
     }
 }
 
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(64) void k_sample(const int8_t *__restrict__ mask, 
     Lane L;
     if (!lane_setup(L, n, ntiles)) return;
     tile_in<kActions>(mask + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
-    __syncthreads();
+    wave_lds_fence();
     uint32_t d[14];
     row_load<kActions>(s_mask, L.lane, d);
     if (!L.valid) return;
@@ -332,13 +341,13 @@ __global__ __launch_bounds__(64) void k_decode_obs(const int8_t *__restrict__ ob
     Lane L;
     if (!lane_setup(L, n, ntiles)) return;
     tile_in<kObs>(obs + L.tile * (kTile * kObs), s_obs, L.lane, L.rows);
-    __syncthreads();
+    wave_lds_fence();
     uint32_t d[30];
     row_load<kObs>(s_obs, L.lane, d);
     uint32_t r[7];
     int agent = decode_obs_row(d, r);
     row_stage<kCells>(s_state, L.lane, r);
-    __syncthreads();
+    wave_lds_fence();
     tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
     if (L.valid) to_move[L.b] = (int8_t)agent;
 }
@@ -361,11 +370,11 @@ __global__ __launch_bounds__(64) void k_greedy(const int8_t *__restrict__ state,
     uint64_t mask;
     if (mask_in) {
         tile_in<kActions>(mask_in + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
-        __syncthreads();
+        wave_lds_fence();
         uint32_t d[14];
         row_load<kActions>(s_mask, L.lane, d);
         mask = mask_bits(d);
-        __syncthreads();
+        wave_lds_fence();
     } else {
         mask = legal54(p, me);
     }
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(64) void k_greedy(const int8_t *__restrict__ state,
         uint32_t d[14];
         mask_row(g.cands, d);
         row_stage<kActions>(s_mask, L.lane, d);
-        __syncthreads();
+        wave_lds_fence();
         tile_out<kActions>(cand_out + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
     }
     if (L.valid) {
@@ -553,7 +562,7 @@ int gbl_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, u
 
 int gbl_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_out, int8_t *winner_out,
                 int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, uint64_t seed, uint64_t env_base,
-                uint32_t ply0, uint32_t plies, int illegal_mode, int every_ply, int64_t *counters, void *stream)
+                uint32_t ply0, uint32_t plies, int illegal_mode, int64_t *counters, void *stream)
 {
     GBL_CHECK_N(n);
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done");
@@ -563,18 +572,18 @@ int gbl_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_o
     GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask_out, "mask_out"); GBL_ALIGNED(obs_out, "obs_out");
     if (reward_out && (reinterpret_cast<uintptr_t>(reward_out) & 1u))
         return fail(GBL_ERR_ALIGN, "reward_out must be 2-byte aligned");
-    if (counters && (reinterpret_cast<uintptr_t>(counters) & 7u))
-        return fail(GBL_ERR_ALIGN, "counters must be 8-byte aligned");
+    if (counters && (reinterpret_cast<uintptr_t>(counters) & 127u))
+        return fail(GBL_ERR_ALIGN, "counters must be 128-byte aligned");
     Geometry g = geometry(n);
     hipStream_t s = (hipStream_t)stream;
-    if (every_ply)
-        hipLaunchKernelGGL(k_rollout<true>, dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions_out, winner_out,
-                           reward_out, mask_out, obs_out, n, g.ntiles, seed, env_base, ply0, plies, illegal_mode,
-                           counters);
-    else
-        hipLaunchKernelGGL(k_rollout<false>, dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions_out,
-                           winner_out, reward_out, mask_out, obs_out, n, g.ntiles, seed, env_base, ply0, plies,
-                           illegal_mode, counters);
+#define GBL_ROLL(M, O)                                                                                               \
+    hipLaunchKernelGGL((k_rollout<M, O>), dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions_out, winner_out, \
+                       reward_out, mask_out, obs_out, n, g.ntiles, seed, env_base, ply0, plies, illegal_mode, counters)
+    if (mask_out && obs_out) GBL_ROLL(true, true);
+    else if (mask_out) GBL_ROLL(true, false);
+    else if (obs_out) GBL_ROLL(false, true);
+    else GBL_ROLL(false, false);
+#undef GBL_ROLL
     GBL_LAUNCHED("gbl_rollout");
 }
 

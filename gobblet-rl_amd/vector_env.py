@@ -49,13 +49,20 @@ class BatchedGobblet:
         self.action_mask = torch.empty((n, nat.ACTIONS), dtype=torch.int8, device=dev)
         self.observation = torch.empty((n, 3, 3, 13), dtype=torch.int8, device=dev) if with_observation else None
         self.actions = torch.zeros(n, dtype=torch.int32, device=dev)
-        self.counters = torch.zeros(4, dtype=torch.int64, device=dev)  # plies, games, p1 wins, p2 wins (rollout)
+        # rollout tallies, striped (include/gobblet_hip.h); totals via the ``counters`` property
+        self._counters = torch.zeros((nat.COUNTER_STRIPES, nat.COUNTER_STRIDE), dtype=torch.int64, device=dev)
         self.ply = 0  # lockstep ply counter (keys the sampler)
         self.reset()
 
     @property
     def squares(self) -> torch.Tensor:
         return self.board.squares
+
+    @property
+    def counters(self) -> torch.Tensor:
+        """int64 (4,): plies played, games finished, player_1 wins, player_2 wins over all
+        ``rollout(..., count=True)`` calls."""
+        return self._counters.sum(0)[:4]
 
     def _stream(self):
         return nat.current_stream(self.device)
@@ -111,15 +118,18 @@ class BatchedGobblet:
                                        self.env_base, self.ply, self._stream()), "gbl_sample")
         return out
 
-    def rollout(self, plies: int, every_ply: bool = False):
-        """``plies`` masked-random plies with auto-reset in ONE kernel launch (state stays in
-        registers).  every_ply=True stores mask / observation / winner / rewards after every ply,
-        False only after the last.  Accumulates ``counters``."""
+    def rollout(self, plies: int = 1, count: bool = False):
+        """``plies`` masked-random plies with auto-reset in ONE kernel launch (sample + step fused;
+        the boards stay in registers between plies).  The attribute tensors hold the outputs of
+        the last ply.  ``count=True`` also accumulates ``counters`` (device atomics, a few
+        microseconds per launch).  ``rollout(1)`` is one ply of the benchmark pipeline with every
+        output materialised."""
         n = self.num_envs
         nat.check(self._lib.gbl_rollout(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
                                         self.actions.data_ptr(), self.winner.data_ptr(), self.rewards.data_ptr(),
                                         self.action_mask.data_ptr(), nat.ptr(self.observation), n, self.seed,
-                                        self.env_base, self.ply, int(plies), self.illegal_mode, int(bool(every_ply)),
-                                        self.counters.data_ptr(), self._stream()), "gbl_rollout")
+                                        self.env_base, self.ply, int(plies), self.illegal_mode,
+                                        self._counters.data_ptr() if count else None, self._stream()),
+                  "gbl_rollout")
         self.ply += int(plies)
         return self.observe(), self.rewards, self.done, self.winner

@@ -52,6 +52,13 @@ extern "C" {
 #define GBL_ACTIONS 54
 #define GBL_OBS_BYTES 117
 
+/* gbl_rollout tallies: int64[GBL_COUNTER_STRIPES][GBL_COUNTER_STRIDE]; words 0..3 of every
+ * stripe hold {plies played, games finished, player_1 wins, player_2 wins}; a total is the
+ * sum over stripes.  (Striped so that concurrently finishing wavefronts do not serialise on
+ * one address; one stripe per 128-byte line.) */
+#define GBL_COUNTER_STRIPES 64
+#define GBL_COUNTER_STRIDE 16
+
 /* illegal_mode */
 #define GBL_ILLEGAL_NOOP 0      /* raw_env.step: silent no-op, the turn still passes (gobblet.py:244-246, board.py:125-126) */
 #define GBL_ILLEGAL_TERMINATE 1 /* env(): TerminateIllegalWrapper(illegal_reward=-1) (gobblet.py:114, :50-51) */
@@ -115,16 +122,18 @@ int gbl_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, u
 
 /* Fused masked-random rollout: `plies` lockstep plies in ONE
  * launch; per ply and board: legal mask -> gbl_sample rule with ply index
- * ply0 + t -> gbl_step with auto-reset.  State stays in registers between
- * plies.  every_ply != 0: mask / obs / winner / reward / actions / done are
- * stored after EVERY ply (the traffic a consumer of each ply's outputs
- * causes); 0: only after the last ply.  counters: device int64[4], atomically
- * incremented by {plies played, games finished, player_1 wins, player_2 wins}
- * (may be NULL).  actions_out / winner_out / reward_out / mask_out / obs_out
- * may be NULL. */
+ * ply0 + t -> gbl_step with auto-reset.  The board stays in registers between
+ * plies; state / to_move / done and the optional outputs (action, winner,
+ * reward, mask, obs of the agent to move) are stored after the LAST ply.
+ * plies = 1 is "sample + step" fused into one launch: every ply's outputs
+ * are then materialised in HBM for a consumer, as with gbl_sample + gbl_step.
+ * counters: device int64[GBL_COUNTER_STRIPES][GBL_COUNTER_STRIDE], 128-byte
+ * aligned, atomically incremented (see above; may be NULL -- the atomics cost
+ * a few microseconds per launch at 2^20 boards).  actions_out / winner_out /
+ * reward_out / mask_out / obs_out may be NULL. */
 int gbl_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_out, int8_t *winner_out,
                 int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, uint64_t seed, uint64_t env_base,
-                uint32_t ply0, uint32_t plies, int illegal_mode, int every_ply, int64_t *counters, void *stream);
+                uint32_t ply0, uint32_t plies, int illegal_mode, int64_t *counters, void *stream);
 
 /* GreedyGobbletPolicy.compute_action board decode, greedy_policy.py:43-71:
  * obs int8[n][3][3][13] -> state int8[n][27], to_move int8[n] (channel 12). */

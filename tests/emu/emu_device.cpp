@@ -60,6 +60,13 @@ void stage_all(uint32_t *img, uint32_t (*rows)[NW])
     for (int l = 0; l < 64; ++l) row_stage<ROWB>(img, l, rows[l]);
 }
 
+// the kernels' observation path: zero the image, then every lane scatters its bytes
+void obs_all(uint32_t *img, const Planes *pl, const int *observer)
+{
+    for (int l = 0; l < 64; ++l) obs_image_zero(img, l);
+    for (int l = 0; l < 64; ++l) obs_scatter(img, l, pl[l], observer[l]);
+}
+
 template <int ROWB>
 void in_all(const int8_t *g, uint32_t *img, int rows)
 {
@@ -186,14 +193,16 @@ void emu_covered(const int8_t *state, int8_t *cov, int64_t n)
 void emu_observe(const int8_t *state, const int8_t *to_move, int agent_sel, int8_t *obs, int64_t n)
 {
     for_tiles(n, [&](TileCtx t) {
-        uint32_t r[64][7], d[64][30];
+        uint32_t r[64][7];
+        Planes pl[64];
+        int who[64];
         load_rows(state, t, r);
         for (int l = 0; l < 64; ++l) {
-            int who = agent_sel >= 0 ? agent_sel : (l < t.rows ? to_move[t.tile * 64 + l] : 0);
-            obs_row(make_planes(r[l]), who != 0, d[l]);
+            who[l] = (agent_sel >= 0 ? agent_sel : (l < t.rows ? to_move[t.tile * 64 + l] : 0)) != 0;
+            pl[l] = make_planes(r[l]);
         }
         Image<kObs> img;
-        stage_all<kObs, 30>(img.p(), d);
+        obs_all(img.p(), pl, who);
         out_all<kObs>(obs + t.tile * (kTile * kObs), img.p(), t.rows);
     });
 }
@@ -202,7 +211,9 @@ void emu_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actio
               int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, int illegal_mode, int auto_reset)
 {
     for_tiles(n, [&](TileCtx t) {
-        uint32_t r[64][7], dm[64][14], dobs[64][30];
+        uint32_t r[64][7], dm[64][14];
+        Planes pl[64];
+        int who[64];
         load_rows(state, t, r);
         for (int l = 0; l < 64; ++l) {
             bool valid = l < t.rows;
@@ -218,7 +229,7 @@ void emu_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actio
             int dn;
             step_lane(r[l], p, mover, was_done, action, illegal_mode, auto_reset, dn, y);
             mask_row(next_mask(p, mover, dn, auto_reset), dm[l]);
-            obs_row(p, mover, dobs[l]);
+            pl[l] = p; who[l] = mover;
             if (valid) {
                 to_move[b] = (int8_t)mover;
                 done[b] = (int8_t)dn;
@@ -236,7 +247,7 @@ void emu_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actio
         }
         if (obs_out) {
             Image<kObs> io;
-            stage_all<kObs, 30>(io.p(), dobs);
+            obs_all(io.p(), pl, who);
             out_all<kObs>(obs_out + t.tile * (kTile * kObs), io.p(), t.rows);
         }
     });
@@ -247,7 +258,9 @@ void emu_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_
                  uint32_t ply0, uint32_t plies, int illegal_mode, int64_t *counters)
 {
     for_tiles(n, [&](TileCtx t) {
-        uint32_t r[64][7], dm[64][14], dobs[64][30];
+        uint32_t r[64][7], dm[64][14];
+        Planes pl[64];
+        int who[64];
         load_rows(state, t, r);
         for (int l = 0; l < 64; ++l) {
             bool valid = l < t.rows;
@@ -268,7 +281,7 @@ void emu_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_
                 }
             }
             mask_row(legal54(p, mover), dm[l]);
-            obs_row(p, mover, dobs[l]);
+            pl[l] = p; who[l] = mover;
             if (valid) {
                 to_move[b] = (int8_t)mover;
                 done[b] = (int8_t)dn;
@@ -287,7 +300,7 @@ void emu_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_
         }
         if (obs_out) {
             Image<kObs> io;
-            stage_all<kObs, 30>(io.p(), dobs);
+            obs_all(io.p(), pl, who);
             out_all<kObs>(obs_out + t.tile * (kTile * kObs), io.p(), t.rows);
         }
     });

@@ -182,10 +182,10 @@ def test_sampler_and_rollout_vs_oracle(G):
         oracle.batch_step(s, tm, dn, exp_a, auto_reset=True)
         assert np.array_equal(npy(env.squares), s)
     # fused rollout continues the same stream (ply index carries on)
-    for every in (False, True):
+    for plies in (1, plies):
         o = oracle.batch_rollout(s, tm, dn, seed, base, env.ply, plies, threads=8)
         before = npy(env.counters).copy()
-        obs, rew, done, win = env.rollout(plies, every_ply=every)
+        obs, rew, done, win = env.rollout(plies, count=True)
         assert np.array_equal(npy(env.squares), s) and np.array_equal(npy(env.to_move), tm)
         assert np.array_equal(npy(done), dn) and np.array_equal(npy(win), o["winner"])
         assert np.array_equal(npy(rew), o["reward"]) and np.array_equal(npy(env.actions), o["actions"])
@@ -240,7 +240,7 @@ def test_greedy_vs_oracle_selfplay(G):
 def test_full_size_step_and_rollout_properties(G):
     n = 1 << 20
     env = G.BatchedGobblet(n, DEV, auto_reset=True, seed=0)
-    env.rollout(64)                       # warm-up plies of the benchmark workload
+    env.rollout(64, count=True)           # warm-up plies of the benchmark workload
     state, tm = npy(env.squares), npy(env.to_move)
     # invariants of reachable states: every piece at most once, on its own level
     for k in range(3):
