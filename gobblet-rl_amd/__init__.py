@@ -13,5 +13,6 @@ from . import gobblet_v1  # noqa: F401
 from ._native import GobbletHipError, build  # noqa: F401
 from .board import BatchedBoard  # noqa: F401
 from .vector_env import BatchedGobblet  # noqa: F401
+from .sharding import make_shard, reduce_counters, shard_bounds  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,55 @@
+"""world_size-2 `gloo` test of the N>1 path on CPU: contiguous shards, sampler keyed by the global
+board id (results independent of the number of shards), no collective on the step path, tallies
+summed afterwards.  The per-shard compute is the device code compiled for the host (tests/emu),
+standing in for the GPU each rank would own."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import gobblet_rl_amd as G
+import oracle
+from tests import emu
+
+TOTAL, PLIES, SEED = 1000 + 37, 30, 11
+
+
+def _worker(rank, world, initfile, outdir):
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    start, count = G.shard_bounds(TOTAL, world, rank)
+    s, tm, dn = oracle.batch_reset(count)
+    out = emu.rollout(s, tm, dn, SEED, start, 0, PLIES)          # env_base = first global board of the shard
+    tallies = G.reduce_counters(torch.from_numpy(out["counters"]))  # the only communication, after the run
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), start=start, count=count, state=s, to_move=tm,
+             mask=out["mask"], tallies=tallies.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds():
+    for total, world in [(1 << 20, 8), (1037, 2), (5, 8), (64, 1)]:
+        spans = [G.shard_bounds(total, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+        assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    with pytest.raises(ValueError):
+        G.shard_bounds(10, 2, 2)
+
+
+def test_two_rank_gloo_equals_single_shard():
+    with tempfile.TemporaryDirectory() as d:
+        initfile = os.path.join(d, "init")
+        mp.spawn(_worker, args=(2, initfile, d), nprocs=2, join=True)
+        parts = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(2)]
+    s, tm, dn = oracle.batch_reset(TOTAL)
+    ref = oracle.batch_rollout(s, tm, dn, SEED, 0, 0, PLIES, threads=4)
+    assert int(parts[0]["start"]) == 0 and int(parts[1]["start"]) == int(parts[0]["count"])
+    assert np.array_equal(np.concatenate([p["state"] for p in parts]), s)
+    assert np.array_equal(np.concatenate([p["to_move"] for p in parts]), tm)
+    assert np.array_equal(np.concatenate([p["mask"] for p in parts]), ref["mask"])
+    for p in parts:  # both ranks hold the global tallies
+        assert np.array_equal(p["tallies"], ref["counters"])
