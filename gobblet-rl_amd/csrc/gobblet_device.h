@@ -540,65 +540,128 @@ struct GreedyResult {
     bool fallback;   // the reference would call np.random.choice(actions_depth1)
 };
 
+// Outcome of EVERY move of `mover` on board p at once: bit a of `win` / `lose` is set iff
+// check_for_winner() after play_turn(mover, a) is the mover's / the other side's value
+// (board.py:118-132 then :183-194).  Only meaningful for legal a -- the caller masks with legal54.
+//
+// Bit-parallel over the 9 destinations of one piece: lifting the piece from its square s exposes
+// what lies beneath (tops after the lift: Tm, To); dropping it on q sets the mover's top at q and
+// clears the other side's.  Line l is then complete for the mover iff q supplies its only missing
+// square (or nothing is missing), and stays complete for the other side iff it was complete and q is
+// not on it.  The reference lets the LAST matching line decide, so lines are resolved from index 7
+// down, each destination taking the first verdict it meets.
+__device__ __forceinline__ void outcomes54(const Planes &p, int mover, uint64_t &win, uint64_t &lose)
+{
+    uint32_t mine = mover ? (p.nz & p.neg) : (p.nz & ~p.neg);
+    uint32_t othr = mover ? (p.nz & ~p.neg) : (p.nz & p.neg);
+    uint32_t m0 = mine & 0x1FFu, m1 = (mine >> 9) & 0x1FFu, m2 = (mine >> 18) & 0x1FFu;
+    uint32_t t0 = othr & 0x1FFu, t1 = (othr >> 9) & 0x1FFu, t2 = (othr >> 18) & 0x1FFu;
+    uint32_t o1 = m1 | t1, o2 = m2 | t2;
+    uint32_t Tm = m2 | (~o2 & (m1 | (~o1 & m0)));  // squares whose top piece is the mover's
+    uint32_t To = t2 | (~o2 & (t1 | (~o1 & t0)));  // ... the other side's
+    // owner of the highest piece strictly below level k (what a lift from level k exposes)
+    uint32_t um[3] = {0u, m0, m1 | (~o1 & m0)};
+    uint32_t uo[3] = {0u, t0, t1 | (~o1 & t0)};
+    constexpr uint32_t L[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x111u, 0x054u};  // board.py:135-153
+    win = 0;
+    lose = 0;
+#pragma unroll
+    for (int pi = 0; pi < 6; ++pi) {
+        int k = pi >> 1;
+        uint32_t src = ((mine & ((pi & 1) ? ~p.odd : p.odd)) >> (9 * k)) & 0x1FFu;  // where the piece stands (0: in hand)
+        uint32_t Tm_l = (Tm & ~src) | (src & um[k]);
+        uint32_t To_l = To | (src & uo[k]);
+        uint32_t w9 = 0, l9 = 0, open = 0x1FFu;
+#pragma unroll
+        for (int l = 7; l >= 0; --l) {
+            uint32_t miss = L[l] & ~Tm_l;
+            uint32_t need = (miss & (miss - 1u)) ? 0u : (miss ? miss : 0x1FFu);
+            uint32_t keep = (L[l] & ~To_l) ? 0u : (~L[l] & 0x1FFu);
+            uint32_t w = need & open;
+            w9 |= w;
+            open &= ~w;
+            uint32_t x = keep & open;
+            l9 |= x;
+            open &= ~x;
+        }
+        win |= (uint64_t)w9 << (9 * pi);
+        lose |= (uint64_t)l9 << (9 * pi);
+    }
+}
+
+__device__ __forceinline__ uint64_t below_eq(int b) { return (2ull << b) - 1ull; }  // bits 0..b, b < 63
+
 // One decision for the agent `me` on board p.  `mask` is the legal mask handed to the policy
 // (greedy_policy.py:76), prev3 the agent's last three actions packed one per byte (0xFF = none).
-// Sequential restatement of the reference's control flow over bit planes: the depth-1 loop
-// (:84-101), the depth-2 loop with its order-dependent pruning (:103-157) and the fallback test
-// (:211-214).
+// The reference's control flow -- the depth-1 loop (:84-101), the depth-2 loop with its
+// order-dependent pruning (:103-157), the fallback test (:211-214) -- is replayed in order over
+// outcome bit-sets, so that no per-leaf loop remains: per depth-1 candidate one moved(),
+// one legal54() and one outcomes54() give every opponent reply's result.
 __device__ __forceinline__ GreedyResult greedy_decide(const Planes &p, int me, uint64_t mask, int depth, uint32_t prev3)
 {
     const int opp = 1 - me;
-    const int w_me = me ? -1 : 1, w_opp = -w_me;  // winner_values, :74
-    uint64_t cands = mask;                        // actions_depth1, :77-79
+    uint64_t cands = mask;  // actions_depth1, :77-79
     int ncands = __popcll(mask);
     int chosen = -1;
-    uint64_t legal_me = legal54(p, me);           // board.is_legal(agent_index, a), :85 and :141
-    uint64_t res_zero = 0;                        // keys of `results` whose value is 0, insertion = ascending order
-    // depth 1, :84-101
-    for (uint64_t it = mask & legal_me; it;) {
-        int a = __builtin_ctzll(it);
-        it &= it - 1;
-        int r = winner_of(moved(p, me, (uint32_t)a));
-        if (r == 0) res_zero |= 1ull << a;
-        if (r == w_me) {
+    uint64_t legal_me = legal54(p, me);  // board.is_legal(agent_index, a), :85 and :141
+    uint64_t tried = mask & legal_me;    // actions the depth-1 loop evaluates, ascending
+    uint64_t win1, lose1;
+    outcomes54(p, me, win1, lose1);
+    win1 &= tried;
+    lose1 &= tried;
+    // depth 1, :84-101: walk the decisive results in order; everything before the stop is in `results`
+    uint64_t seen = tried;
+    for (uint64_t ev = win1 | lose1; ev;) {
+        int a = __builtin_ctzll(ev);
+        ev &= ev - 1;
+        if ((win1 >> a) & 1ull) {  // :92-94
             chosen = a;
+            seen = tried & below_eq(a);
             break;
-        } else if (r == w_opp) {
-            if (ncands > 1) {
-                cands &= ~(1ull << a);
-                --ncands;
-            } else
-                break;
+        }
+        if (ncands > 1) {          // :95-99
+            cands &= ~(1ull << a);
+            --ncands;
+        } else {                   // :100-101
+            seen = tried & below_eq(a);
+            break;
         }
     }
     if (depth > 1) {  // :103-157
-        for (uint64_t it = res_zero; it;) {
+        for (uint64_t it = seen & ~win1 & ~lose1; it;) {  // results with value 0, insertion order
             int a = __builtin_ctzll(it);
             it &= it - 1;
-            Planes d1 = moved(p, me, (uint32_t)a);
-            bool all_me = true, none_opp = true;
-            for (uint64_t it2 = legal54(d1, opp); it2;) {  // :112-116
-                int a2 = __builtin_ctzll(it2);
-                it2 &= it2 - 1;
-                int r2 = winner_of(moved(d1, opp, (uint32_t)a2));  // :120-126
-                all_me = all_me && (r2 == w_me);
-                none_opp = none_opp && (r2 != w_opp);
-                if (r2 == w_opp) {  // :129-143
-                    if (ncands > 1) {
-                        if ((cands >> a) & 1ull) {
-                            cands &= ~(1ull << a);
-                            --ncands;
-                        }
-                    } else
-                        break;
-                    if (((legal_me >> a2) & 1ull) && chosen < 0) chosen = a2;
+            Planes d1 = moved(p, me, (uint32_t)a);  // :107-109
+            uint64_t legal2 = legal54(d1, opp);     // :112-116
+            uint64_t ow, mw;                        // opponent wins / we win after reply a2, :120-126
+            outcomes54(d1, opp, ow, mw);
+            ow &= legal2;
+            mw &= legal2;
+            uint64_t evald = legal2;                // replies that got a result before any break
+            if (ow) {                               // :129-143
+                int f = __builtin_ctzll(ow);
+                uint64_t rest = ow & (ow - 1);
+                if (ncands > 1) {
+                    if ((cands >> a) & 1ull) {
+                        cands &= ~(1ull << a);
+                        --ncands;
+                    }
+                    if (ncands > 1 || !rest) {      // no break: every opponent win is looked at
+                        uint64_t block = ow & legal_me;
+                        if (chosen < 0 && block) chosen = __builtin_ctzll(block);
+                    } else {                        // break at the second opponent win
+                        if (chosen < 0 && ((legal_me >> f) & 1ull)) chosen = f;
+                        evald = legal2 & below_eq(__builtin_ctzll(rest));
+                    }
+                } else {                            // break at the first opponent win
+                    evald = legal2 & below_eq(f);
                 }
             }
-            if (all_me) {  // :146-151
+            if ((evald & ~mw) == 0) {  // all(... == our win), :146-151
                 chosen = a;
                 break;
             }
-            if (none_opp) chosen = a;  // :153-157
+            if ((evald & ow) == 0) chosen = a;  // all(... != their win), :153-157
         }
     }
     bool fb = chosen < 0;  // :211-214

@@ -142,12 +142,25 @@ def test_greedy_vs_golden_and_oracle(golden_dir, depth):
     assert np.array_equal(o[0], act3) and np.array_equal(o[1], cm3) and np.array_equal(o[2], fb3)
 
 
-def test_greedy_vs_oracle_selfplay():
-    state, tm, dn, rng = selfplay_states(600, 26, seed=8)
+def test_greedy_vs_oracle_selfplay(boards):
+    state, tm, dn, rng = selfplay_states(6000, 26, seed=8)
     live = oracle.batch_winner(state) == 0
-    state, tm = np.ascontiguousarray(state[live]), np.ascontiguousarray(tm[live])
+    state, tm = state[live], tm[live]
+    # plus the dense random valid boards of the golden set (non-terminal ones), both movers
+    dense = boards["squares"][boards["winner"] == 0]
+    state = np.ascontiguousarray(np.concatenate([state, dense, dense]))
+    tm = np.ascontiguousarray(np.concatenate([tm, np.zeros(len(dense), np.int8), np.ones(len(dense), np.int8)]))
+    hist = rng.integers(-1, 54, (len(state), 2, 3)).astype(np.int8)
     for depth in (1, 2):
-        e = emu.greedy(state, tm, depth=depth)
-        o = oracle.batch_greedy(state, tm, depth=depth)
-        for x, y in zip(e, o):
-            assert np.array_equal(x, y)
+        for h in (None, hist):
+            e = emu.greedy(state, tm, hist=h, depth=depth)
+            o = oracle.batch_greedy(state, tm, hist=h, depth=depth)
+            for x, y in zip(e, o):
+                assert np.array_equal(x, y)
+    # a mask that is a strict subset of the legal moves (the policy only searches the moves it is handed)
+    m = oracle.batch_legal_mask(state, tm) * (rng.random((len(state), 54)) < 0.7)
+    m = np.ascontiguousarray(m.astype(np.int8))
+    e = emu.greedy(state, tm, mask=m, depth=2)
+    o = oracle.batch_greedy(state, tm, mask=m, depth=2)
+    for x, y in zip(e, o):
+        assert np.array_equal(x, y)
