@@ -14,6 +14,7 @@ import torch
 
 from . import _native as nat
 from .board import BatchedBoard
+from .greedy_policy import GreedyGobbletPolicy  # noqa: F401  (gobblet_v1.py:2 re-exports it)
 
 try:  # pragma: no cover - not installed in the build image
     from pettingzoo import AECEnv as _AECBase

@@ -1,0 +1,96 @@
+"""``GreedyGobbletPolicy`` -- the reference's depth-1/2 lookahead policy (gobblet_rl/game/greedy_policy.py)
+for N boards at once on the GPU.
+
+Same constructor and method names as the reference class.  ``compute_action(obs, mask)`` takes one
+observation like the reference (and returns a numpy scalar); ``compute_actions(obs, mask)`` takes
+batches (torch tensors on the device, or numpy) and returns an int32 tensor (N,).  The board is
+rebuilt from the observation exactly as greedy_policy.py:43-71 does (``gbl_decode_obs``); the search
+is ``gbl_greedy``.  Per-agent history of own actions (``prev_actions``, greedy_policy.py:19,211-219) is
+kept per board on the device.  Where the reference falls back to ``np.random.choice(actions_depth1)``
+(:211-217, numpy's global RNG) this class draws uniformly from the same candidate set with the
+library's counter-based sampler (``gbl_sample``), keyed by (seed, board, call index).
+Depth 3 (:160-208) is not implemented.
+"""
+from __future__ import annotations
+
+from typing import Any, Optional
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+
+class GreedyGobbletPolicy:
+    def __init__(self, depth: Optional[int] = 2, seed: Optional[int] = 0, device="cuda:0", **kwargs: Any) -> None:
+        if depth not in (1, 2):
+            raise ValueError("depth must be 1 or 2 (the reference's depth-3 branch is out of scope)")
+        self.depth = depth
+        self.seed = int(seed or 0)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise nat.GobbletHipError("GreedyGobbletPolicy needs a GPU device (there is no CPU fallback)")
+        self._lib = nat.lib()
+        self.prev_actions = None  # int8 (N, 2, 3) on device: last three own actions per agent, -1 = none
+        self._calls = 0
+        # outputs of the last call (device tensors): chosen-or--1, candidate set, fallback flag
+        self.last_chosen = self.last_candidates = self.last_fallback = None
+
+    def _stream(self):
+        return nat.current_stream(self.device)
+
+    def _ensure(self, n):
+        if self.prev_actions is None or self.prev_actions.shape[0] != n:
+            self.prev_actions = torch.full((n, 2, 3), -1, dtype=torch.int8, device=self.device)
+
+    def reset_history(self):
+        self.prev_actions = None
+
+    def compute_actions(self, obs, mask=None) -> torch.Tensor:
+        """obs: int8 (N,3,3,13); mask: int8 (N,54) or None (derive the legal mask from the board)."""
+        obs = torch.as_tensor(obs).to(device=self.device, dtype=torch.int8).reshape(-1, 3, 3, 13).contiguous()
+        n = obs.shape[0]
+        if mask is not None:
+            mask = torch.as_tensor(mask).to(device=self.device, dtype=torch.int8).reshape(n, nat.ACTIONS).contiguous()
+        state = torch.empty((n, nat.CELLS), dtype=torch.int8, device=self.device)
+        who = torch.empty(n, dtype=torch.int8, device=self.device)
+        nat.check(self._lib.gbl_decode_obs(obs.data_ptr(), state.data_ptr(), who.data_ptr(), n, self._stream()),
+                  "gbl_decode_obs")  # greedy_policy.py:43-71
+        return self.compute_actions_from_state(state, who, mask)
+
+    def compute_actions_from_state(self, state: torch.Tensor, to_move: torch.Tensor, mask=None) -> torch.Tensor:
+        """The same decision from ``squares`` (N,27) + ``to_move`` (N,) directly (no observation round trip)."""
+        n = state.shape[0]
+        self._ensure(n)
+        act = torch.empty(n, dtype=torch.int32, device=self.device)
+        cand = torch.empty((n, nat.ACTIONS), dtype=torch.int8, device=self.device)
+        fb = torch.empty(n, dtype=torch.int8, device=self.device)
+        nat.check(self._lib.gbl_greedy(state.data_ptr(), to_move.data_ptr(), nat.ptr(mask),
+                                       self.prev_actions.data_ptr(), self.depth, act.data_ptr(), cand.data_ptr(),
+                                       fb.data_ptr(), n, self._stream()), "gbl_greedy")
+        # :211-217 fallback: uniform over actions_depth1
+        drawn = torch.empty(n, dtype=torch.int32, device=self.device)
+        nat.check(self._lib.gbl_sample(cand.data_ptr(), drawn.data_ptr(), n, self.seed, 0, self._calls,
+                                       self._stream()), "gbl_sample")
+        self.last_chosen, self.last_candidates, self.last_fallback = act, cand, fb
+        out = torch.where(fb.bool(), drawn, act)
+        # :219 history append for the acting agent
+        idx = torch.arange(n, device=self.device)
+        h = self.prev_actions[idx, to_move.long()]
+        self.prev_actions[idx, to_move.long()] = torch.cat([h[:, 1:], out.to(torch.int8)[:, None]], dim=1)
+        self._calls += 1
+        return out
+
+    # -- reference-shaped single-observation entry points ------------------------------------------------
+    def compute_action(self, obs, mask) -> np.ndarray:  # greedy_policy.py:38-221
+        return np.array(int(self.compute_actions(np.asarray(obs)[None], np.asarray(mask)[None])[0]))
+
+    def compute_actions_rllib(self, obs_batch):  # greedy_policy.py:21-31
+        observations = np.asarray(obs_batch["observation"])
+        observations = observations.reshape(observations.shape[0], 3, 3, -1)
+        return list(self.compute_actions(observations, np.asarray(obs_batch["action_mask"])).cpu().numpy())
+
+    def compute_action_tianshou(self, obs):  # greedy_policy.py:33-36
+        mask = obs.mask
+        obs = obs.obs if hasattr(obs, "obs") else obs
+        return self.compute_action(obs, mask)

@@ -96,6 +96,16 @@ class BatchedGobblet:
         """{"observation", "action_mask"} of the agent to move on every board (gobblet.py:215)."""
         return {"observation": self.observation, "action_mask": self.action_mask}
 
+    # -- batches shaped like the reference's callers (SURVEY.md 8f2): zero-copy device views ---------------
+    def tianshou_batch(self):
+        """What Tianshou's PettingZooEnv wrapper hands a policy (greedy_policy_tianshou.py:63-84 reads
+        ``obs.obs``, ``obs.mask``, ``agent_id``), for all boards: {"obs", "mask", "agent_id"}."""
+        return {"obs": self.observation, "mask": self.action_mask.bool(), "agent_id": self.to_move}
+
+    def rllib_batch(self):
+        """The ``obs_batch`` of RLlib-style callers (greedy_policy.py:21-31): flat observation + mask."""
+        return {"observation": self.observation.reshape(self.num_envs, -1), "action_mask": self.action_mask}
+
     # -- gobblet.py:231-271 + 179-215 ------------------------------------------------------------------
     def step(self, actions):
         """Apply ``actions`` (int (N,)) for the agents to move.  Returns

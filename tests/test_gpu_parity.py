@@ -306,3 +306,43 @@ def test_aec_facade_on_gpu(G, golden_dir):
             mask = observation["action_mask"]
             env.step(int(rng.choice(np.arange(len(mask)), p=mask / np.sum(mask))))
     assert sorted(totals.values()) == [-1, 1]
+
+
+def test_greedy_policy_class(G, golden_dir):
+    """Host mirror of GreedyGobbletPolicy: decisions from observations, history guard, fallback draw."""
+    g = np.load(os.path.join(golden_dir, "greedy.npz"))
+    pol = G.GreedyGobbletPolicy(depth=2, device=DEV)
+    a = pol.compute_actions(g["obs"], g["mask"])
+    ref = g["chosen_d2"].astype(np.int32)
+    assert np.array_equal(npy(a), ref)               # empty history, a move was always chosen in this set
+    assert np.array_equal(npy(pol.last_candidates), g["cands_d2"]) and not npy(pol.last_fallback).any()
+    # second call on the same positions: the chosen action is now in the agent's last three -> fallback
+    b = pol.compute_actions(g["obs"], g["mask"])
+    assert npy(pol.last_fallback).all()
+    picked = npy(b)
+    assert (g["cands_d2"][np.arange(len(picked)), picked] == 1).all()  # drawn from actions_depth1
+    # single-observation, reference-shaped call
+    one = G.GreedyGobbletPolicy(depth=1, device=DEV).compute_action(g["obs"][320], g["mask"][320])
+    assert int(one) == 8 and one.shape == ()
+    assert G.gobblet_v1.GreedyGobbletPolicy is G.GreedyGobbletPolicy
+
+
+def test_greedy_vs_greedy_games(G):
+    """Two greedy agents play 2048 games in lockstep on the device (tutorials/GreedyAgent usage): runs to
+    termination, and every move played was legal."""
+    n = 2048
+    env = G.BatchedGobblet(n, DEV, auto_reset=False)
+    pol = G.GreedyGobbletPolicy(depth=2, device=DEV)
+    for ply in range(2):  # first two plies random, as the tutorial does
+        env.step(env.sample_actions())
+    finished = 0
+    for ply in range(60):
+        live = npy(env.done) == 0
+        if not live.any():
+            break
+        a = pol.compute_actions_from_state(env.squares, env.to_move)
+        legal = npy(env.action_mask)[np.arange(n), np.clip(npy(a), 0, 53)]
+        assert (legal[live] == 1).all()
+        env.step(a)
+    finished = int((npy(env.done) != 0).sum())
+    assert finished > n * 0.9
