@@ -284,15 +284,18 @@ def test_error_behaviour(G):
 def test_aec_facade_on_gpu(G, golden_dir):
     g = np.load(os.path.join(golden_dir, "random_games.npz"))
     e = G.gobblet_v1.raw_env(device=DEV)
-    for i in np.flatnonzero(g["game"] < 6):
+    for i in range(len(g["action"])):  # all 96 golden games, ply by ply, through the AEC surface
         if g["ply"][i] == 0:
             e.reset()
         e.step(int(g["action"][i]))
         assert np.array_equal(e.board.squares, g["squares_after"][i])
         o = e.observe(e.agent_selection)
         assert np.array_equal(o["action_mask"], g["mask_next"][i])
-        assert np.array_equal(e.observe("player_1")["observation"], g["obs_p1"][i])
+        if g["game"][i] < 24:
+            assert np.array_equal(e.observe("player_1")["observation"], g["obs_p1"][i])
+            assert np.array_equal(e.observe("player_2")["observation"], g["obs_p2"][i])
         assert [e.rewards["player_1"], e.rewards["player_2"]] == g["reward"][i].tolist()
+        assert e.terminations["player_1"] == bool(g["done"][i])
     rng = np.random.default_rng(0)
     env = G.gobblet_v1.env(device=DEV)
     env.reset()
