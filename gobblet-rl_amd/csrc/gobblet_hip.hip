@@ -239,14 +239,16 @@ __global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t 
     __shared__ uint32_t s_img[kOutImageWords];
     Lane L;
     if (!lane_setup(L, n, ntiles)) return;
+    // Per-board scalars first, from a clamped index and with no branch around them (a branch would
+    // pin their s_waitcnt to the load): they are in flight together with the tile's loads -- one HBM
+    // round trip per wave instead of two.
+    const int64_t bs = L.valid ? L.b : n - 1;
+    int mover = to_move[bs], was_done = done[bs], action = actions[bs];
     uint32_t r[7];
     load_state(state, s_img, L, r);
-    int mover = 0, was_done = 0, action = 0;
-    if (L.valid) {
-        mover = to_move[L.b] != 0;
-        was_done = auto_reset ? 0 : (done[L.b] != 0);
-        action = actions[L.b];
-    }
+    mover = L.valid && mover != 0;
+    was_done = L.valid && !auto_reset && was_done != 0;
+    action = L.valid ? action : 0;
     Planes p = make_planes(r);
     Ply y;
     int dn;
@@ -277,9 +279,10 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
     __shared__ uint32_t s_img[kOutImageWords];
     Lane L;
     if (!lane_setup(L, n, ntiles)) return;
+    int mover = to_move[L.valid ? L.b : n - 1];  // issued before the tile loads, branch-free (see k_step)
     uint32_t r[7];
     load_state(state, s_img, L, r);
-    int mover = L.valid ? (to_move[L.b] != 0) : 0;
+    mover = L.valid && mover != 0;
     Planes p = make_planes(r);
     uint32_t games = 0, w1 = 0, w2 = 0;  // wave-uniform tallies (ballot + popcount)
     Ply y{0, 0, 0, false};
