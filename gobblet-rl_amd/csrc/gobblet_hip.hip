@@ -213,7 +213,7 @@ __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, const u
         wave_lds_fence();
         obs_scatter(img, L.lane, p, observer);
         wave_lds_fence();
-        tile_out<kObs>(obs_out + L.tile * (kTile * kObs), img, L.lane, L.rows, true);
+        tile_out<kObs>(obs_out + L.tile * (kTile * kObs), img, L.lane, L.rows, (GBL_NT_STORES & 1) != 0);
         wave_lds_fence();
     }
     uint32_t *img_mask = img, *img_state = img + image_words<kActions>();
@@ -225,7 +225,7 @@ __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, const u
     }
     wave_lds_fence();
     tile_out<kCells>(state + L.tile * (kTile * kCells), img_state, L.lane, L.rows);
-    if (WITH_MASK) tile_out<kActions>(mask_out + L.tile * (kTile * kActions), img_mask, L.lane, L.rows, true);
+    if (WITH_MASK) tile_out<kActions>(mask_out + L.tile * (kTile * kActions), img_mask, L.lane, L.rows, (GBL_NT_STORES & 2) != 0);
 }
 
 // gbl_step: fused raw_env.step + observe(next mover) over a tile of boards.
