@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--boards", type=int, default=1 << 20, help="boards per GPU")
+    ap.add_argument("--boards", type=int, default=1 << 20, help="boards per GPU (weak scaling, the default)")
+    ap.add_argument("--total-boards", type=int, default=0,
+                    help="fixed TOTAL board count split over the GPUs instead (strong scaling, e.g. 1048576)")
     ap.add_argument("--mode", choices=["step", "fused"], default="fused")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the K timed plies as one hipGraph; 0: eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,8 +131,11 @@ def main():
 
     import gobblet_rl_amd as G
 
-    boards = args.boards
-    env = G.BatchedGobblet(boards, dev, illegal_mode="noop", auto_reset=True, seed=0, env_base=rank * boards)
+    if args.total_boards:
+        env_base, boards = G.shard_bounds(args.total_boards, world, rank)
+    else:
+        boards, env_base = args.boards, rank * args.boards
+    env = G.BatchedGobblet(boards, dev, illegal_mode="noop", auto_reset=True, seed=0, env_base=env_base)
     K, W = args.steps, args.warmup
     lib, nat = G._native.lib(), G._native
     P = dict(sq=env.squares.data_ptr(), tm=env.to_move.data_ptr(), dn=env.done.data_ptr(),
@@ -209,7 +214,8 @@ def main():
     achieved = ALGO_BYTES_FULL * units_per_launch / mean_kernel_s / 1e9
 
     if rank == 0:
-        total_steps = boards * K * world
+        all_boards = args.total_boards if args.total_boards else boards * world
+        total_steps = all_boards * K
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):  # HBM bytes per launch from a committed rocprofv3 --pmc run of this command
@@ -228,13 +234,13 @@ def main():
             "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_boards else "weak",
             "vs_baseline": None,
             "dtype": "int8",
             "data": "synthetic",
             "config": {"workload": f"{boards} boards per GPU x {world} GPU(s), masked-random actions, auto-reset, "
                                    f"FULL outputs (state+mask+obs+winner+reward+done) every ply",
-                       "boards_per_gpu": boards, "total_boards": boards * world, "mode": args.mode,
+                       "boards_per_gpu": boards, "total_boards": all_boards, "mode": args.mode,
                        "launches_per_step": 2 if args.mode == "step" else 1,
                        "sharding": f"contiguous board ranges, {world} shard(s), no collective on the step path"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -318,7 +318,7 @@ class raw_env(_AECBase):  # noqa: N801  (reference spelling, gobblet.py:123)
             return
         from .render import render_text
         out = render_text(self, full=self.render_mode == "text_full")
-        print(out)
+        print(out)  # (the reference ends with an empty print(); `out` ends with that newline's line)
         return out
 
     def close(self):

@@ -1,33 +1,56 @@
-"""Text rendering of one board (reference ``render_mode`` "text" / "text_full", gobblet.py:299-429).
-Host-side inspection code, not part of the hot path.  Format restated, not copied: the same
-information (top pieces per square; with ``full`` all three levels), laid out as the reference
-draws it -- positions run down the columns (board.py:14-17)."""
+"""Text rendering of one board: the reference's ``render_mode`` "text" and "text_full"
+(gobblet.py:299-429; sample output README.md:132-159).  Host-side inspection code, not part of the
+hot path.  The layout is restated from the reference's format -- a header line, then 3x3 grids of
+7-character cells whose squares run down the columns (board.py:14-17) -- and checked character for
+character against output captured from the reference (tests/golden/render_text.json)."""
 from __future__ import annotations
 
 import numpy as np
 
-
-def _sym(v: int) -> str:
-    if v == 0:
-        return " . "
-    return f"{int(v):+d} "
+_BLANK = " " * 7 + "|" + " " * 7 + "|" + " " * 7
+_RULE = "_" * 7 + "|" + "_" * 7 + "|" + "_" * 7
 
 
-def render_text(env_or_squares, full: bool = False) -> str:
-    sq = getattr(getattr(env_or_squares, "board", None), "squares", env_or_squares)
-    sq = np.asarray(sq).astype(int).reshape(3, 9)
+def _sym_full(v) -> str:  # gobblet.py:299-305: signed piece number
+    v = int(v)
+    return "- " if v == 0 else (f"+{v}" if v > 0 else f"{v}")
+
+
+def _sym_size(v) -> str:  # gobblet.py:307-313: signed piece size
+    v = int(v)
+    return "- " if v == 0 else (f"+{(v + 1) // 2}" if v > 0 else f"{v // 2}")
+
+
+def _cells(c) -> str:
+    return f"  {c[0]}   " + "|" + f"   {c[1]}  " + "|" + f"   {c[2]}  "
+
+
+def _grid_rows(grids):
+    """grids: list of 9-symbol lists; yields the 9 text lines of the grids side by side."""
+    join = lambda parts: "  ".join(parts)  # noqa: E731
+    for r in range(3):
+        yield join([_BLANK] * len(grids))
+        yield join([_cells([g[r], g[r + 3], g[r + 6]]) for g in grids])
+        yield join([_RULE if r < 2 else _BLANK] * len(grids))
+
+
+def render_text(env, full: bool = False) -> str:
+    """The text the reference prints for `env` (a raw_env-like object with ``board``, ``turn``,
+    ``agent_selection``, ``action``), without the trailing newline of the last print()."""
+    pos = env.action % 9
+    piece = (env.action // 9) + 1
     lines = []
-    if hasattr(env_or_squares, "turn"):
-        lines.append(f"TURN: {env_or_squares.turn}, AGENT: {env_or_squares.agent_selection}, "
-                     f"ACTION: {env_or_squares.action}")
-    levels = [("SMALL", 0), ("MEDIUM", 1), ("LARGE", 2)] if full else []
-    top = np.zeros(9, int)
-    for p in range(9):
-        col = sq[:, p]
-        top[p] = col[2] if col[2] else (col[1] if col[1] else col[0])
-    blocks = [("TOP", top)] + [(name, sq[k]) for name, k in levels]
-    for name, cells in blocks:
-        lines.append(f"[{name}]")
-        for r in range(3):  # displayed row r holds positions r, r+3, r+6
-            lines.append("|".join(_sym(cells[r + 3 * c]) for c in range(3)))
+    if not full:
+        piece = (piece + 1) // 2
+        lines.append(f"TURN: {env.turn}, AGENT: {env.agent_selection}, ACTION: {env.action}, "
+                     f"POSITION: {pos}, PIECE: {piece}")
+        lines.extend(_grid_rows([[_sym_size(v) for v in env.board.get_flatboard()]]))
+    else:
+        lines.append(f"TURN: {env.turn}, AGENT: {env.agent_selection}, ACTION: {env.action}, "
+                     f"POSITION: {pos}, PIECE: {piece}")
+        lines.append(" " * 9 + "SMALL" + " " * 9 + "  " + " " * 10 + "MED" + " " * 10 + "  " + " " * 9 + "LARGE"
+                     + " " * 9 + "  ")
+        sq = np.asarray(env.board.squares)
+        lines.extend(_grid_rows([[_sym_full(v) for v in sq[9 * k:9 * k + 9]] for k in range(3)]))
+    lines.append("")
     return "\n".join(lines)

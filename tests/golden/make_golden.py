@@ -347,7 +347,30 @@ def greedy_vectors(games, n_positions=320, seed=7):
 
 
 # --------------------------------------------------------------------------------------
+def render_text():
+    """stdout of the reference's render() in "text" / "text_full" mode along two golden games."""
+    import contextlib
+    import io
+    g = np.load(os.path.join(OUT, "random_games.npz"))
+    out = []
+    for mode in ("text", "text_full"):
+        env = raw_env(render_mode=mode)
+        for i in np.flatnonzero(g["game"] < 2):
+            if g["ply"][i] == 0:
+                env.reset()
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                env.step(int(g["action"][i]))  # step() calls render() when a mode is set (gobblet.py:272-273)
+            out.append({"mode": mode, "index": int(i), "text": buf.getvalue()})
+    with open(os.path.join(OUT, "render_text.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("render_text.json:", len(out), "frames")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "render":
+        render_text()
+        return
     kat_collector()
     games = random_games()
     rng = np.random.default_rng(99)
@@ -362,6 +385,7 @@ def main():
         i = names.index(k)
         print(f"  {k}: winner {bf['winner'][i]} flat {bf['flatboard'][i].tolist()}")
     greedy_vectors(games)
+    render_text()
 
 
 if __name__ == "__main__":

@@ -150,9 +150,16 @@ def test_env_illegal_move_terminates_with_minus_one():
         G.gobblet_v1.env(board_backend=OracleBoardBackend(1)).reset() or e.step(54)
 
 
-def test_text_render_smoke(capsys):
-    e = G.gobblet_v1.raw_env(render_mode="text_full", board_backend=OracleBoardBackend(1))
-    e.reset()
-    e.step(18)
-    out = capsys.readouterr().out
-    assert "[TOP]" in out and "[LARGE]" in out and "+3" in out
+def test_text_render_matches_reference(capsys, golden_dir):
+    """render_mode "text" / "text_full" (gobblet.py:299-429), character for character."""
+    frames = json.load(open(os.path.join(golden_dir, "render_text.json")))
+    g = np.load(os.path.join(golden_dir, "random_games.npz"))
+    for mode in ("text", "text_full"):
+        e = G.gobblet_v1.raw_env(render_mode=mode, board_backend=OracleBoardBackend(1))
+        for fr in [f for f in frames if f["mode"] == mode]:
+            i = fr["index"]
+            if g["ply"][i] == 0:
+                e.reset()
+            capsys.readouterr()
+            e.step(int(g["action"][i]))
+            assert capsys.readouterr().out == fr["text"], (mode, i)
