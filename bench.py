@@ -35,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ALGO_BYTES_FULL = 234      # reads 33 + writes 201 per env-step
+ALGO_BYTES_MASK_ONLY = 117  # same without the 117-byte observation
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -48,6 +49,8 @@ def parse():
                     help="fixed TOTAL board count split over the GPUs instead (strong scaling, e.g. 1048576)")
     ap.add_argument("--mode", choices=["step", "fused"], default="fused")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the K timed plies as one hipGraph; 0: eager launches")
+    ap.add_argument("--no-obs", action="store_true",
+                    help="MASK_ONLY variant (BASELINE.md: 117 algorithmic bytes per env-step): no observation tensor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the multi-rank path on a one-GPU box")
@@ -135,12 +138,14 @@ def main():
         env_base, boards = G.shard_bounds(args.total_boards, world, rank)
     else:
         boards, env_base = args.boards, rank * args.boards
-    env = G.BatchedGobblet(boards, dev, illegal_mode="noop", auto_reset=True, seed=0, env_base=env_base)
+    env = G.BatchedGobblet(boards, dev, illegal_mode="noop", auto_reset=True, seed=0, env_base=env_base,
+                           with_observation=not args.no_obs)
+    algo_bytes = ALGO_BYTES_MASK_ONLY if args.no_obs else ALGO_BYTES_FULL
     K, W = args.steps, args.warmup
     lib, nat = G._native.lib(), G._native
     P = dict(sq=env.squares.data_ptr(), tm=env.to_move.data_ptr(), dn=env.done.data_ptr(),
              ac=env.actions.data_ptr(), wi=env.winner.data_ptr(), rw=env.rewards.data_ptr(),
-             mk=env.action_mask.data_ptr(), ob=env.observation.data_ptr())
+             mk=env.action_mask.data_ptr(), ob=None if args.no_obs else env.observation.data_ptr())
 
     def enqueue_ply(ply, stream, ev=None):
         """One ply of the pipeline on `stream`; ev = (start, stop) events bracketing the dominant kernel."""
@@ -204,14 +209,14 @@ def main():
     if graph is not None:
         # events bracket the whole replay: K dominant-kernel launches (+ K sampler launches in step
         # mode, which are subtracted pro rata by their share of algorithmic bytes: 58 of 292)
-        share = 1.0 if args.mode == "fused" else ALGO_BYTES_FULL / (ALGO_BYTES_FULL + 58.0)
+        share = 1.0 if args.mode == "fused" else algo_bytes / (algo_bytes + 58.0)
         mean_kernel_s = kernel_ms[0] * share / K / 1e3
         launches = K
     else:
         launches = len(kernel_ms)
         mean_kernel_s = sum(kernel_ms) / launches / 1e3
     units_per_launch = boards
-    achieved = ALGO_BYTES_FULL * units_per_launch / mean_kernel_s / 1e9
+    achieved = algo_bytes * units_per_launch / mean_kernel_s / 1e9
 
     if rank == 0:
         all_boards = args.total_boards if args.total_boards else boards * world
@@ -221,7 +226,7 @@ def main():
         if os.path.exists(tpath):  # HBM bytes per launch from a committed rocprofv3 --pmc run of this command
             try:
                 tj = json.load(open(tpath))
-                key = f"{args.mode}:{boards}"
+                key = f"{args.mode}{'-noobs' if args.no_obs else ''}:{boards}"
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:  # noqa: BLE001
                 traffic = None
@@ -239,14 +244,15 @@ def main():
             "dtype": "int8",
             "data": "synthetic",
             "config": {"workload": f"{boards} boards per GPU x {world} GPU(s), masked-random actions, auto-reset, "
-                                   f"FULL outputs (state+mask+obs+winner+reward+done) every ply",
+                                   f"{'MASK_ONLY' if args.no_obs else 'FULL'} outputs (state+mask{'' if args.no_obs else '+obs'}+winner+reward+done) every ply",
                        "boards_per_gpu": boards, "total_boards": all_boards, "mode": args.mode,
                        "launches_per_step": 2 if args.mode == "step" else 1,
                        "sharding": f"contiguous board ranges, {world} shard(s), no collective on the step path"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_step<mask,obs>" if args.mode == "step" else "k_rollout<mask,obs> (plies=1)",
-                         "algorithmic_bytes_per_env_step": ALGO_BYTES_FULL,
+                         "kernel": ("k_step" if args.mode == "step" else "k_rollout (plies=1)")
+                                   + ("<mask>" if args.no_obs else "<mask,obs>"),
+                         "algorithmic_bytes_per_env_step": algo_bytes,
                          "env_steps_per_launch": units_per_launch,
                          "mean_launch_us": mean_kernel_s * 1e6, "launches_timed": launches,
                          "timing": ("HIP events around the graph replay / K (includes kernel boundaries)"

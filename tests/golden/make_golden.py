@@ -367,9 +367,38 @@ def render_text():
     print("render_text.json:", len(out), "frames")
 
 
+def c1_thousand_games(n_games=1000):
+    """the AEC loop of examples/example_basic.py:50-67 over the reference
+    raw_env, masked-uniform actions drawn from numpy.random.default_rng(0); whole trajectories."""
+    rng = np.random.default_rng(0)
+    env = raw_env()
+    acts, sq, masks, winners, lens = [], [], [], [], []
+    for g in range(n_games):
+        env.reset()
+        n = 0
+        while not env.terminations["player_1"]:
+            mask = env.observe(env.agent_selection)["action_mask"]
+            a = int(rng.choice(np.arange(len(mask)), p=mask / np.sum(mask)))
+            env.step(a)
+            acts.append(a); sq.append(i8(env.board.squares)); masks.append(mask.copy())
+            winners.append(env.board.check_for_winner())
+            n += 1
+        lens.append(n)
+        if g % 100 == 0:
+            print("  c1 game", g, flush=True)
+    np.savez_compressed(os.path.join(OUT, "c1_1000_games.npz"), action=np.array(acts, np.int8),
+                        squares_after=np.array(sq, np.int8), mask_before=np.packbits(np.array(masks, np.uint8), axis=1),
+                        winner=np.array(winners, np.int8), game_len=np.array(lens, np.int16))
+    print(f"c1_1000_games.npz: {n_games} games, {len(acts)} plies, mean length {np.mean(lens):.2f}, "
+          f"P1 wins {np.mean(np.array(winners)[np.cumsum(lens) - 1] == 1):.3f}")
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "render":
         render_text()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "c1":
+        c1_thousand_games()
         return
     kat_collector()
     games = random_games()
@@ -386,6 +415,7 @@ def main():
         print(f"  {k}: winner {bf['winner'][i]} flat {bf['flatboard'][i].tolist()}")
     greedy_vectors(games)
     render_text()
+    c1_thousand_games()
 
 
 if __name__ == "__main__":

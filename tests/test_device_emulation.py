@@ -164,3 +164,12 @@ def test_greedy_vs_oracle_selfplay(boards):
     o = oracle.batch_greedy(state, tm, mask=m, depth=2)
     for x, y in zip(e, o):
         assert np.array_equal(x, y)
+
+
+def test_c1_thousand_reference_games(golden_dir):
+    from tests.test_oracle_golden import c1_plies
+    g, before, mover, mask = c1_plies(golden_dir)
+    assert np.array_equal(emu.legal_mask(before, mover), mask)
+    state, tm, dn = before.copy(), mover.copy(), np.zeros(len(mover), np.int8)
+    out = emu.step(state, tm, dn, g["action"].astype(np.int32))
+    assert np.array_equal(state, g["squares_after"]) and np.array_equal(out["winner"], g["winner"])

@@ -349,3 +349,34 @@ def test_greedy_vs_greedy_games(G):
         env.step(a)
     finished = int((npy(env.done) != 0).sum())
     assert finished > n * 0.9
+
+
+def test_c1_thousand_reference_games(G, golden_dir):
+    """BASELINE.md C1.  (a) all 12 009 plies of the 1000 reference games as one batched step;
+    (b) the AEC loop of examples/example_basic.py:50-67 over gobblet_v1.env() with the same
+    numpy.random.default_rng(0) stream: identical masks at every ply => identical action draws =>
+    identical trajectories, game after game."""
+    from tests.test_oracle_golden import c1_plies
+    g, before, mover, mask = c1_plies(golden_dir)
+    n = len(mover)
+    env = vec_env(G, n, before, mover, np.zeros(n, np.int8))
+    assert np.array_equal(npy(env.action_mask), mask)
+    obs, rew, done, win = env.step(t(g["action"].astype(np.int32)))
+    assert np.array_equal(npy(env.squares), g["squares_after"]) and np.array_equal(npy(win), g["winner"])
+    rng = np.random.default_rng(0)
+    e = G.gobblet_v1.env(device=DEV)
+    i = 0
+    for game in range(120):
+        e.reset()
+        for agent in e.agent_iter():
+            observation, reward, termination, truncation, info = e.last()
+            if termination or truncation:
+                e.step(None)
+                continue
+            m = observation["action_mask"]
+            a = int(rng.choice(np.arange(len(m)), p=m / np.sum(m)))
+            assert a == g["action"][i]
+            e.step(a)
+            assert np.array_equal(e.unwrapped.board.squares, g["squares_after"][i])
+            i += 1
+        assert i == int(np.cumsum(g["game_len"])[game])

@@ -219,3 +219,30 @@ def test_rollout_equals_sample_then_step():
     assert np.array_equal(r["winner"], out["winner"]) and np.array_equal(r["actions"], a)
     assert r["counters"][0] == n * plies and r["counters"][1] == games and games > n
     assert r["counters"][2] + r["counters"][3] == games
+
+
+def c1_plies(golden_dir):
+    """The C1 fixture (1000 reference games) flattened to independent plies: (before, mover, action, after, mask)."""
+    g = np.load(os.path.join(golden_dir, "c1_1000_games.npz"))
+    n = len(g["action"])
+    starts = np.concatenate([[0], np.cumsum(g["game_len"])[:-1]])
+    first = np.zeros(n, bool); first[starts] = True
+    before = np.zeros((n, 27), np.int8)
+    before[~first] = g["squares_after"][:-1][~first[1:]]
+    ply_in_game = np.arange(n) - np.repeat(starts, g["game_len"])
+    mover = (ply_in_game % 2).astype(np.int8)
+    mask = np.unpackbits(g["mask_before"], axis=1)[:, :54].astype(np.int8)
+    return g, before, mover, mask
+
+
+def test_c1_thousand_reference_games(golden_dir):
+    """1000 masked-random games played by the reference; every ply's mask, board and
+    winner through the oracle's batched step."""
+    g, before, mover, mask = c1_plies(golden_dir)
+    assert np.array_equal(oracle.batch_legal_mask(before, mover), mask)
+    state, tm, dn = before.copy(), mover.copy(), np.zeros(len(mover), np.int8)
+    out = oracle.batch_step(state, tm, dn, g["action"].astype(np.int32), threads=4)
+    assert np.array_equal(state, g["squares_after"]) and np.array_equal(out["winner"], g["winner"])
+    ends = np.cumsum(g["game_len"]) - 1
+    assert (g["winner"][ends] != 0).all() and (np.delete(g["winner"], ends) == 0).all()
+    assert np.array_equal(dn, (g["winner"] != 0).astype(np.int8))
