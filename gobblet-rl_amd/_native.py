@@ -40,6 +40,7 @@ SIGNATURES = {
     "gbl_winner": (_int, [_vp, _vp, _i64, _vp]),
     "gbl_flatboard": (_int, [_vp, _vp, _i64, _vp]),
     "gbl_covered": (_int, [_vp, _vp, _i64, _vp]),
+    "gbl_validate": (_int, [_vp, _vp, _i64, _vp]),
     "gbl_observe": (_int, [_vp, _vp, _int, _vp, _i64, _vp]),
     "gbl_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
     "gbl_sample": (_int, [_vp, _vp, _i64, _u64, _u64, _u32, _vp]),

@@ -165,6 +165,22 @@ class BatchedBoard:
         nat.check(self._lib.gbl_covered(self._squares.data_ptr(), out.data_ptr(), n, self._stream()), "gbl_covered")
         return out
 
+    # -- state contract (for callers that assign ``squares``) --------------------------------------------
+    def validate(self, raise_on_error: bool = True) -> torch.Tensor:
+        """int8 (N,) flags: bit 0 = a cell holds a value its level cannot hold, bit 1 = a piece number
+        occurs twice.  With ``raise_on_error`` a duplicate raises what the reference's ``is_legal`` raises
+        (board.py:94-95) and an impossible value raises ValueError."""
+        n = self.num_envs
+        out = torch.empty(n, dtype=torch.int8, device=self.device)
+        nat.check(self._lib.gbl_validate(self._squares.data_ptr(), out.data_ptr(), n, self._stream()), "gbl_validate")
+        if raise_on_error:
+            worst = int(out.max())
+            if worst & 2:
+                raise Exception("PIECE HAS BEEN USED TWICE")
+            if worst & 1:
+                raise ValueError("a cell holds a value its level cannot hold (level k: 0, +-(2k+1), +-(2k+2))")
+        return out
+
     # -- gobblet.py:179-208 (the observation planes are a pure function of the board) -------------------
     def observation(self, agent_index) -> torch.Tensor:
         """int8 (N, 3, 3, 13) as seen by ``agent_index`` (scalar 0/1 or an (N,) tensor)."""

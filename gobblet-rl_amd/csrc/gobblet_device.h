@@ -374,6 +374,28 @@ __device__ __forceinline__ void covered_row(const Planes &p, uint32_t (&d)[7])
     for (int j = 0; j < 7; ++j) d[j] = __umul24((cov >> (4 * j)) & 0xFu, 0x00204081u) & 0x01010101u;
 }
 
+// State-contract check (not on the hot path): bit 0 = some cell of level k holds a value other than
+// 0, +-(2k+1), +-(2k+2); bit 1 = some piece number occurs twice -- the condition on which the
+// reference raises Exception("PIECE HAS BEEN USED TWICE") (board.py:94-95).
+__device__ __forceinline__ uint32_t validate_row(const uint32_t (&r)[7])
+{
+    uint32_t bad = 0;
+#pragma unroll
+    for (int c = 0; c < kCells; ++c) {
+        int v = (int)(int8_t)((r[c >> 2] >> (8 * (c & 3))) & 0xFFu);
+        int a = v < 0 ? -v : v, k = c / 9;
+        bad |= (v != 0 && a != 2 * k + 1 && a != 2 * k + 2) ? 1u : 0u;
+    }
+    Planes p = make_planes(r);
+    uint32_t pos = p.nz & ~p.neg, ngv = p.nz & p.neg;
+    uint32_t X[4] = {pos & p.odd, pos & ~p.odd, ngv & p.odd, ngv & ~p.odd};
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) bad |= (__popc((X[g] >> (9 * k)) & 0x1FFu) > 1) ? 2u : 0u;
+    return bad;
+}
+
 // ---- Philox4x32-10 (Salmon et al., SC'11); known answers are checked in tests/ ---------------
 __device__ __forceinline__ uint32_t philox_first(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                  uint32_t k1)

@@ -355,6 +355,19 @@ __global__ __launch_bounds__(64) void k_decode_obs(const int8_t *__restrict__ ob
     if (L.valid) to_move[L.b] = (int8_t)agent;
 }
 
+// gbl_validate: state-contract flags per board
+__global__ __launch_bounds__(64) void k_validate(const int8_t *__restrict__ state, int8_t *__restrict__ flags, int64_t n,
+                                                 int64_t ntiles)
+{
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    Lane L;
+    if (!lane_setup(L, n, ntiles)) return;
+    uint32_t r[7];
+    load_state(state, s_state, L, r);
+    if (!L.valid) return;
+    flags[L.b] = (int8_t)validate_row(r);
+}
+
 // gbl_greedy: one decision per board (first version: one board per lane, sequential search)
 __global__ __launch_bounds__(64) void k_greedy(const int8_t *__restrict__ state, const int8_t *__restrict__ to_move,
                                                const int8_t *__restrict__ mask_in, const int8_t *__restrict__ hist,
@@ -598,6 +611,16 @@ int gbl_decode_obs(const int8_t *obs, int8_t *state, int8_t *to_move, int64_t n,
     Geometry g = geometry(n);
     hipLaunchKernelGGL(k_decode_obs, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, obs, state, to_move, n, g.ntiles);
     GBL_LAUNCHED("gbl_decode_obs");
+}
+
+int gbl_validate(const int8_t *state, int8_t *flags, int64_t n, void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(flags, "flags");
+    GBL_ALIGNED(state, "state");
+    Geometry g = geometry(n);
+    hipLaunchKernelGGL(k_validate, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, state, flags, n, g.ntiles);
+    GBL_LAUNCHED("gbl_validate");
 }
 
 int gbl_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask, const int8_t *hist, int depth,

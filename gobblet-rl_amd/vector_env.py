@@ -96,6 +96,19 @@ class BatchedGobblet:
         """{"observation", "action_mask"} of the agent to move on every board (gobblet.py:215)."""
         return {"observation": self.observation, "action_mask": self.action_mask}
 
+    # -- checkpoint / resume: the whole environment is a handful of tensors ------------------------------
+    def state_dict(self) -> dict:
+        return {"squares": self.squares.clone(), "to_move": self.to_move.clone(), "done": self.done.clone(),
+                "winner": self.winner.clone(), "rewards": self.rewards.clone(), "counters": self._counters.clone(),
+                "ply": self.ply, "seed": self.seed, "env_base": self.env_base}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.board.squares = sd["squares"]
+        self.to_move.copy_(sd["to_move"]); self.done.copy_(sd["done"]); self.winner.copy_(sd["winner"])
+        self.rewards.copy_(sd["rewards"]); self._counters.copy_(sd["counters"])
+        self.ply, self.seed, self.env_base = int(sd["ply"]), int(sd["seed"]), int(sd["env_base"])
+        self.refresh()
+
     # -- batches shaped like the reference's callers (SURVEY.md 8f2): zero-copy device views ---------------
     def tianshou_batch(self):
         """What Tianshou's PettingZooEnv wrapper hands a policy (greedy_policy_tianshou.py:63-84 reads

@@ -94,6 +94,12 @@ int gbl_flatboard(const int8_t *state, int8_t *flat, int64_t n, void *stream);
 /* Board.check_covered(), board.py:203-220: cov int8[n][27]. */
 int gbl_covered(const int8_t *state, int8_t *cov, int64_t n, void *stream);
 
+/* State-contract check for callers that assign `state` themselves (the reference lets callers
+ * assign Board.squares: greedy_policy.py:71, manual_policy.py:60).  flags int8[n]: bit 0 = a cell
+ * holds a value its level cannot hold; bit 1 = a piece number occurs twice, where the reference's
+ * is_legal raises Exception("PIECE HAS BEEN USED TWICE") (board.py:94-95).  0 = board is valid. */
+int gbl_validate(const int8_t *state, int8_t *flags, int64_t n, void *stream);
+
 /* raw_env.observe(agent)["observation"], gobblet.py:179-208.
  * agent_sel = 0 / 1: observe every board as that agent; -1: as to_move[b]
  * (to_move may be NULL unless agent_sel == -1). */

@@ -105,3 +105,8 @@ def greedy(state, to_move, mask=None, hist=None, depth=2):
     act = np.full(n, 77, np.int32); cm = np.full((n, 54), 77, np.int8); fb = np.full(n, 77, np.int8)
     lib().emu_greedy(_p(state), _p(to_move), _p(mask), _p(hist), C.c_int(depth), _p(act), _p(cm), _p(fb), C.c_int64(n))
     return act, cm, fb
+
+
+def validate(state):
+    n = len(state); out = np.full(n, 77, np.int8)
+    lib().emu_validate(_p(state), _p(out), C.c_int64(n)); return out

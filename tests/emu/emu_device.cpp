@@ -166,6 +166,15 @@ void emu_winner(const int8_t *state, int8_t *winner, int64_t n)
     });
 }
 
+void emu_validate(const int8_t *state, int8_t *flags, int64_t n)
+{
+    for_tiles(n, [&](TileCtx t) {
+        uint32_t r[64][7];
+        load_rows(state, t, r);
+        for (int l = 0; l < t.rows; ++l) flags[t.tile * 64 + l] = (int8_t)validate_row(r[l]);
+    });
+}
+
 void emu_flatboard(const int8_t *state, int8_t *flat, int64_t n)
 {
     for_tiles(n, [&](TileCtx t) {

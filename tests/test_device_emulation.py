@@ -173,3 +173,15 @@ def test_c1_thousand_reference_games(golden_dir):
     state, tm, dn = before.copy(), mover.copy(), np.zeros(len(mover), np.int8)
     out = emu.step(state, tm, dn, g["action"].astype(np.int32))
     assert np.array_equal(state, g["squares_after"]) and np.array_equal(out["winner"], g["winner"])
+
+
+def test_validate_flags(boards):
+    sq = np.ascontiguousarray(boards["squares"][:100]).copy()
+    assert (emu.validate(sq) == 0).all()
+    sq[3, 0] = 5          # a large piece on the small level
+    sq[7, 9:11] = (3, 3)  # piece 3 twice
+    sq[9, 18] = 9         # not a piece at all
+    f = emu.validate(sq)
+    assert f[3] & 1 and f[7] & 2 and f[9] & 1 and (np.delete(f, [3, 7, 9]) == 0).all()
+    with pytest.raises(Exception, match="PIECE HAS BEEN USED TWICE"):
+        oracle.is_legal(sq[7], 18, 0)  # what the reference does on that board (board.py:94-95)

@@ -267,6 +267,22 @@ def test_full_size_step_and_rollout_properties(G):
     assert np.array_equal(npy(e1.squares)[2048:], npy(e2.squares))
 
 
+def test_validate(G, golden_dir):
+    g = np.load(os.path.join(golden_dir, "board_functions.npz"))
+    sq = g["squares"][:100].copy()
+    b = G.BatchedBoard(100, DEV, squares=t(sq))
+    assert (npy(b.validate()) == 0).all()
+    sq[7, 9:11] = (3, 3)
+    b.squares = t(sq)
+    with pytest.raises(Exception, match="PIECE HAS BEEN USED TWICE"):  # board.py:94-95
+        b.validate()
+    sq[7, 9:11] = (0, 0); sq[3, 0] = 5
+    b.squares = t(sq)
+    with pytest.raises(ValueError):
+        b.validate()
+    assert npy(b.validate(raise_on_error=False))[3] == 1
+
+
 def test_error_behaviour(G):
     from gobblet_rl_amd import _native as nat
     L = nat.lib()
@@ -380,3 +396,15 @@ def test_c1_thousand_reference_games(G, golden_dir):
             assert np.array_equal(e.unwrapped.board.squares, g["squares_after"][i])
             i += 1
         assert i == int(np.cumsum(g["game_len"])[game])
+
+
+def test_checkpoint_resume(G, tmp_path):
+    a = G.BatchedGobblet(5000, DEV, auto_reset=True, seed=3)
+    a.rollout(20, count=True)
+    torch.save(a.state_dict(), tmp_path / "env.pt")
+    a.rollout(15, count=True)
+    b = G.BatchedGobblet(5000, DEV, auto_reset=True)
+    b.load_state_dict(torch.load(tmp_path / "env.pt"))
+    b.rollout(15, count=True)
+    assert torch.equal(a.squares, b.squares) and torch.equal(a.action_mask, b.action_mask)
+    assert torch.equal(a.counters, b.counters) and a.ply == b.ply
