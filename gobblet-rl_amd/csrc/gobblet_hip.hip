@@ -228,6 +228,31 @@ __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, const u
     if (WITH_MASK) tile_out<kActions>(mask_out + L.tile * (kTile * kActions), img_mask, L.lane, L.rows, (GBL_NT_STORES & 2) != 0);
 }
 
+// Diagnostic build only (-DGBL_STAMPS): per-wavefront s_memtime stamps of the fused kernel's phases,
+// written to a side buffer that nothing else reads (scripts/microbench/phase_stamps.py).  In the real
+// build the macros expand to nothing.
+#ifdef GBL_STAMPS
+__device__ unsigned long long g_stamps[1 << 17][8];
+#define GBL_STAMP(i) unsigned long long st_##i = __builtin_amdgcn_s_memtime()
+#define GBL_STAMP_DEP(i, v)                                  \
+    asm volatile("" ::"v"(v));                               \
+    unsigned long long st_##i = __builtin_amdgcn_s_memtime()
+#define GBL_STAMP_DRAIN(i)                                   \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         \
+    unsigned long long st_##i = __builtin_amdgcn_s_memtime()
+#define GBL_STAMP_FLUSH(tile)                                                                              \
+    if (threadIdx.x == 0 && (tile) < (1 << 17)) {                                                          \
+        unsigned long long *o_ = g_stamps[tile];                                                           \
+        o_[0] = st_0; o_[1] = st_1; o_[2] = st_2; o_[3] = st_3; o_[4] = st_4; o_[5] = st_5;               \
+        o_[6] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); /* HW_REG_HW_ID */                   \
+    }
+#else
+#define GBL_STAMP(i)
+#define GBL_STAMP_DEP(i, v)
+#define GBL_STAMP_DRAIN(i)
+#define GBL_STAMP_FLUSH(tile)
+#endif
+
 // gbl_step: fused raw_env.step + observe(next mover) over a tile of boards.
 template <bool WITH_MASK, bool WITH_OBS>
 __global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t *__restrict__ to_move,
@@ -277,12 +302,14 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
                                                 uint32_t plies, int illegal_mode, int64_t *__restrict__ counters)
 {
     __shared__ uint32_t s_img[kOutImageWords];
+    GBL_STAMP(0);
     Lane L;
     if (!lane_setup(L, n, ntiles)) return;
     int mover = to_move[L.valid ? L.b : n - 1];  // issued before the tile loads, branch-free (see k_step)
     uint32_t r[7];
     load_state(state, s_img, L, r);
     mover = L.valid && mover != 0;
+    GBL_STAMP_DEP(1, r[0] + (uint32_t)mover);
     Planes p = make_planes(r);
     uint32_t games = 0, w1 = 0, w2 = 0;  // wave-uniform tallies (ballot + popcount)
     Ply y{0, 0, 0, false};
@@ -296,9 +323,11 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
             w2 += __popcll(__ballot(L.valid && y.winner == -1));
         }
     }
+    GBL_STAMP_DEP(2, p.nz + (uint32_t)action);
     wave_lds_fence();
     store_rows<WITH_MASK, WITH_OBS>(s_img, L, r, WITH_MASK ? legal54(p, mover) : 0ull, p, mover, state, mask_out,
                                     obs_out);
+    GBL_STAMP(3);
     if (L.valid) {
         to_move[L.b] = (int8_t)mover;
         done[L.b] = (int8_t)dn;
@@ -317,6 +346,9 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
         if (w1) atomicAdd(c + 2, (unsigned long long)w1);
         if (w2) atomicAdd(c + 3, (unsigned long long)w2);
     }
+    GBL_STAMP(4);
+    GBL_STAMP_DRAIN(5);
+    GBL_STAMP_FLUSH(L.tile);
 }
 
 // gbl_sample: mask rows -> one action per board
@@ -440,6 +472,13 @@ __global__ __launch_bounds__(64) void k_greedy(const int8_t *__restrict__ state,
     } while (0)
 
 extern "C" {
+
+#ifdef GBL_STAMPS
+int gbl_debug_stamps(unsigned long long *host_out, int64_t ntiles)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), (size_t)ntiles * 8 * sizeof(unsigned long long));
+}
+#endif
 
 const char *gbl_last_error(void) { return g_err; }
 

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does a wavefront of the fused kernel spend its life?  Needs the library built
+with -DGBL_STAMPS (GOBBLET_HIP_LIB=.../lib_stamps.so); reads the per-wave s_memtime stamps of ONE
+launch.  Shares, not absolute speed (the stamped build is not the shipped one)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import gobblet_rl_amd as G  # noqa: E402
+
+boards = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+env = G.BatchedGobblet(boards, "cuda:0", auto_reset=True)
+for _ in range(64):
+    env.rollout(1)
+torch.cuda.synchronize()
+env.rollout(1)
+torch.cuda.synchronize()
+ntiles = min(boards // 64, 1 << 17)
+buf = np.zeros((ntiles, 8), np.uint64)
+lib = G._native.lib()
+lib.gbl_debug_stamps.argtypes = [C.c_void_p, C.c_int64]
+assert lib.gbl_debug_stamps(buf.ctypes.data, ntiles) == 0
+t = buf[:, :6].astype(np.int64)
+names = ["launch->start", "load (tile + scalars arrive)", "compute (sample+step)", "stage + issue stores", "scalar stores",
+         "drain (stores acknowledged)"]
+print(f"boards {boards}, waves {ntiles}; s_memtime ticks (100 MHz on gfx9: 10 ns)")
+d = np.diff(t, axis=1)
+for i in range(5):
+    print(f"  {names[i + 1]:34s} mean {d[:, i].mean():8.1f}  p50 {np.median(d[:, i]):8.1f}  p95 {np.percentile(d[:, i], 95):8.1f}")
+life = t[:, 5] - t[:, 0]
+print(f"  wave lifetime                      mean {life.mean():8.1f}  p50 {np.median(life):8.1f}  p95 {np.percentile(life, 95):8.1f}")
+# (s_memtime counters of different XCDs are not synchronised: only per-wave differences are meaningful)
