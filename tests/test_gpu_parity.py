@@ -408,3 +408,24 @@ def test_checkpoint_resume(G, tmp_path):
     b.rollout(15, count=True)
     assert torch.equal(a.squares, b.squares) and torch.equal(a.action_mask, b.action_mask)
     assert torch.equal(a.counters, b.counters) and a.ply == b.ply
+
+
+def test_forty_million_boards_64bit_offsets(G):
+    """40 M boards: the obs / mask buffers exceed 2^32 / 2^31 bytes, so every tile offset must be
+    64-bit.  Slices around those byte boundaries and at both ends are checked against the oracle
+    (boards are independent and the sampler is keyed by the global board id, so a slice can be
+    replayed on its own)."""
+    n, plies, seed = 40_000_000 + 13, 6, 5
+    env = G.BatchedGobblet(n, DEV, auto_reset=True, seed=seed)
+    env.rollout(plies)
+    torch.cuda.synchronize()
+    spots = [0, (1 << 31) // 117, (1 << 32) // 117, (1 << 31) // 54, (1 << 32) // 54, (1 << 30) // 27, n - 4096]
+    for s0 in spots:
+        s0 = max(0, min(n - 4096, s0 - 2048))
+        st, tm, dn = oracle.batch_reset(4096)
+        o = oracle.batch_rollout(st, tm, dn, seed, s0, 0, plies, threads=4)
+        sl = slice(s0, s0 + 4096)
+        assert np.array_equal(npy(env.squares[sl]), st), s0
+        assert np.array_equal(npy(env.action_mask[sl]), o["mask"]), s0
+        assert np.array_equal(npy(env.observation[sl]), o["obs"]), s0
+        assert np.array_equal(npy(env.winner[sl]), o["winner"]) and np.array_equal(npy(env.actions[sl]), o["actions"])
