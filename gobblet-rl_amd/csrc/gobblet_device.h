@@ -283,41 +283,13 @@ __device__ __forceinline__ void mask_row(uint64_t m, uint32_t (&d)[14])
     }
 }
 
-// raw_env.observe, gobblet.py:179-208: obs[pos][ch], int8[9][13], as 30 dwords.
+// raw_env.observe, gobblet.py:179-208: obs[pos][ch], int8[9][13]:
 //   ch 0..5 : cell(level ch/2, pos) == +(ch+1) seen from the observer (own pieces)
 //   ch 6..11: cell(level (ch-6)/2, pos) == -(ch-5)                     (opponent's)
 //   ch 12   : the observer's agent index
-__device__ __forceinline__ void obs_row(const Planes &p, int observer, uint32_t (&d)[30])
-{
-    uint32_t pos = p.nz & ~p.neg, ngv = p.nz & p.neg;
-    uint32_t own = observer ? ngv : pos, opp = observer ? pos : ngv;
-    uint32_t A = own & p.odd, B = own & ~p.odd, C = opp & p.odd, D = opp & ~p.odd;
-    uint32_t ob = observer ? 1u : 0u;
-#pragma unroll
-    for (int j = 0; j < 30; ++j) {
-        uint32_t w = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            int idx = 4 * j + b;
-            if (idx >= kObs) break;
-            int ps = idx / 13, ch = idx % 13;
-            uint32_t bitv;
-            if (ch == 12) {
-                bitv = ob;
-            } else {
-                int k = (ch % 6) / 2;
-                uint32_t src = (ch < 6) ? ((ch & 1) ? B : A) : ((ch & 1) ? D : C);
-                bitv = (src >> (9 * k + ps)) & 1u;
-            }
-            w |= bitv << (8 * b);
-        }
-        d[j] = w;
-    }
-}
-
-// The same observation written SPARSELY into a tile's LDS image: an observation has at most 12
+// written SPARSELY into a tile's LDS image: an observation has at most 12
 // ones among channels 0..11 (one per piece on the board) plus the 9 bytes of channel 12, so instead
-// of building 30 dwords per board (obs_row: ~2 VALU per byte) the wave zero-fills the image with
+// of composing 30 dwords per board (~2 VALU per byte) the wave zero-fills the image with
 // 16-byte stores and every lane then drops single bytes at  lane*117 + 13*pos + ch  -- one
 // predicated ds_write_b8 per piece.  Relies on the state contract (a piece number occurs at most
 // once), like everything else.  Call obs_image_zero, fence, obs_scatter, fence, tile_out.
