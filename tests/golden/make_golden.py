@@ -393,7 +393,46 @@ def c1_thousand_games(n_games=1000):
           f"P1 wins {np.mean(np.array(winners)[np.cumsum(lens) - 1] == 1):.3f}")
 
 
+def greedy_restricted_masks(n_positions=260, seed=21):
+    """Greedy decisions when the policy is handed only a SUBSET of the legal moves (1-3 actions, or a
+    random 40 %): drives the `len(actions_depth1) > 1` guards and the early `break`s of
+    greedy_policy.py:98-101,132-136 that full masks rarely reach."""
+    rng = np.random.default_rng(seed)
+    g = np.load(os.path.join(OUT, "random_games.npz"))
+    idx = np.flatnonzero((g["done"] == 0) & (g["ply"] >= 2))
+    pick = rng.choice(idx, size=n_positions, replace=False)
+    env = raw_env()
+    env.reset()
+    rows = {k: [] for k in ["squares", "to_move", "mask", "chosen_d1", "cands_d1", "chosen_d2", "cands_d2"]}
+    for n, i in enumerate(pick):
+        sq, tm = g["squares_after"][i], int(g["to_move_after"][i])
+        b = Board(); b.squares = sq.astype(np.float64)
+        env.board = b
+        env.agent_selection = env.agents[tm]
+        o = env.observe(env.agents[tm])
+        legal = np.flatnonzero(o["action_mask"])
+        if n % 4 == 3:
+            keep = legal[rng.random(len(legal)) < 0.4]
+            if len(keep) == 0:
+                keep = legal[:1]
+        else:
+            keep = rng.choice(legal, size=min(len(legal), 1 + n % 3), replace=False)
+        mask = np.zeros(54, np.int8); mask[keep] = 1
+        rows["squares"].append(sq); rows["to_move"].append(tm); rows["mask"].append(mask)
+        for depth in (1, 2):
+            chosen, cands, _ = greedy_decision(o["observation"], mask, depth)
+            cm = np.zeros(54, np.int8); cm[cands] = 1
+            rows[f"chosen_d{depth}"].append(chosen); rows[f"cands_d{depth}"].append(cm)
+    out = {k: np.asarray(v).astype(np.int8) for k, v in rows.items()}
+    np.savez_compressed(os.path.join(OUT, "greedy_restricted.npz"), **out)
+    print(f"greedy_restricted.npz: {n_positions} positions; depth-2 None {int((out['chosen_d2'] < 0).sum())}, "
+          f"mask sizes {np.bincount(out['mask'].sum(1))[:5]}")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "greedy_restricted":
+        greedy_restricted_masks()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "render":
         render_text()
         return
@@ -416,6 +455,7 @@ def main():
     greedy_vectors(games)
     render_text()
     c1_thousand_games()
+    greedy_restricted_masks()
 
 
 if __name__ == "__main__":

@@ -185,3 +185,13 @@ def test_validate_flags(boards):
     assert f[3] & 1 and f[7] & 2 and f[9] & 1 and (np.delete(f, [3, 7, 9]) == 0).all()
     with pytest.raises(Exception, match="PIECE HAS BEEN USED TWICE"):
         oracle.is_legal(sq[7], 18, 0)  # what the reference does on that board (board.py:94-95)
+
+
+@pytest.mark.parametrize("depth", [1, 2])
+def test_greedy_restricted_masks(golden_dir, depth):
+    g = np.load(os.path.join(golden_dir, "greedy_restricted.npz"))
+    act, cm, fb = emu.greedy(np.ascontiguousarray(g["squares"]), np.ascontiguousarray(g["to_move"]),
+                             mask=np.ascontiguousarray(g["mask"]), depth=depth)
+    assert np.array_equal(act, g[f"chosen_d{depth}"].astype(np.int32))
+    assert np.array_equal(cm, g[f"cands_d{depth}"])
+    assert np.array_equal(fb, (g[f"chosen_d{depth}"] < 0).astype(np.int8))

@@ -216,6 +216,23 @@ def test_decode_obs_and_greedy_vs_golden(G, golden_dir):
     assert int(g["chosen_d1"][320]) == 8 and int(npy(act)[320]) == 7  # App. B quirk: depth 2 overwrites the win
 
 
+def test_greedy_restricted_masks(G, golden_dir):
+    """Reference decisions when handed 1-3 (or a random 40 % of the) legal moves: guard / break paths."""
+    from gobblet_rl_amd import _native as nat
+    g = np.load(os.path.join(golden_dir, "greedy_restricted.npz"))
+    n = len(g["squares"])
+    st, who, m = t(g["squares"]), t(g["to_move"]), t(g["mask"])
+    for depth in (1, 2):
+        act = torch.empty(n, dtype=torch.int32, device=DEV); cm = torch.empty((n, 54), dtype=torch.int8, device=DEV)
+        fb = torch.empty(n, dtype=torch.int8, device=DEV)
+        nat.check(nat.lib().gbl_greedy(st.data_ptr(), who.data_ptr(), m.data_ptr(), None, depth, act.data_ptr(),
+                                       cm.data_ptr(), fb.data_ptr(), n, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(npy(act), g[f"chosen_d{depth}"].astype(np.int32))
+        assert np.array_equal(npy(cm), g[f"cands_d{depth}"])
+        assert np.array_equal(npy(fb), (g[f"chosen_d{depth}"] < 0).astype(np.int8))
+
+
 def test_greedy_vs_oracle_selfplay(G):
     from gobblet_rl_amd import _native as nat
     state, tm, dn = selfplay(3000, 26, seed=8)

@@ -246,3 +246,15 @@ def test_c1_thousand_reference_games(golden_dir):
     ends = np.cumsum(g["game_len"]) - 1
     assert (g["winner"][ends] != 0).all() and (np.delete(g["winner"], ends) == 0).all()
     assert np.array_equal(dn, (g["winner"] != 0).astype(np.int8))
+
+
+@pytest.mark.parametrize("depth", [1, 2])
+def test_greedy_restricted_masks(golden_dir, depth):
+    """Subsets of the legal moves (1-3 actions / random 40 %): the len(actions_depth1) > 1 guards and early
+    breaks of greedy_policy.py:98-101,132-136."""
+    g = np.load(os.path.join(golden_dir, "greedy_restricted.npz"))
+    act, cm, fb = oracle.batch_greedy(np.ascontiguousarray(g["squares"]), np.ascontiguousarray(g["to_move"]),
+                                      mask=np.ascontiguousarray(g["mask"]), depth=depth)
+    assert np.array_equal(act, g[f"chosen_d{depth}"].astype(np.int32))
+    assert np.array_equal(cm, g[f"cands_d{depth}"])
+    assert np.array_equal(fb, (g[f"chosen_d{depth}"] < 0).astype(np.int8))
