@@ -543,12 +543,13 @@ struct GreedyResult {
 // check_for_winner() after play_turn(mover, a) is the mover's / the other side's value
 // (board.py:118-132 then :183-194).  Only meaningful for legal a -- the caller masks with legal54.
 //
-// Bit-parallel over the 9 destinations of one piece: lifting the piece from its square s exposes
-// what lies beneath (tops after the lift: Tm, To); dropping it on q sets the mover's top at q and
-// clears the other side's.  Line l is then complete for the mover iff q supplies its only missing
-// square (or nothing is missing), and stays complete for the other side iff it was complete and q is
-// not on it.  The reference lets the LAST matching line decide, so lines are resolved from index 7
-// down, each destination taking the first verdict it meets.
+// Bit-parallel over the 9 destinations of a piece, and SWAR over three pieces at a time (10-bit fields
+// of a 32-bit word, bit 9 of each field a guard): lifting a piece from its square s exposes what
+// lies beneath (tops after the lift: Tm, To); dropping it on q sets the mover's top at q and clears
+// the other side's.  Line l is then complete for the mover iff q supplies its only missing square
+// (or nothing is missing), and stays complete for the other side iff it was complete and q is not
+// on it.  The reference lets the LAST matching line decide, so lines are resolved from index 7 down,
+// each destination taking the first verdict it meets.
 __device__ __forceinline__ void outcomes54(const Planes &p, int mover, uint64_t &win, uint64_t &lose)
 {
     uint32_t mine = mover ? (p.nz & p.neg) : (p.nz & ~p.neg);
@@ -562,29 +563,46 @@ __device__ __forceinline__ void outcomes54(const Planes &p, int mover, uint64_t 
     uint32_t um[3] = {0u, m0, m1 | (~o1 & m0)};
     uint32_t uo[3] = {0u, t0, t1 | (~o1 & t0)};
     constexpr uint32_t L[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x111u, 0x054u};  // board.py:135-153
+    constexpr uint32_t LOW3 = 0x00100401u;   // bit 0 of each field
+    constexpr uint32_t G3 = LOW3 << 9;       // guard bit of each field
+    constexpr uint32_t F3 = LOW3 * 0x1FFu;   // the 9 board bits of each field
+    uint32_t TmR = Tm | (Tm << 10) | (Tm << 20), ToR = To | (To << 10) | (To << 20);
     win = 0;
     lose = 0;
 #pragma unroll
-    for (int pi = 0; pi < 6; ++pi) {
-        int k = pi >> 1;
-        uint32_t src = ((mine & ((pi & 1) ? ~p.odd : p.odd)) >> (9 * k)) & 0x1FFu;  // where the piece stands (0: in hand)
-        uint32_t Tm_l = (Tm & ~src) | (src & um[k]);
-        uint32_t To_l = To | (src & uo[k]);
-        uint32_t w9 = 0, l9 = 0, open = 0x1FFu;
+    for (int w = 0; w < 2; ++w) {  // word w: pieces 3w, 3w+1, 3w+2
+        uint32_t lost = 0, gain = 0;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            int pi = 3 * w + f, k = pi >> 1;
+            uint32_t src = ((mine & ((pi & 1) ? ~p.odd : p.odd)) >> (9 * k)) & 0x1FFu;  // where the piece stands (0: in hand)
+            lost |= (src & ~um[k]) << (10 * f);  // the mover's top that leaves with the lift
+            gain |= (src & uo[k]) << (10 * f);   // a piece of the other side the lift exposes
+        }
+        uint32_t nTm = ~(TmR & ~lost), nTo = ~(ToR | gain);  // complements of the tops after the lift
+        uint32_t W = 0, Z = 0, open = F3;
 #pragma unroll
         for (int l = 7; l >= 0; --l) {
-            uint32_t miss = L[l] & ~Tm_l;
-            uint32_t need = (miss & (miss - 1u)) ? 0u : (miss ? miss : 0x1FFu);
-            uint32_t keep = (L[l] & ~To_l) ? 0u : (~L[l] & 0x1FFu);
-            uint32_t w = need & open;
-            w9 |= w;
-            open &= ~w;
-            uint32_t x = keep & open;
-            l9 |= x;
-            open &= ~x;
+            const uint32_t Lr = L[l] | (L[l] << 10) | (L[l] << 20);
+            uint32_t miss = Lr & nTm;                         // squares of line l the mover lacks
+            uint32_t multi = miss & ((miss | G3) - LOW3);     // != 0 in a field: two or more missing
+            uint32_t mg = (multi + F3) & G3, mm = mg - (mg >> 9);
+            uint32_t zg = G3 & ~(miss + F3), zm = zg - (zg >> 9);  // fields with nothing missing
+            uint32_t need = (miss & ~mm) | zm;                // destinations that complete line l
+            uint32_t kg = G3 & ~((Lr & nTo) + F3);            // fields where the other side holds line l
+            uint32_t keep = (kg - (kg >> 9)) & ~Lr;           // ... and keeps it: destinations off the line
+            uint32_t wv = need & open;
+            W |= wv;
+            open &= ~wv;
+            uint32_t xv = keep & open;
+            Z |= xv;
+            open &= ~xv;
         }
-        win |= (uint64_t)w9 << (9 * pi);
-        lose |= (uint64_t)l9 << (9 * pi);
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            win |= (uint64_t)((W >> (10 * f)) & 0x1FFu) << (9 * (3 * w + f));
+            lose |= (uint64_t)((Z >> (10 * f)) & 0x1FFu) << (9 * (3 * w + f));
+        }
     }
 }
 
