@@ -12,7 +12,9 @@
 // Row sizes are odd (27, 54, 117 bytes) so lane l's row starts at byte l*ROWB,
 // which is dword-aligned only every 4th (2nd) lane; the byte shift is done in
 // registers with v_alignbyte_b32 so that every LDS access is an aligned dword
-// and every HBM access a full 16-byte vector.
+// and every HBM access a full 16-byte vector.  The 117-byte observation rows are
+// the exception on the way out: they are mostly zeros, so the wave zero-fills
+// the image and each lane scatters its <= 21 one-bytes (obs_scatter).
 //
 // The game logic runs on three 27-bit planes per board (bit c = cell c of
 // Board.squares, c = 9*level + pos):  nz (cell occupied), neg (player_2's
