@@ -44,7 +44,10 @@ __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t
 // Measured (fused kernel): -2.5 % time at 2^20 boards, where the working set lives in the Infinity
 // Cache, but +7 % at 2^22, where eight far-apart write fronts cost more in HBM than the shared
 // lines save -- so batches beyond 2^21 boards keep the identity map.
-constexpr int64_t kXcdRemapMaxTiles = (int64_t)1 << 15;
+#ifndef GBL_XCD_REMAP_MAX_TILES
+#define GBL_XCD_REMAP_MAX_TILES ((int64_t)1 << 15)
+#endif
+constexpr int64_t kXcdRemapMaxTiles = GBL_XCD_REMAP_MAX_TILES;
 
 __device__ __forceinline__ int64_t xcd_tile(uint32_t bid, int64_t ntiles)
 {
@@ -58,21 +61,21 @@ __device__ __forceinline__ int64_t xcd_tile(uint32_t bid, int64_t ntiles)
 // Full tiles move as 16-byte vectors, lane l handling vectors l, l+64, ... : every wave
 // instruction covers 1 KiB of contiguous HBM.  All loads of a tile are issued before the first
 // dependent LDS write (and all LDS reads before the first store) so they overlap.
-#ifndef GBL_NT_STORES
-#define GBL_NT_STORES 1  // non-temporal hint on tile stores: bit 0 = obs (write-once, 117 B of the 207 B written per board), bit 1 = mask; measured: obs -8 %, mask neutral
-#endif
+// NT = non-temporal hint on the stores (write-once streams).  It is a TEMPLATE parameter on purpose:
+// as a runtime flag the `if (nt) nontemporal-store else store` pair is merged by the optimiser into
+// one plain store and the hint is silently lost.
+typedef uint32_t __attribute__((ext_vector_type(4))) vec4u;
 
-__device__ __forceinline__ void store16(uint4 *dst, const uint4 &v, bool nt)
+template <bool NT>
+__device__ __forceinline__ void store16(uint4 *dst, const uint4 &v)
 {
-#if GBL_NT_STORES && !defined(GBL_HOST_EMU)
-    if (nt) {  // callers pass (GBL_NT_STORES & bit) != 0
-        typedef uint32_t __attribute__((ext_vector_type(4))) v4u;
-        v4u t = {v.x, v.y, v.z, v.w};
-        __builtin_nontemporal_store(t, reinterpret_cast<v4u *>(dst));
+#ifndef GBL_HOST_EMU
+    if (NT) {
+        vec4u t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<vec4u *>(dst));
         return;
     }
 #endif
-    (void)nt;
     *dst = v;
 }
 
@@ -97,9 +100,8 @@ __device__ __forceinline__ void tile_in(const int8_t *__restrict__ g, uint32_t *
     }
 }
 
-template <int ROWB>
-__device__ __forceinline__ void tile_out(int8_t *__restrict__ g, const uint32_t *lds, int lane, int rows,
-                                         bool nt = false)
+template <int ROWB, bool NT = false>
+__device__ __forceinline__ void tile_out(int8_t *__restrict__ g, const uint32_t *lds, int lane, int rows)
 {
     constexpr int NV = kTile * ROWB / 16, FULL = NV / 64, REM = NV % 64;
     if (rows == kTile) {
@@ -110,8 +112,8 @@ __device__ __forceinline__ void tile_out(int8_t *__restrict__ g, const uint32_t 
         for (int i = 0; i < FULL; ++i) v[i] = lv[lane + 64 * i];
         if (REM && lane < REM) v[FULL] = lv[lane + 64 * FULL];
 #pragma unroll
-        for (int i = 0; i < FULL; ++i) store16(&gv[lane + 64 * i], v[i], nt);
-        if (REM && lane < REM) store16(&gv[lane + 64 * FULL], v[FULL], nt);
+        for (int i = 0; i < FULL; ++i) store16<NT>(&gv[lane + 64 * i], v[i]);
+        if (REM && lane < REM) store16<NT>(&gv[lane + 64 * FULL], v[FULL]);
     } else {
         int bytes = rows * ROWB;
         const int8_t *lb = reinterpret_cast<const int8_t *>(lds);

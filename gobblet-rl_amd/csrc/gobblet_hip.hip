@@ -3,6 +3,7 @@
 #include "gobblet_device.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/gobblet_hip.h"
@@ -39,6 +40,19 @@ inline Geometry geometry(int64_t n)
     int64_t chunk = (g.ntiles + 7) / 8;
     g.grid = (uint32_t)(chunk * 8);
     return g;
+}
+
+// Non-temporal store policy of the step kernels (see store_rows): stream the observation always, the
+// mask too once one ply's footprint exceeds the 256 MiB Infinity Cache.  GBL_NT_POLICY (environment,
+// read once) overrides it for A/B runs.
+inline int nt_policy(int64_t n)
+{
+    static const int forced = [] {
+        const char *e = getenv("GBL_NT_POLICY");
+        return e ? atoi(e) : -1;
+    }();
+    if (forced >= 0) return forced & 7;
+    return n * 234 > ((int64_t)256 << 20) ? 3 : 1;
 }
 
 // LDS words for a tile image of ROWB-byte rows (+ slack for row_load's look-ahead dword)
@@ -203,7 +217,12 @@ constexpr int kOutImageWords = image_words<kObs>() > image_words<kActions>() + i
                                    ? image_words<kObs>()
                                    : image_words<kActions>() + image_words<kCells>();
 
-template <bool WITH_MASK, bool WITH_OBS>
+// NT: which row streams are stored with the non-temporal hint -- bit 0 observation, bit 1 mask, bit 2
+// state.  Measured (profiles/r01): the write-once observation stream always gains from it; the mask
+// stream gains once a ply's footprint (234 B per board) no longer fits the 256 MiB Infinity Cache
+// (2^22 boards: 169 -> 141 us) and loses ~2 % below that; the state rows are re-read next ply and stay
+// cached.  The host picks the variant from the batch size (nt_policy()).
+template <bool WITH_MASK, bool WITH_OBS, int NT>
 __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, const uint32_t (&r)[7], uint64_t mask,
                                            const Planes &p, int observer, int8_t *__restrict__ state,
                                            int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out)
@@ -213,7 +232,7 @@ __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, const u
         wave_lds_fence();
         obs_scatter(img, L.lane, p, observer);
         wave_lds_fence();
-        tile_out<kObs>(obs_out + L.tile * (kTile * kObs), img, L.lane, L.rows, (GBL_NT_STORES & 1) != 0);
+        tile_out<kObs, (NT & 1) != 0>(obs_out + L.tile * (kTile * kObs), img, L.lane, L.rows);
         wave_lds_fence();
     }
     uint32_t *img_mask = img, *img_state = img + image_words<kActions>();
@@ -224,8 +243,9 @@ __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, const u
         row_stage<kActions>(img_mask, L.lane, d);
     }
     wave_lds_fence();
-    tile_out<kCells>(state + L.tile * (kTile * kCells), img_state, L.lane, L.rows);
-    if (WITH_MASK) tile_out<kActions>(mask_out + L.tile * (kTile * kActions), img_mask, L.lane, L.rows, (GBL_NT_STORES & 2) != 0);
+    tile_out<kCells, (NT & 4) != 0>(state + L.tile * (kTile * kCells), img_state, L.lane, L.rows);
+    if (WITH_MASK)
+        tile_out<kActions, (NT & 2) != 0>(mask_out + L.tile * (kTile * kActions), img_mask, L.lane, L.rows);
 }
 
 // Diagnostic build only (-DGBL_STAMPS): per-wavefront s_memtime stamps of the fused kernel's phases,
@@ -254,7 +274,7 @@ __device__ unsigned long long g_stamps[1 << 17][8];
 #endif
 
 // gbl_step: fused raw_env.step + observe(next mover) over a tile of boards.
-template <bool WITH_MASK, bool WITH_OBS>
+template <bool WITH_MASK, bool WITH_OBS, int NT>
 __global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t *__restrict__ to_move,
                                              int8_t *__restrict__ done, const int32_t *__restrict__ actions,
                                              int8_t *__restrict__ winner_out, int8_t *__restrict__ reward_out,
@@ -279,7 +299,7 @@ __global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t 
     int dn;
     step_lane(r, p, mover, was_done, action, illegal_mode, auto_reset, dn, y);
     wave_lds_fence();  // every lane holds its row: the image may be reused
-    store_rows<WITH_MASK, WITH_OBS>(s_img, L, r, WITH_MASK ? next_mask(p, mover, dn, auto_reset) : 0ull, p, mover,
+    store_rows<WITH_MASK, WITH_OBS, NT>(s_img, L, r, WITH_MASK ? next_mask(p, mover, dn, auto_reset) : 0ull, p, mover,
                                     state, mask_out, obs_out);
     if (L.valid) {
         to_move[L.b] = (int8_t)mover;
@@ -293,7 +313,7 @@ __global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t 
 // gbl_rollout: `plies` masked-random plies (sample + step + auto-reset) per launch; the board lives
 // in registers between plies and the outputs of the LAST ply are stored.  plies = 1 is the fused
 // "sample + step" ply of the benchmark pipeline.
-template <bool WITH_MASK, bool WITH_OBS>
+template <bool WITH_MASK, bool WITH_OBS, int NT>
 __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8_t *__restrict__ to_move,
                                                 int8_t *__restrict__ done, int32_t *__restrict__ actions_out,
                                                 int8_t *__restrict__ winner_out, int8_t *__restrict__ reward_out,
@@ -325,7 +345,7 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
     }
     GBL_STAMP_DEP(2, p.nz + (uint32_t)action);
     wave_lds_fence();
-    store_rows<WITH_MASK, WITH_OBS>(s_img, L, r, WITH_MASK ? legal54(p, mover) : 0ull, p, mover, state, mask_out,
+    store_rows<WITH_MASK, WITH_OBS, NT>(s_img, L, r, WITH_MASK ? legal54(p, mover) : 0ull, p, mover, state, mask_out,
                                     obs_out);
     GBL_STAMP(3);
     if (L.valid) {
@@ -592,14 +612,23 @@ int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *action
     Geometry g = geometry(n);
     hipStream_t s = (hipStream_t)stream;
     auto_reset = auto_reset != 0;
-#define GBL_STEP(M, O)                                                                                              \
-    hipLaunchKernelGGL((k_step<M, O>), dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions, winner_out,     \
+    const int nt = nt_policy(n);
+#define GBL_STEP_NT(M, O, NT)                                                                                       \
+    hipLaunchKernelGGL((k_step<M, O, NT>), dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions, winner_out, \
                        reward_out, mask_out, obs_out, n, g.ntiles, illegal_mode, auto_reset)
-    if (mask_out && obs_out) GBL_STEP(true, true);
-    else if (mask_out) GBL_STEP(true, false);
-    else if (obs_out) GBL_STEP(false, true);
-    else GBL_STEP(false, false);
+#define GBL_STEP(M, O)                                          \
+    switch (nt) {                                               \
+    case 0: GBL_STEP_NT(M, O, 0); break;                        \
+    case 1: GBL_STEP_NT(M, O, 1); break;                        \
+    case 7: GBL_STEP_NT(M, O, 7); break;                        \
+    default: GBL_STEP_NT(M, O, 3); break;                       \
+    }
+    if (mask_out && obs_out) GBL_STEP(true, true)
+    else if (mask_out) GBL_STEP(true, false)
+    else if (obs_out) GBL_STEP(false, true)
+    else GBL_STEP(false, false)
 #undef GBL_STEP
+#undef GBL_STEP_NT
     GBL_LAUNCHED("gbl_step");
 }
 
@@ -631,14 +660,24 @@ int gbl_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_o
         return fail(GBL_ERR_ALIGN, "counters must be 128-byte aligned");
     Geometry g = geometry(n);
     hipStream_t s = (hipStream_t)stream;
-#define GBL_ROLL(M, O)                                                                                               \
-    hipLaunchKernelGGL((k_rollout<M, O>), dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions_out, winner_out, \
-                       reward_out, mask_out, obs_out, n, g.ntiles, seed, env_base, ply0, plies, illegal_mode, counters)
-    if (mask_out && obs_out) GBL_ROLL(true, true);
-    else if (mask_out) GBL_ROLL(true, false);
-    else if (obs_out) GBL_ROLL(false, true);
-    else GBL_ROLL(false, false);
+    const int nt = nt_policy(n);
+#define GBL_ROLL_NT(M, O, NT)                                                                                       \
+    hipLaunchKernelGGL((k_rollout<M, O, NT>), dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions_out,      \
+                       winner_out, reward_out, mask_out, obs_out, n, g.ntiles, seed, env_base, ply0, plies,         \
+                       illegal_mode, counters)
+#define GBL_ROLL(M, O)                                          \
+    switch (nt) {                                               \
+    case 0: GBL_ROLL_NT(M, O, 0); break;                        \
+    case 1: GBL_ROLL_NT(M, O, 1); break;                        \
+    case 7: GBL_ROLL_NT(M, O, 7); break;                        \
+    default: GBL_ROLL_NT(M, O, 3); break;                       \
+    }
+    if (mask_out && obs_out) GBL_ROLL(true, true)
+    else if (mask_out) GBL_ROLL(true, false)
+    else if (obs_out) GBL_ROLL(false, true)
+    else GBL_ROLL(false, false)
 #undef GBL_ROLL
+#undef GBL_ROLL_NT
     GBL_LAUNCHED("gbl_rollout");
 }
 
