@@ -174,7 +174,9 @@ def main():
         # the K timed plies as ONE hipGraph (every kernel node carries its own ply index);
         # capture + instantiate happen here, outside the timed region; the replay is timed
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: calls made by other threads of this process (e.g. RCCL's watchdog polling its
+        # events in the multi-GPU runs) must not invalidate the capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             cs = nat.current_stream(dev)
             for k in range(K):
                 nat.check(enqueue_ply(W + k, cs), "capture")
