@@ -15,6 +15,7 @@ from ._native import GobbletHipError, build  # noqa: F401
 from .board import BatchedBoard  # noqa: F401
 from .vector_env import BatchedGobblet  # noqa: F401
 from .greedy_policy import GreedyGobbletPolicy  # noqa: F401
+from .random_policy import RandomAdmissiblePolicy  # noqa: F401
 from .sharding import make_shard, reduce_counters, shard_bounds  # noqa: F401
 
 __version__ = "0.1.0"

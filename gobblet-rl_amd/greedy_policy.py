@@ -90,6 +90,15 @@ class GreedyGobbletPolicy:
         observations = observations.reshape(observations.shape[0], 3, 3, -1)
         return list(self.compute_actions(observations, np.asarray(obs_batch["action_mask"])).cpu().numpy())
 
+    def forward(self, batch, state=None, **kwargs):
+        """Tianshou-adapter shape (greedy_policy_tianshou.py:63-84): ``batch.obs.obs`` / ``batch.obs.mask``
+        (or dict keys "obs" / "mask") for all environments at once -> {"act": int64 (N,)} on the host."""
+        ob = batch["obs"] if isinstance(batch, dict) else batch.obs
+        obs = ob["obs"] if isinstance(ob, dict) else ob.obs
+        mask = ob["mask"] if isinstance(ob, dict) else ob.mask
+        act = self.compute_actions(obs, torch.as_tensor(mask).to(torch.int8))
+        return {"act": act.to(torch.int64).cpu().numpy()}
+
     def compute_action_tianshou(self, obs):  # greedy_policy.py:33-36
         mask = obs.mask
         obs = obs.obs if hasattr(obs, "obs") else obs

@@ -446,3 +446,23 @@ def test_forty_million_boards_64bit_offsets(G):
         assert np.array_equal(npy(env.action_mask[sl]), o["mask"]), s0
         assert np.array_equal(npy(env.observation[sl]), o["obs"]), s0
         assert np.array_equal(npy(env.winner[sl]), o["winner"]) and np.array_equal(npy(env.actions[sl]), o["actions"])
+
+
+def test_caller_shaped_adapters(G, golden_dir):
+    """batches shaped like the reference's callers (Tianshou / RLlib adapters)."""
+    g = np.load(os.path.join(golden_dir, "greedy.npz"))
+    n = len(g["squares"])
+    env = vec_env(G, n, g["squares"], g["to_move"], np.zeros(n, np.int8))
+    tb = env.tianshou_batch()
+    assert tb["obs"].shape == (n, 3, 3, 13) and tb["mask"].dtype == torch.bool and torch.equal(tb["agent_id"], env.to_move)
+    out = G.GreedyGobbletPolicy(depth=2, device=DEV).forward({"obs": {"obs": tb["obs"], "mask": tb["mask"]}})
+    assert np.array_equal(out["act"], g["chosen_d2"].astype(np.int64))
+    rb = env.rllib_batch()
+    assert rb["observation"].shape == (n, 117)
+    acts = G.GreedyGobbletPolicy(depth=1, device=DEV).compute_actions_rllib({k: v.cpu().numpy() for k, v in rb.items()})
+    ref = g["chosen_d1"].astype(np.int64)
+    assert all(int(a) == r for a, r in zip(acts, ref) if r >= 0)
+    rnd = G.RandomAdmissiblePolicy(seed=4, device=DEV)
+    a = rnd.compute_actions(rb)
+    assert np.array_equal(npy(a), oracle.batch_sample(g["mask"], 4, 0, 0))
+    assert (g["mask"][np.arange(n), npy(a)] == 1).all()
