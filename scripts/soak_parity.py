@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on a GPU: random batch sizes / modes / seeds, every kernel against the CPU
+oracle, bit for bit, until the time budget is used.  Prints one summary line per round and a total."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gobblet_rl_amd as G  # noqa: E402
+import oracle  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+master = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+DEV = "cuda:0"
+nat = G._native
+t_end = time.time() + budget
+rounds = boards_checked = 0
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+while time.time() < t_end:
+    n = int(master.choice([1, 7, 63, 64, 65, 1000, 4097, 30011, 131072 + 5, int(master.integers(1, 200000))]))
+    seed = int(master.integers(0, 2 ** 62))
+    base = int(master.integers(0, 2 ** 40))
+    illegal = str(master.choice(["noop", "terminate"]))
+    auto = bool(master.integers(0, 2))
+    with_obs = bool(master.integers(0, 4) > 0)
+    env = G.BatchedGobblet(n, DEV, illegal_mode=illegal, auto_reset=True, with_observation=with_obs, seed=seed,
+                           env_base=base)
+    s, tm, dn = oracle.batch_reset(n)
+    k0 = int(master.integers(1, 40))
+    env.rollout(k0, count=True)
+    o = oracle.batch_rollout(s, tm, dn, seed, base, 0, k0, illegal_mode=nat.ILLEGAL_NOOP if illegal == "noop" else 1,
+                             threads=8)
+    assert np.array_equal(env.squares.cpu().numpy(), s) and np.array_equal(env.action_mask.cpu().numpy(), o["mask"])
+    assert np.array_equal(env.counters.cpu().numpy(), o["counters"])
+    # external-action steps (with wild actions), chosen auto_reset mode
+    env.auto_reset = auto
+    env.done.zero_(); dn[:] = 0
+    env.refresh()
+    for k in range(3):
+        m = oracle.batch_legal_mask(s, tm)
+        a = oracle.batch_sample(m, seed, base, 1000 + k)
+        wild = master.random(n) < 0.1
+        a = np.where(wild | (a < 0), master.integers(-2, 57, n), a).astype(np.int32)
+        oo = oracle.batch_step(s, tm, dn, a, illegal_mode=0 if illegal == "noop" else 1, auto_reset=auto, threads=8)
+        obs, rew, done, win = env.step(t(a))
+        assert np.array_equal(env.squares.cpu().numpy(), s) and np.array_equal(done.cpu().numpy(), dn)
+        assert np.array_equal(obs["action_mask"].cpu().numpy(), oo["mask"]) and np.array_equal(win.cpu().numpy(), oo["winner"])
+        assert np.array_equal(rew.cpu().numpy(), oo["reward"])
+        if with_obs:
+            assert np.array_equal(obs["observation"].cpu().numpy(), oo["obs"])
+    # board API + greedy on the current states
+    b = G.BatchedBoard(n, DEV, squares=t(s))
+    assert np.array_equal(b.check_for_winner().cpu().numpy(), oracle.batch_winner(s))
+    assert np.array_equal(b.get_flatboard().cpu().numpy(), oracle.batch_flatboard(s))
+    assert np.array_equal(b.check_covered().cpu().numpy(), oracle.batch_covered(s))
+    assert (b.validate(raise_on_error=False) == 0).all()
+    m = min(n, 20000)
+    hist = master.integers(-1, 54, (m, 2, 3)).astype(np.int8)
+    for depth in (1, 2):
+        act = torch.empty(m, dtype=torch.int32, device=DEV); cm = torch.empty((m, 54), dtype=torch.int8, device=DEV)
+        fb = torch.empty(m, dtype=torch.int8, device=DEV)
+        st, who, h = t(s[:m]), t(tm[:m]), t(hist)
+        nat.check(nat.lib().gbl_greedy(st.data_ptr(), who.data_ptr(), None, h.data_ptr(), depth, act.data_ptr(),
+                                       cm.data_ptr(), fb.data_ptr(), m, None))
+        torch.cuda.synchronize()
+        og = oracle.batch_greedy(s[:m].copy(), tm[:m].copy(), hist=hist, depth=depth)
+        assert np.array_equal(act.cpu().numpy(), og[0]) and np.array_equal(cm.cpu().numpy(), og[1])
+        assert np.array_equal(fb.cpu().numpy(), og[2])
+    rounds += 1
+    boards_checked += n
+    print(f"round {rounds}: n={n} illegal={illegal} auto_reset={auto} obs={with_obs} plies={k0}+3 OK", flush=True)
+print(f"SOAK OK: {rounds} rounds, {boards_checked} boards, every comparison bit-exact")
