@@ -153,13 +153,13 @@ def main():
             lib.gbl_sample(P["mk"], P["ac"], boards, env.seed, env.env_base, ply, stream)
             if ev:
                 ev[0].record()
-            rc = lib.gbl_step(P["sq"], P["tm"], P["dn"], P["ac"], P["wi"], P["rw"], P["mk"], P["ob"], boards, 0, 1,
+            rc = lib.gbl_step(P["sq"], P["tm"], P["dn"], P["ac"], P["wi"], P["rw"], P["mk"], P["ob"], None, boards, 0, 1,
                               stream)
         else:
             if ev:
                 ev[0].record()
             rc = lib.gbl_rollout(P["sq"], P["tm"], P["dn"], P["ac"], P["wi"], P["rw"], P["mk"], P["ob"], boards,
-                                 env.seed, env.env_base, ply, 1, 0, None, stream)
+                                 env.seed, env.env_base, ply, 1, 0, None, None, stream)
         if ev:
             ev[1].record()
         return rc

@@ -42,9 +42,9 @@ SIGNATURES = {
     "gbl_covered": (_int, [_vp, _vp, _i64, _vp]),
     "gbl_validate": (_int, [_vp, _vp, _i64, _vp]),
     "gbl_observe": (_int, [_vp, _vp, _int, _vp, _i64, _vp]),
-    "gbl_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
+    "gbl_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
     "gbl_sample": (_int, [_vp, _vp, _i64, _u64, _u64, _u32, _vp]),
-    "gbl_rollout": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u64, _u64, _u32, _u32, _int, _vp, _vp]),
+    "gbl_rollout": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u64, _u64, _u32, _u32, _int, _vp, _vp, _vp]),
     "gbl_decode_obs": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "gbl_greedy": (_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp]),
 }

@@ -427,12 +427,13 @@ struct Ply {
     int winner;     // check_for_winner() after the move
     int r0, r1;     // rewards of player_1 / player_2 for this step
     bool terminal;  // the episode ended on this step
+    bool stepped;   // raw_env.step ran, i.e. the reference did `self.turn += 1` (gobblet.py:270)
 };
 
 __device__ __forceinline__ Ply play_ply(Planes &p, uint32_t (&r)[7], int &mover, uint64_t legal, int action,
                                         int illegal_mode)
 {
-    Ply y{0, 0, 0, false};
+    Ply y{0, 0, 0, false, false};
     bool ok = (uint32_t)action < (uint32_t)kActions && ((legal >> (action & 63)) & 1ull);
     if (!ok && illegal_mode == kIllegalTerminate) {
         // gobblet.py:50-51, :114: mover -1, the other 0, everyone terminated, board untouched
@@ -441,6 +442,7 @@ __device__ __forceinline__ Ply play_ply(Planes &p, uint32_t (&r)[7], int &mover,
         y.terminal = true;
         return y;
     }
+    y.stepped = true;
     if (ok) apply_move(p, r, mover, (uint32_t)action);  // gobblet.py:244 (illegal: silent no-op, board.py:125-126)
     mover ^= 1;                                          // gobblet.py:246,267
     y.winner = winner_of(p);                             // gobblet.py:248-249
@@ -455,7 +457,7 @@ __device__ __forceinline__ Ply play_ply(Planes &p, uint32_t (&r)[7], int &mover,
 __device__ __forceinline__ void step_lane(uint32_t (&r)[7], Planes &p, int &mover, int was_done, int action,
                                           int illegal_mode, int auto_reset, int &dn, Ply &y)
 {
-    y = Ply{0, 0, 0, false};
+    y = Ply{0, 0, 0, false, false};
     dn = was_done;
     if (was_done) {
         y.winner = winner_of(p);  // frozen board (reference: _was_dead_step, gobblet.py:232-236): standing result
@@ -469,6 +471,13 @@ __device__ __forceinline__ void step_lane(uint32_t (&r)[7], Planes &p, int &move
             for (int j = 0; j < 7; ++j) r[j] = 0;
         }
     }
+}
+
+// raw_env.turn of one board after a ply (gobblet.py:270 `self.turn += 1`, :289 reset to 0)
+__device__ __forceinline__ int next_turn(int turn, const Ply &y, int auto_reset)
+{
+    turn += y.stepped ? 1 : 0;
+    return (y.terminal && auto_reset) ? 0 : turn;
 }
 
 // gobblet.py:209: the mask belongs to the agent to move; a frozen board has nobody to move

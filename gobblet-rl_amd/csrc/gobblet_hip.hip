@@ -278,8 +278,9 @@ template <bool WITH_MASK, bool WITH_OBS, int NT>
 __global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t *__restrict__ to_move,
                                              int8_t *__restrict__ done, const int32_t *__restrict__ actions,
                                              int8_t *__restrict__ winner_out, int8_t *__restrict__ reward_out,
-                                             int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out, int64_t n,
-                                             int64_t ntiles, int illegal_mode, int auto_reset)
+                                             int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out,
+                                             int32_t *__restrict__ turn, int64_t n, int64_t ntiles, int illegal_mode,
+                                             int auto_reset)
 {
     __shared__ uint32_t s_img[kOutImageWords];
     Lane L;
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t 
         if (winner_out) winner_out[L.b] = (int8_t)y.winner;
         if (reward_out)
             reinterpret_cast<uint16_t *>(reward_out)[L.b] = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
+        if (turn) turn[L.b] = next_turn(turn[L.b], y, auto_reset);
     }
 }
 
@@ -319,7 +321,8 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
                                                 int8_t *__restrict__ winner_out, int8_t *__restrict__ reward_out,
                                                 int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out, int64_t n,
                                                 int64_t ntiles, uint64_t seed, uint64_t env_base, uint32_t ply0,
-                                                uint32_t plies, int illegal_mode, int64_t *__restrict__ counters)
+                                                uint32_t plies, int illegal_mode, int64_t *__restrict__ counters,
+                                                int32_t *__restrict__ turn)
 {
     __shared__ uint32_t s_img[kOutImageWords];
     GBL_STAMP(0);
@@ -332,11 +335,14 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
     GBL_STAMP_DEP(1, r[0] + (uint32_t)mover);
     Planes p = make_planes(r);
     uint32_t games = 0, w1 = 0, w2 = 0;  // wave-uniform tallies (ballot + popcount)
-    Ply y{0, 0, 0, false};
-    int dn = 0, action = -1;
+    Ply y{0, 0, 0, false, false};
+    int dn = 0, action = -1, tcount = 0;  // tcount: turn delta, or the absolute turn once a reset happened
+    bool treset = false;
     for (uint32_t t = 0; t < plies; ++t) {
         action = sample54(legal54(p, mover), seed, env_base + (uint64_t)L.b, ply0 + t);
         step_lane(r, p, mover, 0, action, illegal_mode, 1, dn, y);
+        tcount = next_turn(tcount, y, 1);
+        treset = treset || y.terminal;
         if (counters) {
             games += __popcll(__ballot(L.valid && y.terminal));
             w1 += __popcll(__ballot(L.valid && y.winner == 1));
@@ -355,6 +361,7 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
         if (winner_out) winner_out[L.b] = (int8_t)y.winner;
         if (reward_out)
             reinterpret_cast<uint16_t *>(reward_out)[L.b] = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
+        if (turn) turn[L.b] = treset ? tcount : turn[L.b] + tcount;
     }
     // Tallies: one stripe (its own 128-byte line) per tile mod GBL_COUNTER_STRIPES, so that the
     // device-scope atomics of concurrently finishing waves go to different lines.
@@ -599,8 +606,8 @@ int gbl_observe(const int8_t *state, const int8_t *to_move, int agent_sel, int8_
 }
 
 int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out,
-             int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, int illegal_mode, int auto_reset,
-             void *stream)
+             int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int64_t n, int illegal_mode,
+             int auto_reset, void *stream)
 {
     GBL_CHECK_N(n);
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done"); GBL_NEED(actions, "actions");
@@ -609,13 +616,14 @@ int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *action
     GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask_out, "mask_out"); GBL_ALIGNED(obs_out, "obs_out");
     if (reward_out && (reinterpret_cast<uintptr_t>(reward_out) & 1u))
         return fail(GBL_ERR_ALIGN, "reward_out must be 2-byte aligned");
+    if (turn && (reinterpret_cast<uintptr_t>(turn) & 3u)) return fail(GBL_ERR_ALIGN, "turn must be 4-byte aligned");
     Geometry g = geometry(n);
     hipStream_t s = (hipStream_t)stream;
     auto_reset = auto_reset != 0;
     const int nt = nt_policy(n);
 #define GBL_STEP_NT(M, O, NT)                                                                                       \
     hipLaunchKernelGGL((k_step<M, O, NT>), dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions, winner_out, \
-                       reward_out, mask_out, obs_out, n, g.ntiles, illegal_mode, auto_reset)
+                       reward_out, mask_out, obs_out, turn, n, g.ntiles, illegal_mode, auto_reset)
 #define GBL_STEP(M, O)                                          \
     switch (nt) {                                               \
     case 0: GBL_STEP_NT(M, O, 0); break;                        \
@@ -646,7 +654,7 @@ int gbl_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, u
 
 int gbl_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_out, int8_t *winner_out,
                 int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, uint64_t seed, uint64_t env_base,
-                uint32_t ply0, uint32_t plies, int illegal_mode, int64_t *counters, void *stream)
+                uint32_t ply0, uint32_t plies, int illegal_mode, int64_t *counters, int32_t *turn, void *stream)
 {
     GBL_CHECK_N(n);
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done");
@@ -664,7 +672,7 @@ int gbl_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_o
 #define GBL_ROLL_NT(M, O, NT)                                                                                       \
     hipLaunchKernelGGL((k_rollout<M, O, NT>), dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions_out,      \
                        winner_out, reward_out, mask_out, obs_out, n, g.ntiles, seed, env_base, ply0, plies,         \
-                       illegal_mode, counters)
+                       illegal_mode, counters, turn)
 #define GBL_ROLL(M, O)                                          \
     switch (nt) {                                               \
     case 0: GBL_ROLL_NT(M, O, 0); break;                        \

@@ -7,6 +7,7 @@ the host unless the caller asks.
 
 Tensors (attributes, all on ``device``)
     squares  int8 (N, 27)        Board.squares of every board
+    turn     int32 (N,)          raw_env.turn per board (only with track_turn=True)
     to_move  int8 (N,)           index of agent_selection (0 = player_1)
     done     int8 (N,)           terminations (auto_reset: "episode ended on the last step")
     winner   int8 (N,)           check_for_winner() after the last step
@@ -26,11 +27,12 @@ class BatchedGobblet:
     metadata = {"name": "gobblet_v1_batched", "num_actions": nat.ACTIONS, "observation_shape": (3, 3, 13)}
 
     def __init__(self, num_envs: int, device="cuda:0", illegal_mode: str | int = "noop", auto_reset: bool = False,
-                 with_observation: bool = True, seed: int = 0, env_base: int = 0):
+                 with_observation: bool = True, seed: int = 0, env_base: int = 0, track_turn: bool = False):
         """illegal_mode: "noop" = raw_env semantics (silent no-op, the turn passes);
         "terminate" = env() semantics (TerminateIllegalWrapper: mover -1, episode ends).
         env_base: global index of this shard's board 0 (keys the sampler so results do not
-        depend on how boards are sharded over GPUs)."""
+        depend on how boards are sharded over GPUs).  track_turn: also keep ``turn`` (int32 (N,)),
+        the reference's per-environment ``raw_env.turn`` (plies since that board's reset)."""
         self.board = BatchedBoard(num_envs, device)
         self.device = self.board.device
         self.num_envs = self.board.num_envs
@@ -49,6 +51,7 @@ class BatchedGobblet:
         self.action_mask = torch.empty((n, nat.ACTIONS), dtype=torch.int8, device=dev)
         self.observation = torch.empty((n, 3, 3, 13), dtype=torch.int8, device=dev) if with_observation else None
         self.actions = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.turn = torch.zeros(n, dtype=torch.int32, device=dev) if track_turn else None
         # rollout tallies, striped (include/gobblet_hip.h); totals via the ``counters`` property
         self._counters = torch.zeros((nat.COUNTER_STRIPES, nat.COUNTER_STRIDE), dtype=torch.int64, device=dev)
         self.ply = 0  # lockstep ply counter (keys the sampler)
@@ -77,6 +80,8 @@ class BatchedGobblet:
         nat.check(self._lib.gbl_reset(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
                                       self.winner.data_ptr(), n, self._stream()), "gbl_reset")
         self.rewards.zero_()
+        if self.turn is not None:
+            self.turn.zero_()
         self.ply = 0
         self.refresh()
         return self.observe()
@@ -127,8 +132,8 @@ class BatchedGobblet:
         a = _as_i32(actions, n, self.device, "actions")
         nat.check(self._lib.gbl_step(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
                                      a.data_ptr(), self.winner.data_ptr(), self.rewards.data_ptr(),
-                                     self.action_mask.data_ptr(), nat.ptr(self.observation), n, self.illegal_mode,
-                                     int(self.auto_reset), self._stream()), "gbl_step")
+                                     self.action_mask.data_ptr(), nat.ptr(self.observation), nat.ptr(self.turn), n,
+                                     self.illegal_mode, int(self.auto_reset), self._stream()), "gbl_step")
         self.ply += 1
         return self.observe(), self.rewards, self.done, self.winner
 
@@ -152,7 +157,8 @@ class BatchedGobblet:
                                         self.actions.data_ptr(), self.winner.data_ptr(), self.rewards.data_ptr(),
                                         self.action_mask.data_ptr(), nat.ptr(self.observation), n, self.seed,
                                         self.env_base, self.ply, int(plies), self.illegal_mode,
-                                        self._counters.data_ptr() if count else None, self._stream()),
+                                        self._counters.data_ptr() if count else None, nat.ptr(self.turn),
+                                        self._stream()),
                   "gbl_rollout")
         self.ply += int(plies)
         return self.observe(), self.rewards, self.done, self.winner

@@ -30,6 +30,7 @@
  *   mask    int8 [n][54]      action_mask of the agent to move
  *   obs     int8 [n][3][3][13] observation of the agent to move
  *   actions int32[n]
+ *   turn    int32[n]          raw_env.turn (plies since reset), optional
  * Contract on `state`: a cell of level k holds 0 or +-(2k+1) or +-(2k+2) --
  * what legal play from reset can produce.  For such states every function is
  * bit-identical to the reference.
@@ -112,10 +113,12 @@ int gbl_observe(const int8_t *state, const int8_t *to_move, int agent_sel, int8_
  *   auto_reset != 0: `done` on entry is ignored; a board that terminates on
  *     this step reports winner / reward / done = 1 and is reset in place
  *     (zeros, player_1 to move); mask / obs are those of the fresh board.
+ *   turn (int32[n], in/out, may be NULL): raw_env.turn per board -- +1 whenever raw_env.step
+ *     runs (also on an illegal no-op, gobblet.py:270), 0 after a reset (gobblet.py:289).
  *   winner_out / reward_out / mask_out / obs_out may each be NULL. */
 int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out,
-             int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, int illegal_mode, int auto_reset,
-             void *stream);
+             int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int64_t n, int illegal_mode,
+             int auto_reset, void *stream);
 
 /* Masked-uniform action sampling -- the rule behind "masked-random actions"
  * (examples/example_basic.py:58-61, random_admissible_policy_rllib.py:23-30:
@@ -135,11 +138,11 @@ int gbl_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, u
  * are then materialised in HBM for a consumer, as with gbl_sample + gbl_step.
  * counters: device int64[GBL_COUNTER_STRIPES][GBL_COUNTER_STRIDE], 128-byte
  * aligned, atomically incremented (see above; may be NULL -- the atomics cost
- * a few microseconds per launch at 2^20 boards).  actions_out / winner_out /
- * reward_out / mask_out / obs_out may be NULL. */
+ * a few microseconds per launch at 2^20 boards).  turn: as in gbl_step (may be
+ * NULL).  actions_out / winner_out / reward_out / mask_out / obs_out may be NULL. */
 int gbl_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_out, int8_t *winner_out,
                 int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, uint64_t seed, uint64_t env_base,
-                uint32_t ply0, uint32_t plies, int illegal_mode, int64_t *counters, void *stream);
+                uint32_t ply0, uint32_t plies, int illegal_mode, int64_t *counters, int32_t *turn, void *stream);
 
 /* GreedyGobbletPolicy.compute_action board decode, greedy_policy.py:43-71:
  * obs int8[n][3][3][13] -> state int8[n][27], to_move int8[n] (channel 12). */

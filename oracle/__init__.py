@@ -60,7 +60,7 @@ def lib() -> C.CDLL:
         L.gbo_observe.restype = None
         L.gbo_observe.argtypes = [_i8p, C.c_int, C.c_int, _i8p, _i8p]
         L.gbo_step.restype = C.c_int
-        L.gbo_step.argtypes = [_i8p, _i8p, _i8p, C.c_int, C.c_int, _i8p]
+        L.gbo_step.argtypes = [_i8p, _i8p, _i8p, C.c_int, C.c_int, _i8p, C.POINTER(C.c_int)]
         L.gbo_philox4x32_10.restype = None
         L.gbo_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
         L.gbo_sample_action.restype = C.c_int
@@ -80,7 +80,7 @@ def lib() -> C.CDLL:
         L.gbo_batch_step.restype = None
         L.gbo_batch_step.argtypes = [_i8p, _i8p, _i8p, _i32p, _i8p, _i8p, _i8p, _i8p, C.c_int64, C.c_int, C.c_int]
         L.gbo_batch_step_mt.restype = None
-        L.gbo_batch_step_mt.argtypes = L.gbo_batch_step.argtypes + [C.c_int]
+        L.gbo_batch_step_mt.argtypes = L.gbo_batch_step.argtypes + [C.c_int, _i32p]
         L.gbo_batch_sample_step_mt.restype = None
         L.gbo_batch_sample_step_mt.argtypes = [_i8p, _i8p, _i8p, _i32p, _i8p, _i8p, _i8p, _i8p, C.c_int64, C.c_uint64,
                                                C.c_uint64, C.c_uint32, C.c_int, C.c_int]
@@ -88,7 +88,7 @@ def lib() -> C.CDLL:
         L.gbo_batch_sample.argtypes = [_i8p, _i32p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32]
         L.gbo_batch_rollout.restype = None
         L.gbo_batch_rollout.argtypes = [_i8p, _i8p, _i8p, _i32p, _i8p, _i8p, _i8p, _i8p, C.c_int64, C.c_uint64,
-                                        C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, _i64p]
+                                        C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, _i64p, _i32p]
         L.gbo_greedy_decode_obs.restype = C.c_int
         L.gbo_greedy_decode_obs.argtypes = [_i8p, _i8p]
         L.gbo_greedy.restype = None
@@ -167,7 +167,7 @@ def step(squares, to_move, done, action, illegal_mode=ILLEGAL_NOOP):
     """One raw_env.step on one board. Returns (squares', to_move', done', winner, reward[2])."""
     s = _i8(squares).copy()
     tm = np.array([to_move], np.int8); dn = np.array([done], np.int8); rw = np.zeros(2, np.int8)
-    w = lib().gbo_step(_p(s), _p(tm), _p(dn), int(action), int(illegal_mode), _p(rw))
+    w = lib().gbo_step(_p(s), _p(tm), _p(dn), int(action), int(illegal_mode), _p(rw), None)
     return s, int(tm[0]), int(dn[0]), int(w), rw
 
 
@@ -228,15 +228,17 @@ def batch_observe(state, to_move, agent_sel=-1):
 
 
 def batch_step(state, to_move, done, actions, illegal_mode=ILLEGAL_NOOP, auto_reset=False, threads=1,
-               want_obs=True, want_mask=True):
-    """In-place lockstep step. Returns dict(winner, reward, mask, obs)."""
+               want_obs=True, want_mask=True, turn=None):
+    """In-place lockstep step. Returns dict(winner, reward, mask, obs).  turn: optional int32[n], updated
+    in place like raw_env.turn (gobblet.py:270,289)."""
     n = state.shape[0]
     actions = np.ascontiguousarray(actions, np.int32)
     winner = np.zeros(n, np.int8); reward = np.zeros((n, 2), np.int8)
     mask = np.zeros((n, ACTIONS), np.int8) if want_mask else None
     obs = np.zeros((n, 3, 3, 13), np.int8) if want_obs else None
     lib().gbo_batch_step_mt(_p(state), _p(to_move), _p(done), _p(actions, C.c_int32), _p(winner), _p(reward),
-                            _p(mask), _p(obs), n, int(illegal_mode), int(bool(auto_reset)), int(threads))
+                            _p(mask), _p(obs), n, int(illegal_mode), int(bool(auto_reset)), int(threads),
+                            _p(turn, C.c_int32))
     return {"winner": winner, "reward": reward, "mask": mask, "obs": obs}
 
 
@@ -255,7 +257,7 @@ def batch_sample_step(state, to_move, done, actions, winner, reward, mask, obs, 
 
 
 def batch_rollout(state, to_move, done, seed, env_base, ply0, plies, illegal_mode=ILLEGAL_NOOP, threads=1,
-                  want_obs=True, want_mask=True):
+                  want_obs=True, want_mask=True, turn=None):
     """In-place fused masked-random rollout with auto-reset.
     Returns dict(actions, winner, reward, mask, obs, counters[plies, games, p1_wins, p2_wins])."""
     n = state.shape[0]
@@ -265,7 +267,7 @@ def batch_rollout(state, to_move, done, seed, env_base, ply0, plies, illegal_mod
     counters = np.zeros(4, np.int64)
     lib().gbo_batch_rollout(_p(state), _p(to_move), _p(done), _p(actions, C.c_int32), _p(winner), _p(reward),
                             _p(mask), _p(obs), n, int(seed), int(env_base), int(ply0), int(plies), int(illegal_mode),
-                            int(threads), _p(counters, C.c_int64))
+                            int(threads), _p(counters, C.c_int64), _p(turn, C.c_int32))
     return {"actions": actions, "winner": winner, "reward": reward, "mask": mask, "obs": obs, "counters": counters}
 
 

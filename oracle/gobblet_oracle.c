@@ -201,9 +201,11 @@ typedef struct {
 /* One raw_env.step(action).  Returns the winner value evaluated after the
  * move.  `done` boards are left untouched (the reference routes them to
  * _was_dead_step, gobblet.py:232-236). */
-int gbo_step(int8_t *s, int8_t *to_move, int8_t *done, int action, int illegal_mode, int8_t *reward2)
+int gbo_step(int8_t *s, int8_t *to_move, int8_t *done, int action, int illegal_mode, int8_t *reward2, int *stepped)
 {
+    /* *stepped (may be NULL): 1 iff raw_env.step ran, i.e. the reference would do `self.turn += 1` (gobblet.py:270) */
     reward2[0] = reward2[1] = 0;
+    if (stepped) *stepped = 0;
     if (*done) return gbo_check_for_winner(s);
     int mover = *to_move;
     int in_range = (action >= 0 && action < GBO_ACTIONS);
@@ -215,6 +217,7 @@ int gbo_step(int8_t *s, int8_t *to_move, int8_t *done, int action, int illegal_m
         *done = 1;
         return 0;
     }
+    if (stepped) *stepped = 1;
     if (legal) gbo_play_turn(s, mover, action); /* gobblet.py:244 */
     *to_move = (int8_t)(1 - mover);              /* gobblet.py:246,267 */
     int w = gbo_check_for_winner(s);             /* gobblet.py:248-249 */
@@ -325,17 +328,20 @@ void gbo_batch_observe(const int8_t *state, const int8_t *to_move, int agent_sel
  * whose turn it would have been.  Any of winner/reward/mask/obs may be NULL. */
 static void batch_step_range(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions,
                              int8_t *winner, int8_t *reward, int8_t *mask, int8_t *obs,
-                             int64_t b0, int64_t b1, int illegal_mode, int auto_reset)
+                             int64_t b0, int64_t b1, int illegal_mode, int auto_reset, int32_t *turn)
 {
     for (int64_t b = b0; b < b1; ++b) {
         int8_t *s = state + b * GBO_CELLS;
         int8_t r2[2];
-        int w = gbo_step(s, &to_move[b], &done[b], actions[b], illegal_mode, r2);
+        int stepped;
+        int w = gbo_step(s, &to_move[b], &done[b], actions[b], illegal_mode, r2, &stepped);
+        if (turn && stepped) turn[b] += 1; /* gobblet.py:270 */
         if (winner) winner[b] = (int8_t)w;
         if (reward) { reward[2 * b] = r2[0]; reward[2 * b + 1] = r2[1]; }
         if (auto_reset && done[b]) { /* done[b] stays 1: "episode ended on this step" */
             memset(s, 0, GBO_CELLS);
             to_move[b] = 0;
+            if (turn) turn[b] = 0; /* gobblet.py:289 */
         }
         if (mask) {
             if (done[b] && !auto_reset) memset(mask + b * GBO_ACTIONS, 0, GBO_ACTIONS);
@@ -351,7 +357,7 @@ void gbo_batch_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t 
 {
     if (auto_reset) /* flags raised last step belong to boards already reset */
         memset(done, 0, (size_t)n);
-    batch_step_range(state, to_move, done, actions, winner, reward, mask, obs, 0, n, illegal_mode, auto_reset);
+    batch_step_range(state, to_move, done, actions, winner, reward, mask, obs, 0, n, illegal_mode, auto_reset, NULL);
 }
 
 /* masked-uniform sampler over a batch (separate-kernel form) */
@@ -367,7 +373,7 @@ void gbo_batch_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t 
  * mask/obs (may be NULL) receive the outputs of the LAST ply. */
 typedef struct {
     int8_t *state, *to_move, *done, *winner, *reward, *mask, *obs;
-    int32_t *actions;
+    int32_t *actions, *turn;
     int64_t b0, b1;
     uint64_t seed, env_base;
     uint32_t ply0, plies;
@@ -387,7 +393,9 @@ static void *rollout_worker(void *arg)
             gbo_legal_mask(s, j->to_move[b], m);
             int a = gbo_sample_action(m, j->seed, j->env_base + (uint64_t)b, j->ply0 + t);
             int8_t r2[2];
-            int w = gbo_step(s, &j->to_move[b], &j->done[b], a, j->illegal_mode, r2);
+            int stepped;
+            int w = gbo_step(s, &j->to_move[b], &j->done[b], a, j->illegal_mode, r2, &stepped);
+            if (j->turn && stepped) j->turn[b] += 1;
             j->counters[0] += 1;
             if (j->actions) j->actions[b] = a;
             if (j->winner) j->winner[b] = (int8_t)w;
@@ -398,6 +406,7 @@ static void *rollout_worker(void *arg)
                 j->counters[3] += (w == -1);
                 memset(s, 0, GBO_CELLS);
                 j->to_move[b] = 0;
+                if (j->turn) j->turn[b] = 0;
             }
         }
         if (j->mask) gbo_legal_mask(s, j->to_move[b], j->mask + b * GBO_ACTIONS);
@@ -409,7 +418,7 @@ static void *rollout_worker(void *arg)
 void gbo_batch_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions,
                        int8_t *winner, int8_t *reward, int8_t *mask, int8_t *obs,
                        int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply0, uint32_t plies,
-                       int illegal_mode, int threads, int64_t *counters)
+                       int illegal_mode, int threads, int64_t *counters, int32_t *turn)
 {
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
@@ -424,7 +433,7 @@ void gbo_batch_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *ac
         rollout_job_t *j = &jobs[used];
         memset(j, 0, sizeof *j);
         j->state = state; j->to_move = to_move; j->done = done; j->actions = actions;
-        j->winner = winner; j->reward = reward; j->mask = mask; j->obs = obs;
+        j->winner = winner; j->reward = reward; j->mask = mask; j->obs = obs; j->turn = turn;
         j->b0 = b0; j->b1 = b1; j->seed = seed; j->env_base = env_base;
         j->ply0 = ply0; j->plies = plies; j->illegal_mode = illegal_mode;
         if (threads == 1) rollout_worker(j);
@@ -443,6 +452,7 @@ void gbo_batch_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *ac
 typedef struct {
     int8_t *state, *to_move, *done, *winner, *reward, *mask, *obs;
     const int32_t *actions;
+    int32_t *turn;
     int64_t b0, b1;
     int illegal_mode, auto_reset;
 } step_job_t;
@@ -452,13 +462,13 @@ static void *step_worker(void *arg)
     step_job_t *j = (step_job_t *)arg;
     if (j->auto_reset) memset(j->done + j->b0, 0, (size_t)(j->b1 - j->b0));
     batch_step_range(j->state, j->to_move, j->done, j->actions, j->winner, j->reward, j->mask, j->obs,
-                     j->b0, j->b1, j->illegal_mode, j->auto_reset);
+                     j->b0, j->b1, j->illegal_mode, j->auto_reset, j->turn);
     return NULL;
 }
 
 void gbo_batch_step_mt(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions,
                        int8_t *winner, int8_t *reward, int8_t *mask, int8_t *obs,
-                       int64_t n, int illegal_mode, int auto_reset, int threads)
+                       int64_t n, int illegal_mode, int auto_reset, int threads, int32_t *turn)
 {
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
@@ -472,7 +482,7 @@ void gbo_batch_step_mt(int8_t *state, int8_t *to_move, int8_t *done, const int32
         if (b1 > n) b1 = n;
         step_job_t *j = &jobs[used];
         j->state = state; j->to_move = to_move; j->done = done; j->actions = actions;
-        j->winner = winner; j->reward = reward; j->mask = mask; j->obs = obs;
+        j->winner = winner; j->reward = reward; j->mask = mask; j->obs = obs; j->turn = turn;
         j->b0 = b0; j->b1 = b1; j->illegal_mode = illegal_mode; j->auto_reset = auto_reset;
         if (threads == 1) step_worker(j);
         else pthread_create(&tid[used], NULL, step_worker, j);
@@ -518,7 +528,7 @@ void gbo_batch_sample_step_mt(int8_t *state, int8_t *to_move, int8_t *done, int3
         ply_job_t *j = &jobs[used];
         j->st.state = state; j->st.to_move = to_move; j->st.done = done; j->st.actions = actions;
         j->st.winner = winner; j->st.reward = reward; j->st.mask = mask; j->st.obs = obs;
-        j->st.b0 = b0; j->st.b1 = b1; j->st.illegal_mode = illegal_mode; j->st.auto_reset = 1;
+        j->st.b0 = b0; j->st.b1 = b1; j->st.illegal_mode = illegal_mode; j->st.auto_reset = 1; j->st.turn = NULL;
         j->actions_rw = actions; j->seed = seed; j->env_base = env_base; j->ply = ply;
         if (threads == 1) ply_worker(j);
         else pthread_create(&tid[used], NULL, ply_worker, j);

@@ -276,7 +276,7 @@ void emu_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_
             int64_t b = t.tile * 64 + l;
             int mover = valid ? (to_move[b] != 0) : 0;
             Planes p = make_planes(r[l]);
-            Ply y{0, 0, 0, false};
+            Ply y{0, 0, 0, false, false};
             int dn = 0, action = -1;
             for (uint32_t k = 0; k < plies; ++k) {
                 uint64_t legal = legal54(p, mover);

@@ -144,7 +144,7 @@ def test_step_optional_outputs_null(G):
     oracle.batch_step(exp_s, exp_t, exp_d, a)
     s, tmv, d, av = t(state), t(tm), t(dn), t(a)
     nat.check(nat.lib().gbl_step(s.data_ptr(), tmv.data_ptr(), d.data_ptr(), av.data_ptr(), None, None, None, None,
-                                 n, 0, 0, None))
+                                 None, n, 0, 0, None))
     torch.cuda.synchronize()
     assert np.array_equal(npy(s), exp_s) and np.array_equal(npy(tmv), exp_t) and np.array_equal(npy(d), exp_d)
 
@@ -466,3 +466,28 @@ def test_caller_shaped_adapters(G, golden_dir):
     a = rnd.compute_actions(rb)
     assert np.array_equal(npy(a), oracle.batch_sample(g["mask"], 4, 0, 0))
     assert (g["mask"][np.arange(n), npy(a)] == 1).all()
+
+
+def test_turn_counter(G, golden_dir):
+    """raw_env.turn per board (gobblet.py:270,289): golden plies (turn = ply + 1 after every step, illegal
+    no-ops included), then auto-reset steps and fused rollouts against the oracle."""
+    g = np.load(os.path.join(golden_dir, "random_games.npz"))
+    n = len(g["action"])
+    env = G.BatchedGobblet(n, DEV, track_turn=True)
+    env.board.squares = t(g["squares_before"]); env.to_move.copy_(t(g["mover"])); env.turn.copy_(t(g["ply"]))
+    env.step(t(g["action"]))
+    assert np.array_equal(npy(env.turn), g["ply"] + 1)
+    n = 5000
+    env = G.BatchedGobblet(n, DEV, auto_reset=True, seed=2, track_turn=True)
+    s, tm, dn = oracle.batch_reset(n); turn = np.zeros(n, np.int32)
+    for k in range(25):
+        a = npy(env.sample_actions())
+        env.step(env.actions)
+        oracle.batch_step(s, tm, dn, a, auto_reset=True, turn=turn)
+        assert np.array_equal(npy(env.turn), turn), k
+    env.rollout(40)
+    oracle.batch_rollout(s, tm, dn, 2, 0, 25, 40, turn=turn, threads=4)
+    assert np.array_equal(npy(env.turn), turn) and np.array_equal(npy(env.squares), s) and turn.max() > 10
+    e2 = G.BatchedGobblet(64, DEV, illegal_mode="terminate", track_turn=True)
+    e2.step(torch.full((64,), 60, dtype=torch.int32, device=DEV))  # illegal: the wrapper never calls raw step
+    assert (npy(e2.turn) == 0).all() and (npy(e2.done) == 1).all()

@@ -258,3 +258,12 @@ def test_greedy_restricted_masks(golden_dir, depth):
     assert np.array_equal(act, g[f"chosen_d{depth}"].astype(np.int32))
     assert np.array_equal(cm, g[f"cands_d{depth}"])
     assert np.array_equal(fb, (g[f"chosen_d{depth}"] < 0).astype(np.int8))
+
+
+def test_turn_counter(games):
+    """raw_env.turn (gobblet.py:270,289): +1 whenever raw step runs, illegal no-ops included."""
+    g = games
+    state = g["squares_before"].copy(); tm = g["mover"].copy(); dn = np.zeros(len(tm), np.int8)
+    turn = g["ply"].astype(np.int32).copy()
+    oracle.batch_step(state, tm, dn, g["action"], turn=turn)
+    assert np.array_equal(turn, g["ply"] + 1)
