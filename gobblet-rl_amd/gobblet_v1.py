@@ -12,7 +12,6 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import _native as nat
 from .board import BatchedBoard
 from .greedy_policy import GreedyGobbletPolicy  # noqa: F401  (gobblet_v1.py:2 re-exports it)
 

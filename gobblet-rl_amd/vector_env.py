@@ -97,6 +97,20 @@ class BatchedGobblet:
             nat.check(self._lib.gbl_observe(self.squares.data_ptr(), self.to_move.data_ptr(), -1,
                                             self.observation.data_ptr(), n, self._stream()), "gbl_observe")
 
+    def reset_where(self, which) -> None:
+        """Reset the boards selected by the bool mask `which` (N,) -- e.g. ``env.turn >= max_plies`` as a
+        truncation guard; the reference itself never truncates (gobblet.py:250-252).  Host-side helper
+        (torch indexing + refresh), not a hot-path kernel."""
+        which = torch.as_tensor(which, device=self.device).bool()
+        self.squares[which] = 0
+        self.to_move[which] = 0
+        self.done[which] = 0
+        self.winner[which] = 0
+        self.rewards[which] = 0
+        if self.turn is not None:
+            self.turn[which] = 0
+        self.refresh()
+
     def observe(self):
         """{"observation", "action_mask"} of the agent to move on every board (gobblet.py:215)."""
         return {"observation": self.observation, "action_mask": self.action_mask}

@@ -488,6 +488,12 @@ def test_turn_counter(G, golden_dir):
     env.rollout(40)
     oracle.batch_rollout(s, tm, dn, 2, 0, 25, 40, turn=turn, threads=4)
     assert np.array_equal(npy(env.turn), turn) and np.array_equal(npy(env.squares), s) and turn.max() > 10
+    before = npy(env.squares).copy()
+    old = env.turn >= 8
+    env.reset_where(old)  # truncation guard built from the turn counter
+    sel = npy(old)
+    assert (npy(env.squares)[sel] == 0).all() and np.array_equal(npy(env.squares)[~sel], before[~sel])
+    assert (npy(env.turn)[sel] == 0).all() and (npy(env.action_mask)[sel] == 1).all()
     e2 = G.BatchedGobblet(64, DEV, illegal_mode="terminate", track_turn=True)
     e2.step(torch.full((64,), 60, dtype=torch.int32, device=DEV))  # illegal: the wrapper never calls raw step
     assert (npy(e2.turn) == 0).all() and (npy(e2.done) == 1).all()
