@@ -93,6 +93,8 @@ def lib() -> C.CDLL:
         L.gbo_greedy_decode_obs.argtypes = [_i8p, _i8p]
         L.gbo_greedy.restype = None
         L.gbo_greedy.argtypes = [_i8p, C.c_int, _i8p, C.c_int, _i8p, C.POINTER(C.c_int), _i8p, C.POINTER(C.c_int)]
+        L.gbo_greedy_work.restype = None
+        L.gbo_greedy_work.argtypes = [_i64p, C.c_int]
         L.gbo_batch_greedy.restype = None
         L.gbo_batch_greedy.argtypes = [_i8p, _i8p, _i8p, _i8p, C.c_int, _i32p, _i8p, _i8p, C.c_int64]
     return _lib
@@ -278,3 +280,9 @@ def batch_greedy(state, to_move, mask=None, hist=None, depth=2):
     lib().gbo_batch_greedy(_p(state), _p(to_move), _p(mask), _p(hist), int(depth), _p(act, C.c_int32), _p(cm),
                            _p(fb), n)
     return act, cm, fb
+
+
+def greedy_work(reset=True):
+    """(legality tests, leaf evaluations) done by greedy() / batch_greedy() since the last reset."""
+    out = np.zeros(2, np.int64)
+    lib().gbo_greedy_work(_p(out, C.c_int64), int(reset)); return int(out[0]), int(out[1])

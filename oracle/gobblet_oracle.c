@@ -561,6 +561,17 @@ int gbo_greedy_decode_obs(const int8_t *obs, int8_t *squares)
     return agent_index;
 }
 
+/* Algorithmic work counters of gbo_greedy: legality tests and leaf
+ * evaluations (play_turn + check_for_winner) performed.  Not thread-safe; read by the bench on a
+ * single-threaded sample. */
+static int64_t g_greedy_legality_tests = 0, g_greedy_leaves = 0;
+void gbo_greedy_work(int64_t *out, int reset)
+{
+    out[0] = g_greedy_legality_tests;
+    out[1] = g_greedy_leaves;
+    if (reset) g_greedy_legality_tests = g_greedy_leaves = 0;
+}
+
 /* Result of one decision.
  *   chosen      : value of chosen_action just before the fallback test
  *                 (greedy_policy.py:211), -1 for None
@@ -586,7 +597,9 @@ void gbo_greedy(const int8_t *squares, int agent_index, const int8_t *mask, int 
     int res_key[GBO_ACTIONS], res_val[GBO_ACTIONS], n_res = 0; /* results dict, insertion order */
     for (int i = 0; i < n_legal; ++i) {                        /* :84 */
         int action = legal_actions[i];
+        ++g_greedy_legality_tests;
         if (gbo_is_legal(squares, action, agent_index) != 1) continue; /* :85 */
+        ++g_greedy_leaves;
         int8_t d1[GBO_CELLS];
         memcpy(d1, squares, GBO_CELLS);
         gbo_play_turn(d1, agent_index, action); /* :86-88 */
@@ -614,7 +627,9 @@ void gbo_greedy(const int8_t *squares, int agent_index, const int8_t *mask, int 
             gbo_play_turn(d1, agent_index, action); /* :107-109 */
             int all_me = 1, none_opp = 1;           /* all() over results_depth2.values() */
             for (int a2 = 0; a2 < GBO_ACTIONS; ++a2) {
+                ++g_greedy_legality_tests;
                 if (gbo_is_legal(d1, a2, opponent_index) != 1) continue; /* :112-116 */
+                ++g_greedy_leaves;
                 int8_t d2[GBO_CELLS];
                 memcpy(d2, d1, GBO_CELLS);
                 gbo_play_turn(d2, opponent_index, a2); /* :120-124 */

@@ -49,14 +49,18 @@ def main():
     ms = e0.elapsed_time(e1) / args.iters
     k = min(args.check, n)
     s, tm = env.squares[:k].cpu().numpy(), env.to_move[:k].cpu().numpy()
+    oracle.greedy_work(reset=True)
     t0 = time.perf_counter()
     o = oracle.batch_greedy(s, tm, depth=args.depth)
     cpu_s = time.perf_counter() - t0
+    tests, leaves = oracle.greedy_work()
     ok = (np.array_equal(act[:k].cpu().numpy(), o[0]) and np.array_equal(cm[:k].cpu().numpy(), o[1])
           and np.array_equal(fb[:k].cpu().numpy(), o[2]))
     print(json.dumps({"metric": "greedy depth-%d decisions/s" % args.depth, "boards": n, "ms_per_call": ms,
                       "decisions_per_s": n / (ms / 1e3), "parity_vs_oracle_on": k, "parity": bool(ok),
-                      "cpu_oracle_decisions_per_s_1core": k / cpu_s}))
+                      "cpu_oracle_decisions_per_s_1core": k / cpu_s,
+                      "reference_work_per_decision": {"legality_tests": tests / k, "leaf_evaluations": leaves / k},
+                      "leaf_evaluations_per_s_equivalent": n / (ms / 1e3) * leaves / k}))
 
 
 if __name__ == "__main__":
