@@ -497,3 +497,50 @@ def test_turn_counter(G, golden_dir):
     e2 = G.BatchedGobblet(64, DEV, illegal_mode="terminate", track_turn=True)
     e2.step(torch.full((64,), 60, dtype=torch.int32, device=DEV))  # illegal: the wrapper never calls raw step
     assert (npy(e2.turn) == 0).all() and (npy(e2.done) == 1).all()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 4097])
+def test_out_of_bounds_canaries(G, n):
+    """Every output buffer sits between canary regions; no kernel may touch a byte outside
+    [0, n * row) of any of them (ragged last tiles included)."""
+    from gobblet_rl_amd import _native as nat
+    L = nat.lib()
+    PAD = 256  # bytes, multiple of 16 so the payload stays 16-byte aligned
+
+    def guarded(nbytes):
+        buf = torch.full((PAD + ((nbytes + 15) // 16) * 16 + PAD,), 0x5A, dtype=torch.uint8, device=DEV)
+        return buf, buf[PAD:PAD + nbytes]
+
+    def intact(buf, nbytes):
+        b = buf.cpu().numpy()
+        return (b[:PAD] == 0x5A).all() and (b[PAD + nbytes:] == 0x5A).all()
+
+    state, tm, dn = selfplay(n, 12, seed=n)
+    a = oracle.batch_sample(oracle.batch_legal_mask(state, tm), 1, 0, 0)
+    sizes = {"state": 27 * n, "tm": n, "dn": n, "act": 4 * n, "win": n, "rew": 2 * n, "mask": 54 * n, "obs": 117 * n,
+             "flat": 9 * n, "cov": 27 * n, "turn": 4 * n}
+    bufs = {k: guarded(v) for k, v in sizes.items()}
+    p = {k: bufs[k][1] for k in bufs}
+    p["state"].copy_(t(state).view(torch.uint8).reshape(-1)); p["tm"].copy_(t(tm).view(torch.uint8))
+    p["dn"].zero_(); p["turn"].zero_()
+    p["act"].copy_(t(a).view(torch.uint8).reshape(-1))
+    ptr = {k: v.data_ptr() for k, v in p.items()}
+    for auto in (0, 1):
+        nat.check(L.gbl_step(ptr["state"], ptr["tm"], ptr["dn"], ptr["act"], ptr["win"], ptr["rew"], ptr["mask"],
+                             ptr["obs"], ptr["turn"], n, 0, auto, None))
+        nat.check(L.gbl_rollout(ptr["state"], ptr["tm"], ptr["dn"], ptr["act"], ptr["win"], ptr["rew"], ptr["mask"],
+                                ptr["obs"], n, 3, 0, 5, 2, 0, None, ptr["turn"], None))
+    nat.check(L.gbl_legal_mask(ptr["state"], ptr["tm"], ptr["mask"], n, None))
+    nat.check(L.gbl_observe(ptr["state"], ptr["tm"], -1, ptr["obs"], n, None))
+    nat.check(L.gbl_sample(ptr["mask"], ptr["act"], n, 1, 0, 0, None))
+    nat.check(L.gbl_winner(ptr["state"], ptr["win"], n, None))
+    nat.check(L.gbl_flatboard(ptr["state"], ptr["flat"], n, None))
+    nat.check(L.gbl_covered(ptr["state"], ptr["cov"], n, None))
+    nat.check(L.gbl_is_legal(ptr["state"], ptr["tm"], ptr["act"], ptr["win"], n, None))
+    nat.check(L.gbl_play_turn(ptr["state"], ptr["tm"], ptr["act"], n, None))
+    nat.check(L.gbl_validate(ptr["state"], ptr["win"], n, None))
+    nat.check(L.gbl_decode_obs(ptr["obs"], ptr["cov"], ptr["win"], n, None))
+    nat.check(L.gbl_greedy(ptr["state"], ptr["tm"], None, None, 2, ptr["act"], ptr["mask"], ptr["win"], n, None))
+    torch.cuda.synchronize()
+    for k, (buf, _) in bufs.items():
+        assert intact(buf, sizes[k]), k
