@@ -53,3 +53,31 @@ def test_two_rank_gloo_equals_single_shard():
     assert np.array_equal(np.concatenate([p["mask"] for p in parts]), ref["mask"])
     for p in parts:  # both ranks hold the global tallies
         assert np.array_equal(p["tallies"], ref["counters"])
+
+
+def _gpu_worker(rank, world, initfile, outdir):
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    env = G.make_shard(TOTAL, rank, world, "cuda:0", auto_reset=True, seed=SEED)  # both ranks share the one GPU here
+    env.rollout(PLIES, count=True)
+    tallies = G.reduce_counters(env.counters.cpu())
+    np.savez(os.path.join(outdir, f"g{rank}.npz"), state=env.squares.cpu().numpy(), mask=env.action_mask.cpu().numpy(),
+             obs=env.observation.cpu().numpy(), tallies=tallies.numpy(), base=env.env_base)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_gloo_on_gpu_equals_single_shard():
+    """The same with the real kernels: two ranks (sharing the one GPU of the test box), contiguous shards,
+    no collective on the step path, tallies summed afterwards == one shard holding every board."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_gpu_worker, args=(2, os.path.join(d, "init"), d), nprocs=2, join=True)
+        parts = [np.load(os.path.join(d, f"g{r}.npz")) for r in range(2)]
+    s, tm, dn = oracle.batch_reset(TOTAL)
+    ref = oracle.batch_rollout(s, tm, dn, SEED, 0, 0, PLIES, threads=4)
+    assert int(parts[1]["base"]) == len(parts[0]["state"])
+    assert np.array_equal(np.concatenate([p["state"] for p in parts]), s)
+    assert np.array_equal(np.concatenate([p["mask"] for p in parts]), ref["mask"])
+    assert np.array_equal(np.concatenate([p["obs"] for p in parts]), ref["obs"])
+    for p in parts:
+        assert np.array_equal(p["tallies"], ref["counters"])
