@@ -544,3 +544,19 @@ def test_out_of_bounds_canaries(G, n):
     torch.cuda.synchronize()
     for k, (buf, _) in bufs.items():
         assert intact(buf, sizes[k]), k
+
+
+def test_c_abi_without_python(G, tmp_path):
+    """The boundary is a plain C-ABI: examples/c_abi_example.cpp drives it with hipMalloc'ed buffers only."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "c_abi_example")
+    csrc = os.path.join(root, "gobblet-rl_amd", "csrc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_abi_example.cpp"), "-L", csrc, "-lgobblet_hip",
+                           f"-Wl,-rpath,{csrc}", "-o", exe])
+    out = subprocess.run([exe, "50000", "30"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "misaligned pointer refused" in out.stdout
