@@ -223,7 +223,7 @@ constexpr int kOutImageWords = image_words<kObs>() > image_words<kActions>() + i
 // (2^22 boards: 169 -> 141 us) and loses ~2 % below that; the state rows are re-read next ply and stay
 // cached.  The host picks the variant from the batch size (nt_policy()).
 template <bool WITH_MASK, bool WITH_OBS, int NT>
-__device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, const uint32_t (&r)[7], uint64_t mask,
+__device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, const uint32_t (&r)[7], bool mask_zero,
                                            const Planes &p, int observer, int8_t *__restrict__ state,
                                            int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out)
 {
@@ -238,8 +238,10 @@ __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, const u
     uint32_t *img_mask = img, *img_state = img + image_words<kActions>();
     row_stage<kCells>(img_state, L.lane, r);
     if (WITH_MASK) {
+        // the next mover's legal mask is computed only now, behind the observation stores: the sooner a
+        // wave's first stores are in flight, the shorter the launch's ramp-up
         uint32_t d[14];
-        mask_row(mask, d);
+        mask_row(mask_zero ? 0ull : legal54(p, observer), d);
         row_stage<kActions>(img_mask, L.lane, d);
     }
     wave_lds_fence();
@@ -300,8 +302,8 @@ __global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t 
     int dn;
     step_lane(r, p, mover, was_done, action, illegal_mode, auto_reset, dn, y);
     wave_lds_fence();  // every lane holds its row: the image may be reused
-    store_rows<WITH_MASK, WITH_OBS, NT>(s_img, L, r, WITH_MASK ? next_mask(p, mover, dn, auto_reset) : 0ull, p, mover,
-                                    state, mask_out, obs_out);
+    // gobblet.py:209: the mask belongs to the agent to move; a frozen board has nobody to move
+    store_rows<WITH_MASK, WITH_OBS, NT>(s_img, L, r, dn && !auto_reset, p, mover, state, mask_out, obs_out);
     if (L.valid) {
         to_move[L.b] = (int8_t)mover;
         done[L.b] = (int8_t)dn;
@@ -351,8 +353,7 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
     }
     GBL_STAMP_DEP(2, p.nz + (uint32_t)action);
     wave_lds_fence();
-    store_rows<WITH_MASK, WITH_OBS, NT>(s_img, L, r, WITH_MASK ? legal54(p, mover) : 0ull, p, mover, state, mask_out,
-                                    obs_out);
+    store_rows<WITH_MASK, WITH_OBS, NT>(s_img, L, r, false, p, mover, state, mask_out, obs_out);
     GBL_STAMP(3);
     if (L.valid) {
         to_move[L.b] = (int8_t)mover;
