@@ -121,6 +121,23 @@ __device__ __forceinline__ void tile_out(int8_t *__restrict__ g, const uint32_t 
     }
 }
 
+// tile_in of a FULL tile of 27-byte state rows in two halves, so that independent work can be placed
+// between the global loads and the LDS writes: 108 16-byte vectors = one per lane + one more for
+// lanes < 44, held in two plain vector registers.
+__device__ __forceinline__ void state_fetch(const int8_t *__restrict__ g, int lane, vec4u &a, vec4u &b)
+{
+    const vec4u *gv = reinterpret_cast<const vec4u *>(g);
+    a = gv[lane];
+    b = gv[lane < 44 ? lane + 64 : 107];  // branch-free: the other lanes re-read the tile's last vector
+}
+
+__device__ __forceinline__ void state_commit(uint32_t *lds, int lane, const vec4u &a, const vec4u &b)
+{
+    vec4u *lv = reinterpret_cast<vec4u *>(lds);
+    lv[lane] = a;
+    if (lane < 44) lv[lane + 64] = b;
+}
+
 // Orders this wave's LDS accesses across lanes.  A workgroup is ONE wavefront, whose LDS
 // instructions execute in issue order, so no s_barrier and no vmcnt drain is needed (a
 // __syncthreads() would also wait for every outstanding global store); the fence only keeps the
@@ -407,16 +424,26 @@ __device__ __forceinline__ uint32_t kth_bit32(uint32_t w, uint32_t k)
     return pos;
 }
 
-// masked-uniform draw (see gbl_sample in include/gobblet_hip.h); -1 if m == 0
-__device__ __forceinline__ int sample54(uint64_t m, uint64_t seed, uint64_t env_id, uint32_t ply)
+// masked-uniform draw (see gbl_sample in include/gobblet_hip.h), in two halves: the 32-bit draw
+// depends only on (seed, board id, ply) -- a kernel can compute it while its tile is still in
+// flight -- and the pick needs the mask.  -1 if m == 0.
+__device__ __forceinline__ uint32_t draw32(uint64_t seed, uint64_t env_id, uint32_t ply)
+{
+    return philox_first((uint32_t)env_id, (uint32_t)(env_id >> 32), ply, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+__device__ __forceinline__ int pick54(uint64_t m, uint32_t r)
 {
     uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
     uint32_t nlo = __popc(lo), n = nlo + __popc(hi);
-    uint32_t r = philox_first((uint32_t)env_id, (uint32_t)(env_id >> 32), ply, 0u, (uint32_t)seed,
-                              (uint32_t)(seed >> 32));
     uint32_t k = __umulhi(r, n);
     int a = (k < nlo) ? (int)kth_bit32(lo, k) : 32 + (int)kth_bit32(hi, k - nlo);
     return n ? a : -1;
+}
+
+__device__ __forceinline__ int sample54(uint64_t m, uint64_t seed, uint64_t env_id, uint32_t ply)
+{
+    return pick54(m, draw32(seed, env_id, ply));
 }
 
 // ---- one ply of one board: raw_env.step bookkeeping, gobblet.py:231-271 -------------------

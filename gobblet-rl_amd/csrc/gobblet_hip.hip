@@ -332,7 +332,23 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
     if (!lane_setup(L, n, ntiles)) return;
     int mover = to_move[L.valid ? L.b : n - 1];  // issued before the tile loads, branch-free (see k_step)
     uint32_t r[7];
-    load_state(state, s_img, L, r);
+    // The first ply's random draw does not depend on the board, so it is computed while the tile's
+    // loads are in flight: full tiles are fetched into registers first, the Philox rounds run, and only
+    // then are the vectors committed to the LDS image (the empty asm pins that order).
+    uint32_t draw;
+    if (L.rows == kTile) {
+        vec4u ta, tb;
+        state_fetch(state + L.tile * (kTile * kCells), L.lane, ta, tb);
+        draw = draw32(seed, env_base + (uint64_t)L.b, ply0);
+        asm volatile("" ::"v"(draw) : "memory");
+        state_commit(s_img, L.lane, ta, tb);
+        wave_lds_fence();
+        row_load<kCells>(s_img, L.lane, r);
+        r[6] &= 0x00FFFFFFu;
+    } else {
+        draw = draw32(seed, env_base + (uint64_t)L.b, ply0);
+        load_state(state, s_img, L, r);
+    }
     mover = L.valid && mover != 0;
     GBL_STAMP_DEP(1, r[0] + (uint32_t)mover);
     Planes p = make_planes(r);
@@ -341,7 +357,8 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
     int dn = 0, action = -1, tcount = 0;  // tcount: turn delta, or the absolute turn once a reset happened
     bool treset = false;
     for (uint32_t t = 0; t < plies; ++t) {
-        action = sample54(legal54(p, mover), seed, env_base + (uint64_t)L.b, ply0 + t);
+        action = pick54(legal54(p, mover), draw);
+        if (t + 1 < plies) draw = draw32(seed, env_base + (uint64_t)L.b, ply0 + t + 1);
         step_lane(r, p, mover, 0, action, illegal_mode, 1, dn, y);
         tcount = next_turn(tcount, y, 1);
         treset = treset || y.terminal;
