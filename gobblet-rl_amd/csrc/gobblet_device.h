@@ -79,8 +79,38 @@ __device__ __forceinline__ void store16(uint4 *dst, const uint4 &v)
     *dst = v;
 }
 
-template <int ROWB>
-__device__ __forceinline__ void tile_in(const int8_t *__restrict__ g, uint32_t *lds, int lane, int rows)
+// `between` runs after the tile's global loads have been issued and before the first dependent LDS
+// write: work that does not depend on the tile (e.g. the Philox draw) placed there overlaps the
+// load latency instead of lengthening the wave's serial path.
+#ifndef GBL_HOST_EMU
+#define GBL_PIN4(a) "v"((a).x), "v"((a).y), "v"((a).z), "v"((a).w)
+template <int N>
+__device__ __forceinline__ void pin_loads(const uint4 (&v)[N])
+{
+    // ONE asm statement per (up to) four vectors: separate statements would let the scheduler slide a
+    // later vector's load behind an earlier statement and serialise the round trips again
+    if constexpr (N == 1) asm volatile("" ::GBL_PIN4(v[0]) : "memory");
+    else if constexpr (N == 2) asm volatile("" ::GBL_PIN4(v[0]), GBL_PIN4(v[1]) : "memory");
+    else if constexpr (N == 3) asm volatile("" ::GBL_PIN4(v[0]), GBL_PIN4(v[1]), GBL_PIN4(v[2]) : "memory");
+    else {
+        asm volatile("" ::GBL_PIN4(v[0]), GBL_PIN4(v[1]), GBL_PIN4(v[2]), GBL_PIN4(v[3]) : "memory");
+        if constexpr (N > 4) {
+            uint4 rest[N - 4];
+#pragma unroll
+            for (int i = 0; i < N - 4; ++i) rest[i] = v[i + 4];
+            pin_loads<N - 4>(rest);
+        }
+    }
+}
+#endif
+
+struct NoWork {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+template <int ROWB, typename Between = NoWork>
+__device__ __forceinline__ void tile_in(const int8_t *__restrict__ g, uint32_t *lds, int lane, int rows,
+                                        Between between = Between())
 {
     constexpr int NV = kTile * ROWB / 16, FULL = NV / 64, REM = NV % 64;
     if (rows == kTile) {
@@ -89,11 +119,20 @@ __device__ __forceinline__ void tile_in(const int8_t *__restrict__ g, uint32_t *
         uint4 v[FULL + 1];
 #pragma unroll
         for (int i = 0; i < FULL; ++i) v[i] = gv[lane + 64 * i];
-        if (REM && lane < REM) v[FULL] = gv[lane + 64 * FULL];
+        if (REM) v[FULL] = gv[lane < REM ? lane + 64 * FULL : NV - 1];  // branch-free (a branch would pin the wait)
+        between();
+#ifndef GBL_HOST_EMU
+        // Keep the LDS writes (and their s_waitcnt) behind `between`, and keep EVERY load of the tile up
+        // here, issued back to back: naming all loaded dwords as operands stops the optimiser from sinking
+        // the last vector's load into the `lane < REM` branch below (or splitting it), and from moving the
+        // other loads behind this point -- either would cost a second, serial round trip to memory.
+        pin_loads<FULL + 1>(v);
+#endif
 #pragma unroll
         for (int i = 0; i < FULL; ++i) lv[lane + 64 * i] = v[i];
         if (REM && lane < REM) lv[lane + 64 * FULL] = v[FULL];
     } else {  // ragged last tile: byte granular
+        between();
         int bytes = rows * ROWB;
         int8_t *lb = reinterpret_cast<int8_t *>(lds);
         for (int i = lane; i < bytes; i += 64) lb[i] = g[i];
@@ -119,23 +158,6 @@ __device__ __forceinline__ void tile_out(int8_t *__restrict__ g, const uint32_t 
         const int8_t *lb = reinterpret_cast<const int8_t *>(lds);
         for (int i = lane; i < bytes; i += 64) g[i] = lb[i];
     }
-}
-
-// tile_in of a FULL tile of 27-byte state rows in two halves, so that independent work can be placed
-// between the global loads and the LDS writes: 108 16-byte vectors = one per lane + one more for
-// lanes < 44, held in two plain vector registers.
-__device__ __forceinline__ void state_fetch(const int8_t *__restrict__ g, int lane, vec4u &a, vec4u &b)
-{
-    const vec4u *gv = reinterpret_cast<const vec4u *>(g);
-    a = gv[lane];
-    b = gv[lane < 44 ? lane + 64 : 107];  // branch-free: the other lanes re-read the tile's last vector
-}
-
-__device__ __forceinline__ void state_commit(uint32_t *lds, int lane, const vec4u &a, const vec4u &b)
-{
-    vec4u *lv = reinterpret_cast<vec4u *>(lds);
-    lv[lane] = a;
-    if (lane < 44) lv[lane + 64] = b;
 }
 
 // Orders this wave's LDS accesses across lanes.  A workgroup is ONE wavefront, whose LDS

@@ -79,9 +79,11 @@ __device__ __forceinline__ bool lane_setup(Lane &L, int64_t n, int64_t ntiles)
     return true;
 }
 
-__device__ __forceinline__ void load_state(const int8_t *state, uint32_t *img, const Lane &L, uint32_t (&r)[7])
+template <typename Between = NoWork>
+__device__ __forceinline__ void load_state(const int8_t *state, uint32_t *img, const Lane &L, uint32_t (&r)[7],
+                                           Between between = Between())
 {
-    tile_in<kCells>(state + L.tile * (kTile * kCells), img, L.lane, L.rows);
+    tile_in<kCells>(state + L.tile * (kTile * kCells), img, L.lane, L.rows, between);
     wave_lds_fence();
     row_load<kCells>(img, L.lane, r);
     r[6] &= 0x00FFFFFFu;
@@ -332,23 +334,10 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
     if (!lane_setup(L, n, ntiles)) return;
     int mover = to_move[L.valid ? L.b : n - 1];  // issued before the tile loads, branch-free (see k_step)
     uint32_t r[7];
-    // The first ply's random draw does not depend on the board, so it is computed while the tile's
-    // loads are in flight: full tiles are fetched into registers first, the Philox rounds run, and only
-    // then are the vectors committed to the LDS image (the empty asm pins that order).
-    uint32_t draw;
-    if (L.rows == kTile) {
-        vec4u ta, tb;
-        state_fetch(state + L.tile * (kTile * kCells), L.lane, ta, tb);
-        draw = draw32(seed, env_base + (uint64_t)L.b, ply0);
-        asm volatile("" ::"v"(draw) : "memory");
-        state_commit(s_img, L.lane, ta, tb);
-        wave_lds_fence();
-        row_load<kCells>(s_img, L.lane, r);
-        r[6] &= 0x00FFFFFFu;
-    } else {
-        draw = draw32(seed, env_base + (uint64_t)L.b, ply0);
-        load_state(state, s_img, L, r);
-    }
+    // The first ply's random draw does not depend on the board: it is computed while the tile's loads
+    // are in flight (between their issue and the LDS commit), off the wave's serial path.
+    uint32_t draw = 0;
+    load_state(state, s_img, L, r, [&] { draw = draw32(seed, env_base + (uint64_t)L.b, ply0); });
     mover = L.valid && mover != 0;
     GBL_STAMP_DEP(1, r[0] + (uint32_t)mover);
     Planes p = make_planes(r);
@@ -403,13 +392,14 @@ __global__ __launch_bounds__(64) void k_sample(const int8_t *__restrict__ mask, 
     __shared__ uint32_t s_mask[image_words<kActions>()];
     Lane L;
     if (!lane_setup(L, n, ntiles)) return;
-    tile_in<kActions>(mask + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
+    uint32_t draw = 0;  // board-independent: computed while the tile is in flight
+    tile_in<kActions>(mask + L.tile * (kTile * kActions), s_mask, L.lane, L.rows,
+                      [&] { draw = draw32(seed, env_base + (uint64_t)L.b, ply); });
     wave_lds_fence();
     uint32_t d[14];
     row_load<kActions>(s_mask, L.lane, d);
     if (!L.valid) return;
-    uint64_t m = mask_bits(d);
-    actions[L.b] = sample54(m, seed, env_base + (uint64_t)L.b, ply);
+    actions[L.b] = pick54(mask_bits(d), draw);
 }
 
 // gbl_decode_obs: greedy_policy.py:43-71
