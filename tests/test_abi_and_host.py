@@ -163,3 +163,48 @@ def test_text_render_matches_reference(capsys, golden_dir):
             capsys.readouterr()
             e.step(int(g["action"][i]))
             assert capsys.readouterr().out == fr["text"], (mode, i)
+
+
+def test_seed_determinism_like_pettingzoo_seed_test():
+    """What pettingzoo.test.seed_test checks (reference tests/test_gobblet_env.py:45-50): two environments
+    driven by the same seeded action stream produce identical observations, rewards and terminations."""
+    def play(seed):
+        rng = np.random.default_rng(seed)
+        e = G.gobblet_v1.env(board_backend=OracleBoardBackend(1))
+        e.reset(seed=seed)
+        trace = []
+        for agent in e.agent_iter(max_iter=60):
+            obs, reward, term, trunc, info = e.last()
+            trace.append((agent, obs["observation"].tobytes(), obs["action_mask"].tobytes(), reward, term, trunc))
+            if term or trunc:
+                e.step(None)
+            else:
+                m = obs["action_mask"]
+                e.step(int(rng.choice(np.flatnonzero(m))))
+        return trace
+    assert play(42) == play(42)
+    assert play(42) != play(43)
+
+
+def test_api_contract_like_pettingzoo_api_test():
+    """The parts of pettingzoo.test.api_test (reference tests/test_gobblet_env.py:32-34) that concern this
+    environment: observations / masks lie in their spaces with the declared dtype and shape, rewards and
+    termination dicts cover exactly the live agents, actions are Discrete(54), dead agents step with None."""
+    e = G.gobblet_v1.env(board_backend=OracleBoardBackend(1))
+    e.reset()
+    assert e.possible_agents == ["player_1", "player_2"] and e.agents == e.possible_agents
+    assert e.action_space("player_1").n == 54
+    rng = np.random.default_rng(1)
+    for agent in e.agent_iter():
+        obs, reward, term, trunc, info = e.last()
+        assert e.observation_space(agent).contains(obs)
+        assert obs["observation"].dtype == np.int8 and obs["observation"].shape == (3, 3, 13)
+        assert obs["action_mask"].dtype == np.int8 and obs["action_mask"].shape == (54,)
+        assert set(e.rewards) == set(e.agents) == set(e.terminations) == set(e.truncations) == set(e.infos)
+        if term or trunc:
+            with pytest.raises(ValueError):
+                e.unwrapped._was_dead_step(3)  # a dead agent may only pass None
+            e.step(None)
+        else:
+            e.step(int(rng.choice(np.flatnonzero(obs["action_mask"]))))
+    assert e.agents == []
