@@ -580,7 +580,7 @@ __device__ __forceinline__ int decode_obs_row(const uint32_t (&d)[30], uint32_t 
     return agent;
 }
 
-// ---- GreedyGobbletPolicy.compute_action, greedy_policy.py:38-221 (depth 1 / 2) ----------------
+// ---- GreedyGobbletPolicy.compute_action, greedy_policy.py:38-221 (depth 1 / 2 / 3) ------------
 // planes-only form of apply_move (no byte row to maintain)
 __device__ __forceinline__ Planes moved(const Planes &p0, int mover, uint32_t a)
 {
@@ -706,7 +706,7 @@ __device__ __forceinline__ GreedyResult greedy_decide(const Planes &p, int me, u
             break;
         }
     }
-    if (depth > 1) {  // :103-157
+    if (depth > 1) {  // :103-157; depth 3 adds :160-208, whose only assignment repeats :157 -- no effect
         for (uint64_t it = seen & ~win1 & ~lose1; it;) {  // results with value 0, insertion order
             int a = __builtin_ctzll(it);
             it &= it - 1;

@@ -722,7 +722,7 @@ int gbl_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask, c
 {
     GBL_CHECK_N(n);
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(action_out, "action_out");
-    if (depth != 1 && depth != 2) return fail(GBL_ERR_ARG, "depth must be 1 or 2");
+    if (depth < 1 || depth > 3) return fail(GBL_ERR_ARG, "depth must be 1, 2 or 3");
     GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask, "mask"); GBL_ALIGNED(cand_mask_out, "cand_mask_out");
     Geometry g = geometry(n);
     hipLaunchKernelGGL(k_greedy, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, state, to_move, mask, hist, depth,

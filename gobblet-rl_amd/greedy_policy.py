@@ -1,4 +1,4 @@
-"""``GreedyGobbletPolicy`` -- the reference's depth-1/2 lookahead policy (gobblet_rl/game/greedy_policy.py)
+"""``GreedyGobbletPolicy`` -- the reference's depth-1/2/3 lookahead policy (gobblet_rl/game/greedy_policy.py)
 for N boards at once on the GPU.
 
 Same constructor and method names as the reference class.  ``compute_action(obs, mask)`` takes one
@@ -9,7 +9,9 @@ is ``gbl_greedy``.  Per-agent history of own actions (``prev_actions``, greedy_p
 kept per board on the device.  Where the reference falls back to ``np.random.choice(actions_depth1)``
 (:211-217, numpy's global RNG) this class draws uniformly from the same candidate set with the
 library's counter-based sampler (``gbl_sample``), keyed by (seed, board, call index).
-Depth 3 (:160-208) is not implemented.
+``depth=3`` is accepted and decides like ``depth=2``: the reference's depth-3 block (:160-208) only ever
+re-assigns ``chosen_action = action``, which :157 has just done (checked against the reference itself,
+tests/golden/greedy_depth3.npz).
 """
 from __future__ import annotations
 
@@ -23,8 +25,8 @@ from . import _native as nat
 
 class GreedyGobbletPolicy:
     def __init__(self, depth: Optional[int] = 2, seed: Optional[int] = 0, device="cuda:0", **kwargs: Any) -> None:
-        if depth not in (1, 2):
-            raise ValueError("depth must be 1 or 2 (the reference's depth-3 branch is out of scope)")
+        if depth not in (1, 2, 3):
+            raise ValueError("depth must be 1, 2 or 3")
         self.depth = depth
         self.seed = int(seed or 0)
         self.device = torch.device(device)

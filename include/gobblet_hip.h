@@ -148,9 +148,12 @@ int gbl_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_o
  * obs int8[n][3][3][13] -> state int8[n][27], to_move int8[n] (channel 12). */
 int gbl_decode_obs(const int8_t *obs, int8_t *state, int8_t *to_move, int64_t n, void *stream);
 
-/* GreedyGobbletPolicy.compute_action, greedy_policy.py:38-221, depth 1 or 2
- * (depth-3 branch :160-208 is out of scope), for the agent
- * to move on each board.
+/* GreedyGobbletPolicy.compute_action, greedy_policy.py:38-221, depth 1, 2 or
+ * 3, for the agent to move on each board.  depth 3 returns the depth-2
+ * decision: the only assignment in the reference's depth-3 block (:160-208)
+ * is `chosen_action = action` (:197), which :157 has just made, and
+ * actions_depth3 is local, so that block cannot change the result (pinned on
+ * the reference itself by tests/golden/greedy_depth3.npz).
  *   mask     : legal mask handed to the policy (NULL = derive from state)
  *   hist     : int8[n][2][3] last three actions per agent, -1 = none (NULL = empty)
  *   action_out   int32[n] : chosen action; -1 where the reference falls back

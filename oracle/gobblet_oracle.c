@@ -539,7 +539,7 @@ void gbo_batch_sample_step_mt(int8_t *state, int8_t *to_move, int8_t *done, int3
 }
 
 /* ------------------------------------------------------------------------- */
-/* GreedyGobbletPolicy.compute_action, greedy_policy.py:38-221, depth 1 or 2. */
+/* GreedyGobbletPolicy.compute_action, greedy_policy.py:38-221, depth 1, 2 or 3. */
 
 /* greedy_policy.py:43-71: rebuild the signed 27-vector from an observation.
  * Returns agent_index (obs[...,12].max()). */
@@ -626,6 +626,7 @@ void gbo_greedy(const int8_t *squares, int agent_index, const int8_t *mask, int 
             memcpy(d1, squares, GBO_CELLS);
             gbo_play_turn(d1, agent_index, action); /* :107-109 */
             int all_me = 1, none_opp = 1;           /* all() over results_depth2.values() */
+            int r2_key[GBO_ACTIONS], r2_val[GBO_ACTIONS], n_r2 = 0; /* results_depth2, insertion order */
             for (int a2 = 0; a2 < GBO_ACTIONS; ++a2) {
                 ++g_greedy_legality_tests;
                 if (gbo_is_legal(d1, a2, opponent_index) != 1) continue; /* :112-116 */
@@ -634,6 +635,8 @@ void gbo_greedy(const int8_t *squares, int agent_index, const int8_t *mask, int 
                 memcpy(d2, d1, GBO_CELLS);
                 gbo_play_turn(d2, opponent_index, a2); /* :120-124 */
                 int r2 = gbo_check_for_winner(d2);     /* :126 */
+                r2_key[n_r2] = a2;
+                r2_val[n_r2++] = r2;
                 if (r2 != winner_values[agent_index]) all_me = 0;
                 if (r2 == winner_values[opponent_index]) none_opp = 0;
                 if (r2 == winner_values[opponent_index]) { /* :129-131 */
@@ -652,7 +655,49 @@ void gbo_greedy(const int8_t *squares, int agent_index, const int8_t *mask, int 
                 chosen = action;
                 break;
             }
-            if (none_opp) chosen = action; /* :153-157 (depth-3 branch :160-208 not restated) */
+            if (none_opp) { /* :153-157 */
+                chosen = action;
+                if (depth == 3) { /* :160-208, restated as written: the moves are played by
+                                   * agent_index, and the leaf replays `action`, not act_depth3 */
+                    memcpy(d1, squares, GBO_CELLS);
+                    gbo_play_turn(d1, agent_index, action); /* :161-163 */
+                    for (int j = 0; j < n_r2; ++j) {
+                        if (r2_val[j] != 0) continue; /* :166-168 */
+                        int8_t d2[GBO_CELLS];
+                        memcpy(d2, d1, GBO_CELLS);
+                        gbo_play_turn(d2, agent_index, r2_key[j]); /* :169-173 */
+                        int8_t in_d3[GBO_ACTIONS];
+                        int n_d3 = 0;
+                        for (int a3 = 0; a3 < GBO_ACTIONS; ++a3) { /* :175-182 */
+                            ++g_greedy_legality_tests;
+                            in_d3[a3] = (int8_t)(gbo_is_legal(d2, a3, agent_index) == 1);
+                            n_d3 += in_d3[a3];
+                        }
+                        int8_t was_legal3[GBO_ACTIONS];
+                        memcpy(was_legal3, in_d3, GBO_ACTIONS); /* legal_actions_depth3 vs actions_depth3 */
+                        for (int a3 = 0; a3 < GBO_ACTIONS; ++a3) { /* :186 */
+                            if (!was_legal3[a3]) continue;
+                            ++g_greedy_leaves;
+                            int8_t d3[GBO_CELLS];
+                            memcpy(d3, d2, GBO_CELLS);
+                            gbo_play_turn(d3, agent_index, action); /* :187-191 */
+                            int r3 = gbo_check_for_winner(d3);      /* :194 */
+                            if (r3 == winner_values[agent_index]) { /* :195-199 */
+                                chosen = action;
+                                break;
+                            } else if (r3 == winner_values[opponent_index]) { /* :200-208 */
+                                if (n_d3 > 1) {
+                                    if (in_d3[action]) {
+                                        in_d3[action] = 0;
+                                        --n_d3;
+                                    }
+                                } else
+                                    break;
+                            }
+                        }
+                    }
+                }
+            }
         }
     }
 

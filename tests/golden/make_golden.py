@@ -429,9 +429,44 @@ def greedy_restricted_masks(n_positions=260, seed=21):
           f"mask sizes {np.bincount(out['mask'].sum(1))[:5]}")
 
 
+def greedy_depth3():
+    """depth=3 decisions of the reference for every position of greedy.npz and greedy_restricted.npz.
+    The depth-3 block (greedy_policy.py:160-208) can only re-assign `chosen_action = action`, which
+    :157 has just assigned, so the decisions must equal the depth-2 ones; this fixture pins that on the
+    reference itself instead of on a reading of its source."""
+    env = raw_env()
+    env.reset()
+    out = {}
+    for tag, name in (("full", "greedy.npz"), ("restricted", "greedy_restricted.npz")):
+        g = np.load(os.path.join(OUT, name))
+        chosen, cands = [], []
+        # the reference's depth 3 costs up to a minute per full-mask position: sample
+        index = sorted(set(range(0, len(g["squares"]), 3 if tag == "full" else 2)) | ({320, 321} if tag == "full" else set()))
+        for n, i in enumerate(index):
+            tm = int(g["to_move"][i])
+            b = Board(); b.squares = g["squares"][i].astype(np.float64)
+            env.board = b
+            env.agent_selection = env.agents[tm]
+            obs = env.observe(env.agents[tm])["observation"]
+            c, lst, _ = greedy_decision(obs, g["mask"][i], 3)
+            cm = np.zeros(54, np.int8); cm[lst] = 1
+            chosen.append(c); cands.append(cm)
+            if n % 20 == 0:
+                print("  depth3", tag, n, "/", len(index), flush=True)
+        out[f"index_{tag}"] = np.asarray(index, np.int32)
+        out[f"chosen_d3_{tag}"] = np.asarray(chosen, np.int8)
+        out[f"cands_d3_{tag}"] = np.asarray(cands, np.int8)
+        print(f"{name}: depth-3 == depth-2 on {int((out[f'chosen_d3_{tag}'] == g['chosen_d2'][index]).sum())} of "
+              f"{len(chosen)} positions; candidate lists equal: {bool((out[f'cands_d3_{tag}'] == g['cands_d2'][index]).all())}")
+    np.savez_compressed(os.path.join(OUT, "greedy_depth3.npz"), **out)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "greedy_restricted":
         greedy_restricted_masks()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "greedy_depth3":
+        greedy_depth3()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "render":
         render_text()
@@ -456,6 +491,7 @@ def main():
     render_text()
     c1_thousand_games()
     greedy_restricted_masks()
+    greedy_depth3()
 
 
 if __name__ == "__main__":

@@ -37,7 +37,8 @@ def test_layout_info_and_host_side_argument_errors():
     assert L.gbl_winner(None, None, 5, None) == nat.ERR_ARG
     assert L.gbl_legal_mask(16, 16, 24, 5, None) == nat.ERR_ALIGN  # mask pointer not 16-byte aligned
     assert L.gbl_step(16, 16, 16, 16, None, None, None, None, None, 5, 7, 0, None) == nat.ERR_ARG  # bad illegal_mode
-    assert L.gbl_greedy(16, 16, None, None, 3, 16, None, None, 5, None) == nat.ERR_ARG       # depth 3 out of scope
+    assert L.gbl_greedy(16, 16, None, None, 4, 16, None, None, 5, None) == nat.ERR_ARG       # depth is 1, 2 or 3
+    assert L.gbl_greedy(16, 16, None, None, 0, 16, None, None, 5, None) == nat.ERR_ARG
     assert L.gbl_observe(16, None, -1, 16, 5, None) == nat.ERR_ARG                           # needs to_move
     with pytest.raises(nat.GobbletHipError):
         nat.check(nat.ERR_ARG, "x")

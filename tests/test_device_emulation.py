@@ -195,3 +195,22 @@ def test_greedy_restricted_masks(golden_dir, depth):
     assert np.array_equal(act, g[f"chosen_d{depth}"].astype(np.int32))
     assert np.array_equal(cm, g[f"cands_d{depth}"])
     assert np.array_equal(fb, (g[f"chosen_d{depth}"] < 0).astype(np.int8))
+
+
+def test_greedy_depth3(golden_dir):
+    """depth 3: device code == the oracle's literal restatement of greedy_policy.py:160-208, every position,
+    with and without history; and == the reference's depth-3 decisions on the sampled positions."""
+    d3 = np.load(os.path.join(golden_dir, "greedy_depth3.npz"))
+    rng = np.random.default_rng(3)
+    for tag, name in (("full", "greedy.npz"), ("restricted", "greedy_restricted.npz")):
+        g = np.load(os.path.join(golden_dir, name))
+        sq, tm, m = (np.ascontiguousarray(g[k]) for k in ("squares", "to_move", "mask"))
+        hist = rng.integers(-1, 54, size=(len(sq), 2, 3)).astype(np.int8)
+        for h in (None, hist):
+            e = emu.greedy(sq, tm, mask=m, hist=h, depth=3)
+            o = oracle.batch_greedy(sq, tm, mask=m, hist=h, depth=3)
+            assert all(np.array_equal(a, b) for a, b in zip(e, o))
+        idx = d3[f"index_{tag}"]
+        act, cm, _ = emu.greedy(sq, tm, mask=m, depth=3)
+        assert np.array_equal(act[idx], d3[f"chosen_d3_{tag}"].astype(np.int32))
+        assert np.array_equal(cm[idx], d3[f"cands_d3_{tag}"])

@@ -233,6 +233,32 @@ def test_greedy_restricted_masks(G, golden_dir):
         assert np.array_equal(npy(fb), (g[f"chosen_d{depth}"] < 0).astype(np.int8))
 
 
+def test_greedy_depth3(G, golden_dir):
+    """depth 3 (greedy_policy.py:160-208): gbl_greedy == the reference's own depth-3 decisions on the
+    sampled positions and == the oracle's literal restatement on all of them."""
+    from gobblet_rl_amd import _native as nat
+    d3 = np.load(os.path.join(golden_dir, "greedy_depth3.npz"))
+    for tag, name in (("full", "greedy.npz"), ("restricted", "greedy_restricted.npz")):
+        g = np.load(os.path.join(golden_dir, name))
+        n = len(g["squares"])
+        st, who, m = t(g["squares"]), t(g["to_move"]), t(g["mask"])
+        act = torch.empty(n, dtype=torch.int32, device=DEV); cm = torch.empty((n, 54), dtype=torch.int8, device=DEV)
+        fb = torch.empty(n, dtype=torch.int8, device=DEV)
+        nat.check(nat.lib().gbl_greedy(st.data_ptr(), who.data_ptr(), m.data_ptr(), None, 3, act.data_ptr(),
+                                       cm.data_ptr(), fb.data_ptr(), n, None))
+        torch.cuda.synchronize()
+        idx = d3[f"index_{tag}"]
+        assert np.array_equal(npy(act)[idx], d3[f"chosen_d3_{tag}"].astype(np.int32))
+        assert np.array_equal(npy(cm)[idx], d3[f"cands_d3_{tag}"])
+        o = oracle.batch_greedy(np.ascontiguousarray(g["squares"]), np.ascontiguousarray(g["to_move"]),
+                                mask=np.ascontiguousarray(g["mask"]), depth=3)
+        assert np.array_equal(npy(act), o[0]) and np.array_equal(npy(cm), o[1]) and np.array_equal(npy(fb), o[2])
+    pol = G.GreedyGobbletPolicy(depth=3, device=DEV)
+    g = np.load(os.path.join(golden_dir, "greedy.npz"))
+    a = pol.compute_actions(g["obs"], g["mask"])  # host class, depth=3: no fallback in this set (empty history)
+    assert np.array_equal(npy(a), g["chosen_d2"].astype(np.int32)) and not npy(pol.last_fallback).any()
+
+
 def test_greedy_vs_oracle_selfplay(G):
     from gobblet_rl_amd import _native as nat
     state, tm, dn = selfplay(3000, 26, seed=8)
@@ -560,3 +586,21 @@ def test_c_abi_without_python(G, tmp_path):
     out = subprocess.run([exe, "50000", "30"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "misaligned pointer refused" in out.stdout
+
+
+def test_example_scripts_run(G):
+    """examples/ run as a user would run them (child processes): the reference's example_basic loop over
+    the AEC surface, and the batched throughput loop with both policies."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = [["examples/example_basic.py", "--seed", "3", "--render_mode", "text"],
+            ["examples/example_batched.py", "--boards", "65536", "--plies", "40", "--policy", "random"],
+            ["examples/example_batched.py", "--boards", "4096", "--plies", "12", "--policy", "greedy"]]
+    for cmd in runs:
+        r = subprocess.run([sys.executable] + cmd, cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        if "basic" in cmd[0]:
+            assert r.stdout.count("Reward:") == 2 and "Reward: 1" in r.stdout and "Reward: -1" in r.stdout
+        else:
+            assert "env-steps/s" in r.stdout and "games finished" in r.stdout

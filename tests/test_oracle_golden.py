@@ -260,6 +260,23 @@ def test_greedy_restricted_masks(golden_dir, depth):
     assert np.array_equal(fb, (g[f"chosen_d{depth}"] < 0).astype(np.int8))
 
 
+def test_greedy_depth3(golden_dir):
+    """depth=3 of the reference (greedy_policy.py:160-208, restated literally in the oracle) on a sample
+    of both greedy fixtures: the reference's own depth-3 decisions, which equal its depth-2 ones."""
+    d3 = np.load(os.path.join(golden_dir, "greedy_depth3.npz"))
+    for tag, name in (("full", "greedy.npz"), ("restricted", "greedy_restricted.npz")):
+        g = np.load(os.path.join(golden_dir, name))
+        idx = d3[f"index_{tag}"]
+        assert len(idx) >= 100
+        act, cm, fb = oracle.batch_greedy(np.ascontiguousarray(g["squares"][idx]), np.ascontiguousarray(g["to_move"][idx]),
+                                          mask=np.ascontiguousarray(g["mask"][idx]), depth=3)
+        assert np.array_equal(act, d3[f"chosen_d3_{tag}"].astype(np.int32))
+        assert np.array_equal(cm, d3[f"cands_d3_{tag}"])
+        assert np.array_equal(fb, (d3[f"chosen_d3_{tag}"] < 0).astype(np.int8))
+        assert np.array_equal(d3[f"chosen_d3_{tag}"], g["chosen_d2"][idx])  # the block has no observable effect
+        assert np.array_equal(d3[f"cands_d3_{tag}"], g["cands_d2"][idx])
+
+
 def test_turn_counter(games):
     """raw_env.turn (gobblet.py:270,289): +1 whenever raw step runs, illegal no-ops included."""
     g = games
