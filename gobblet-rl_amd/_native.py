@@ -9,6 +9,7 @@ the ABI as plain pointers.
 from __future__ import annotations
 
 import ctypes as C
+import fcntl
 import os
 import shutil
 import subprocess
@@ -70,10 +71,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise GobbletHipError("hipcc not found: cannot build csrc/libgobblet_hip.so (there is no CPU fallback)")
-    cmd = [hipcc, *HIPCC_FLAGS, "-o", LIB_PATH, SOURCES[0]]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+    # one builder at a time (ranks of a multi-process launch may all arrive here); the library appears
+    # under its final name only when complete
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or needs_build():
+                tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+                cmd = [hipcc, *HIPCC_FLAGS, "-o", tmp, SOURCES[0]]
+                if verbose:
+                    print(" ".join(cmd[:-3] + ["-o", LIB_PATH, SOURCES[0]]))
+                try:
+                    subprocess.check_call(cmd, cwd=CSRC)
+                    os.replace(tmp, LIB_PATH)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

@@ -9,6 +9,7 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 from __future__ import annotations
 
 import ctypes as C
+import fcntl
 import os
 import subprocess
 
@@ -24,8 +25,13 @@ ILLEGAL_NOOP, ILLEGAL_TERMINATE = 0, 1
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (seconds). Returns the .so path."""
     src = os.path.join(_HERE, "gobblet_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libgobblet_oracle.so"])
+    with open(_LIB_PATH + ".lock", "w") as lock:  # ranks of a multi-process test may arrive together
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+                subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libgobblet_oracle.so"])
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB_PATH
 
 

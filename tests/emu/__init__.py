@@ -1,5 +1,6 @@
 """Host emulation of the device header (TEST INFRASTRUCTURE, see emu_device.cpp)."""
 import ctypes as C
+import fcntl
 import os
 import subprocess
 
@@ -12,9 +13,14 @@ _SRCS = [os.path.join(_HERE, "emu_device.cpp"),
 
 
 def build():
-    if not os.path.exists(_LIB) or any(os.path.getmtime(_LIB) < os.path.getmtime(s) for s in _SRCS):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unknown-pragmas", "-fPIC", "-shared",
-                               "-o", _LIB, _SRCS[0]])
+    with open(_LIB + ".lock", "w") as lock:  # pytest-xdist workers may arrive together
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(_LIB) or any(os.path.getmtime(_LIB) < os.path.getmtime(s) for s in _SRCS):
+                subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unknown-pragmas", "-fPIC", "-shared",
+                                       "-o", _LIB, _SRCS[0]])
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB
 
 
