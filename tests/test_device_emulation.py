@@ -108,6 +108,8 @@ def test_sampler_and_decode():
     m = oracle.batch_legal_mask(state, tm)
     m[::97] = 0  # empty masks -> -1
     assert np.array_equal(emu.sample(m, 9, 12345678901234, 7), oracle.batch_sample(m, 9, 12345678901234, 7))
+    for base in (0, (1 << 32) - 30, (5 << 32) - 700):  # board ids below, across and above 2^32 (derived key)
+        assert np.array_equal(emu.sample(m, 2**63 + 11, base, 4000000000), oracle.batch_sample(m, 2**63 + 11, base, 4000000000))
     obs = oracle.batch_observe(state, tm, -1)
     st, who = emu.decode_obs(obs)
     assert np.array_equal(st, state) and np.array_equal(who, tm)

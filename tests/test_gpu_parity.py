@@ -181,6 +181,14 @@ def test_sampler_and_rollout_vs_oracle(G):
         env.step(a)
         oracle.batch_step(s, tm, dn, exp_a, auto_reset=True)
         assert np.array_equal(npy(env.squares), s)
+    # board ids across the 2^32 boundary inside one wavefront (boards beyond it draw under a derived key)
+    from gobblet_rl_amd import _native as nat
+    m = oracle.batch_legal_mask(s, tm)
+    md, act = t(m), torch.empty(n, dtype=torch.int32, device=DEV)
+    for b0 in ((1 << 32) - 30, (3 << 32) - 2000):
+        nat.check(nat.lib().gbl_sample(md.data_ptr(), act.data_ptr(), n, 2**63 + 11, b0, 4000000000, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(npy(act), oracle.batch_sample(m, 2**63 + 11, b0, 4000000000))
     # fused rollout continues the same stream (ply index carries on)
     for plies in (1, plies):
         o = oracle.batch_rollout(s, tm, dn, seed, base, env.ply, plies, threads=8)
