@@ -146,13 +146,16 @@ __device__ __forceinline__ void tile_out(int8_t *__restrict__ g, const uint32_t 
     if (rows == kTile) {
         uint4 *gv = reinterpret_cast<uint4 *>(g);
         const uint4 *lv = reinterpret_cast<const uint4 *>(lds);
-        uint4 v[FULL ? FULL : 1], rem = {0u, 0u, 0u, 0u};  // rem apart from v[]: a conditionally written
-#pragma unroll                                            // array element sent the array to scratch
+        // (with cached stores and a 117-byte row the compiler keeps v[] in 144 B of scratch; the
+        // observation stream is always stored non-temporally, where it does not -- measured 0.3 %
+        // faster than forms that avoid the scratch in the unused variant)
+        uint4 v[FULL + 1];
+#pragma unroll
         for (int i = 0; i < FULL; ++i) v[i] = lv[lane + 64 * i];
-        if (REM && lane < REM) rem = lv[lane + 64 * FULL];
+        if (REM && lane < REM) v[FULL] = lv[lane + 64 * FULL];
 #pragma unroll
         for (int i = 0; i < FULL; ++i) store16<NT>(&gv[lane + 64 * i], v[i]);
-        if (REM && lane < REM) store16<NT>(&gv[lane + 64 * FULL], rem);
+        if (REM && lane < REM) store16<NT>(&gv[lane + 64 * FULL], v[FULL]);
     } else {
         int bytes = rows * ROWB;
         const int8_t *lb = reinterpret_cast<const int8_t *>(lds);

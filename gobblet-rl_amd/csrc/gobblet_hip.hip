@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void k_observe(const int8_t *__restrict__ state
     wave_lds_fence();
     obs_scatter(s_obs, L.lane, make_planes(r), who != 0);
     wave_lds_fence();
-    tile_out<kObs>(obs + L.tile * (kTile * kObs), s_obs, L.lane, L.rows);
+    tile_out<kObs, true>(obs + L.tile * (kTile * kObs), s_obs, L.lane, L.rows);
 }
 
 // Rows of a tile -> HBM through ONE LDS image that is reused: first the 117-byte observation rows,
