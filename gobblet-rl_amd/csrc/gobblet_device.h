@@ -673,83 +673,150 @@ __device__ __forceinline__ void outcomes54(const Planes &p, int mover, uint64_t 
 
 __device__ __forceinline__ uint64_t below_eq(int b) { return (2ull << b) - 1ull; }  // bits 0..b, b < 63
 
-// One decision for the agent `me` on board p.  `mask` is the legal mask handed to the policy
-// (greedy_policy.py:76), prev3 the agent's last three actions packed one per byte (0xFF = none).
-// The reference's control flow -- the depth-1 loop (:84-101), the depth-2 loop with its
+// One decision for the agent `me` on board p, in four per-board pieces so that a kernel can spread
+// the expensive one (greedy_reply) over the lanes of a wavefront.  `mask` is the legal mask handed to
+// the policy (greedy_policy.py:76), prev3 the agent's last three actions packed one per byte (0xFF =
+// none).  The reference's control flow -- the depth-1 loop (:84-101), the depth-2 loop with its
 // order-dependent pruning (:103-157), the fallback test (:211-214) -- is replayed in order over
-// outcome bit-sets, so that no per-leaf loop remains: per depth-1 candidate one moved(),
-// one legal54() and one outcomes54() give every opponent reply's result.
-__device__ __forceinline__ GreedyResult greedy_decide(const Planes &p, int me, uint64_t mask, int depth, uint32_t prev3)
+// outcome bit-sets, so that no per-leaf loop remains: per depth-1 candidate one moved(), one
+// legal54() and one outcomes54() give every opponent reply's result.
+struct GreedyHead {
+    uint64_t cands;     // actions_depth1 as a 54-bit set, :77-79
+    uint64_t todo;      // depth-1 results with value 0, in insertion (= ascending) order: the depth-2 loop's list
+    uint64_t legal_me;  // board.is_legal(agent_index, a) on the root position, :85 and :141
+    int ncands, chosen;
+};
+
+// depth 1, :84-101
+__device__ __forceinline__ GreedyHead greedy_head(const Planes &p, int me, uint64_t mask, int depth)
 {
-    const int opp = 1 - me;
-    uint64_t cands = mask;  // actions_depth1, :77-79
-    int ncands = __popcll(mask);
-    int chosen = -1;
-    uint64_t legal_me = legal54(p, me);  // board.is_legal(agent_index, a), :85 and :141
-    uint64_t tried = mask & legal_me;    // actions the depth-1 loop evaluates, ascending
+    GreedyHead h;
+    h.cands = mask;
+    h.ncands = __popcll(mask);
+    h.chosen = -1;
+    h.legal_me = legal54(p, me);
+    uint64_t tried = mask & h.legal_me;  // actions the depth-1 loop evaluates, ascending
     uint64_t win1, lose1;
     outcomes54(p, me, win1, lose1);
     win1 &= tried;
     lose1 &= tried;
-    // depth 1, :84-101: walk the decisive results in order; everything before the stop is in `results`
+    // walk the decisive results in order; everything before the stop is in `results`
     uint64_t seen = tried;
     for (uint64_t ev = win1 | lose1; ev;) {
         int a = __builtin_ctzll(ev);
         ev &= ev - 1;
         if ((win1 >> a) & 1ull) {  // :92-94
-            chosen = a;
+            h.chosen = a;
             seen = tried & below_eq(a);
             break;
         }
-        if (ncands > 1) {          // :95-99
-            cands &= ~(1ull << a);
-            --ncands;
+        if (h.ncands > 1) {        // :95-99
+            h.cands &= ~(1ull << a);
+            --h.ncands;
         } else {                   // :100-101
             seen = tried & below_eq(a);
             break;
         }
     }
-    if (depth > 1) {  // :103-157; depth 3 adds :160-208, whose only assignment repeats :157 -- no effect
-        for (uint64_t it = seen & ~win1 & ~lose1; it;) {  // results with value 0, insertion order
-            int a = __builtin_ctzll(it);
-            it &= it - 1;
-            Planes d1 = moved(p, me, (uint32_t)a);  // :107-109
-            uint64_t legal2 = legal54(d1, opp);     // :112-116
-            uint64_t ow, mw;                        // opponent wins / we win after reply a2, :120-126
-            outcomes54(d1, opp, ow, mw);
-            ow &= legal2;
-            mw &= legal2;
-            uint64_t evald = legal2;                // replies that got a result before any break
-            if (ow) {                               // :129-143
-                int f = __builtin_ctzll(ow);
-                uint64_t rest = ow & (ow - 1);
-                if (ncands > 1) {
-                    if ((cands >> a) & 1ull) {
-                        cands &= ~(1ull << a);
-                        --ncands;
-                    }
-                    if (ncands > 1 || !rest) {      // no break: every opponent win is looked at
-                        uint64_t block = ow & legal_me;
-                        if (chosen < 0 && block) chosen = __builtin_ctzll(block);
-                    } else {                        // break at the second opponent win
-                        if (chosen < 0 && ((legal_me >> f) & 1ull)) chosen = f;
-                        evald = legal2 & below_eq(__builtin_ctzll(rest));
-                    }
-                } else {                            // break at the first opponent win
-                    evald = legal2 & below_eq(f);
-                }
-            }
-            if ((evald & ~mw) == 0) {  // all(... == our win), :146-151
-                chosen = a;
-                break;
-            }
-            if ((evald & ow) == 0) chosen = a;  // all(... != their win), :153-157
+    // :103; depth 3 adds :160-208, whose only assignment repeats :157 -- no effect
+    h.todo = depth > 1 ? (seen & ~win1 & ~lose1) : 0ull;
+    return h;
+}
+
+// What the depth-2 loop needs to know about candidate `a` (:107-126), packed in 16 bits:
+//   bit 0      the opponent has a winning reply            (ow != 0)
+//   bits 1-6   the first winning reply f
+//   bit 7      there is a second one
+//   bit 8      some winning reply is a legal move of ours on the root position (:141)
+//   bits 9-14  the first such reply
+//   bit 15     every reply wins the game for us            (all(), :146-149; implies bit 0 clear)
+__device__ __forceinline__ uint32_t greedy_reply(const Planes &p, int me, uint64_t legal_me, uint32_t a)
+{
+    const int opp = 1 - me;
+    Planes d1 = moved(p, me, a);         // :107-109
+    uint64_t legal2 = legal54(d1, opp);  // :112-116
+    uint64_t ow, mw;                     // the opponent wins / we win after reply a2, :120-126
+    outcomes54(d1, opp, ow, mw);
+    ow &= legal2;
+    mw &= legal2;
+    uint64_t block = ow & legal_me;
+    uint32_t s = ow ? 1u : 0u;
+    s |= (ow ? (uint32_t)__builtin_ctzll(ow) : 0u) << 1;
+    s |= (ow & (ow - 1)) ? 1u << 7 : 0u;
+    s |= block ? 1u << 8 : 0u;
+    s |= (block ? (uint32_t)__builtin_ctzll(block) : 0u) << 9;
+    s |= (legal2 & ~mw) == 0 ? 1u << 15 : 0u;
+    return s;
+}
+
+// :129-143 for a candidate a whose summary s has bit 0 set.  none_yet: `chosen_action is None` (:142) can
+// still hold as far as the candidates WITHOUT a winning reply are concerned (h.chosen tracks the rest).
+__device__ __forceinline__ void greedy_threat(GreedyHead &h, int a, uint32_t s, bool none_yet)
+{
+    int f = (int)((s >> 1) & 63u);
+    if (h.ncands > 1) {
+        if ((h.cands >> a) & 1ull) {
+            h.cands &= ~(1ull << a);
+            --h.ncands;
         }
+        if (h.ncands > 1 || !(s & (1u << 7))) {  // no break: every opponent win is looked at
+            if (none_yet && h.chosen < 0 && (s & (1u << 8))) h.chosen = (int)((s >> 9) & 63u);
+        } else {                                  // break at the second opponent win
+            if (none_yet && h.chosen < 0 && ((h.legal_me >> f) & 1ull)) h.chosen = f;
+        }
+    }                                             // else: break at the first opponent win
+}
+
+// One iteration of the depth-2 loop (:129-157) for candidate a with summary s; true = `break` (:151).
+// With a winning reply f among the evaluated replies neither all() can hold (f is evaluated in
+// every early-break variant), so only the no-winning-reply case reaches :146-157.
+__device__ __forceinline__ bool greedy_replay(GreedyHead &h, int a, uint32_t s)
+{
+    if (s & 1u) {
+        greedy_threat(h, a, s, true);
+        return false;
     }
-    bool fb = chosen < 0;  // :211-214
-    fb = fb || (chosen >= 0 && ((prev3 & 0xFFu) == (uint32_t)chosen || ((prev3 >> 8) & 0xFFu) == (uint32_t)chosen ||
-                                ((prev3 >> 16) & 0xFFu) == (uint32_t)chosen));
-    return GreedyResult{chosen, cands, fb};
+    h.chosen = a;              // all(... != their win), :153-157 -- or all(... == our win), :146-151
+    return (s >> 15) & 1u;
+}
+
+// The whole depth-2 loop from two candidate sets -- threat: summaries with bit 0, allwin: with bit 15 --
+// looking up summaries only for the (few) candidates in `threat`.  A candidate without a winning reply
+// assigns chosen_action unconditionally (:157, :150), so the last of them before the :151 break is
+// the result if there is one, and from the first of them on `chosen_action is None` (:142) is false.
+template <typename ReplyOf>
+__device__ __forceinline__ void greedy_replay_sets(GreedyHead &h, uint64_t threat, uint64_t allwin, ReplyOf reply_of)
+{
+    uint64_t todo = h.todo;
+    allwin &= todo;
+    if (allwin) todo &= below_eq(__builtin_ctzll(allwin));  // :151: nothing after the break is looked at
+    const uint64_t calm = todo & ~threat;
+    const uint64_t before_calm = calm ? (1ull << __builtin_ctzll(calm)) - 1ull : ~0ull;
+    for (uint64_t it = threat & todo; it; it &= it - 1) {
+        const int a = __builtin_ctzll(it);
+        greedy_threat(h, a, reply_of(a), (before_calm >> a) & 1ull);
+    }
+    if (calm) h.chosen = 63 - __builtin_clzll(calm);
+}
+
+// :211-214
+__device__ __forceinline__ GreedyResult greedy_finish(const GreedyHead &h, uint32_t prev3)
+{
+    uint32_t c = (uint32_t)h.chosen;
+    bool fb = h.chosen < 0 || (prev3 & 0xFFu) == c || ((prev3 >> 8) & 0xFFu) == c || ((prev3 >> 16) & 0xFFu) == c;
+    return GreedyResult{h.chosen, h.cands, fb};
+}
+
+// the four pieces in sequence on one board
+__device__ __forceinline__ GreedyResult greedy_decide(const Planes &p, int me, uint64_t mask, int depth, uint32_t prev3)
+{
+    GreedyHead h = greedy_head(p, me, mask, depth);
+    for (uint64_t it = h.todo; it;) {
+        int a = __builtin_ctzll(it);
+        it &= it - 1;
+        if (greedy_replay(h, a, greedy_reply(p, me, h.legal_me, (uint32_t)a))) break;
+    }
+    return greedy_finish(h, prev3);
 }
 
 }  // namespace gbl

@@ -106,10 +106,12 @@ def rollout(state, to_move, done, seed, env_base, ply0, plies, illegal_mode=0):
     return {"actions": a, "winner": w, "reward": rw, "mask": mask, "obs": obs, "counters": cnt}
 
 
-def greedy(state, to_move, mask=None, hist=None, depth=2):
+def greedy(state, to_move, mask=None, hist=None, depth=2, pooled=True):
+    """pooled=True: the kernel's flow (pairs pooled over a tile + greedy_replay_sets); False: greedy_decide."""
     n = len(state)
     act = np.full(n, 77, np.int32); cm = np.full((n, 54), 77, np.int8); fb = np.full(n, 77, np.int8)
-    lib().emu_greedy(_p(state), _p(to_move), _p(mask), _p(hist), C.c_int(depth), _p(act), _p(cm), _p(fb), C.c_int64(n))
+    lib().emu_greedy(_p(state), _p(to_move), _p(mask), _p(hist), C.c_int(depth), _p(act), _p(cm), _p(fb), C.c_int64(n),
+                     C.c_int(int(pooled)))
     return act, cm, fb
 
 

@@ -347,11 +347,18 @@ void emu_decode_obs(const int8_t *obs, int8_t *state, int8_t *to_move, int64_t n
     });
 }
 
+// pooled != 0: the kernel's flow (candidate lists of a tile back to back, every pair evaluated by
+// "lane" g % 64, threat / allwin sets, greedy_replay_sets); pooled == 0: greedy_decide per board.
 void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_in, const int8_t *hist, int depth,
-                int32_t *action_out, int8_t *cand_out, int8_t *fallback_out, int64_t n)
+                int32_t *action_out, int8_t *cand_out, int8_t *fallback_out, int64_t n, int pooled)
 {
     for_tiles(n, [&](TileCtx t) {
         uint32_t r[64][7], dc[64][14];
+        Planes P[64];
+        int ME[64];
+        uint32_t PREV[64];
+        uint64_t MASK[64];
+        GreedyHead H[64];
         load_rows(state, t, r);
         Image<kActions> im;
         if (mask_in) in_all<kActions>(mask_in + t.tile * (kTile * kActions), im.p(), t.rows);
@@ -373,7 +380,36 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
                 const int8_t *h = hist + (b * 2 + me) * 3;
                 prev3 = (uint32_t)(uint8_t)h[0] | ((uint32_t)(uint8_t)h[1] << 8) | ((uint32_t)(uint8_t)h[2] << 16);
             }
-            GreedyResult g = greedy_decide(p, me, mask, depth, prev3);
+            P[l] = p;
+            ME[l] = me;
+            PREV[l] = prev3;
+            MASK[l] = mask;
+            H[l] = greedy_head(p, me, mask, depth);
+        }
+        static uint16_t pair[64 * kActions], reply[64][kActions];
+        uint64_t threat[64] = {0}, allwin[64] = {0};
+        int total = 0;
+        for (int l = 0; l < 64; ++l)
+            for (uint64_t it = H[l].todo; it; it &= it - 1) pair[total++] = (uint16_t)((l << 8) | __builtin_ctzll(it));
+        for (int g = 0; pooled && g < total; ++g) {
+            uint32_t o = pair[g] >> 8, a = pair[g] & 0xFFu;
+            uint32_t sum = greedy_reply(P[o], ME[o], H[o].legal_me, a);
+            if (sum & 1u) {
+                reply[o][a] = (uint16_t)sum;
+                threat[o] |= 1ull << a;
+            }
+            if (sum >> 15) allwin[o] |= 1ull << a;
+        }
+        for (int l = 0; l < 64; ++l) {
+            bool valid = l < t.rows;
+            int64_t b = t.tile * 64 + l;
+            GreedyResult g;
+            if (pooled) {
+                greedy_replay_sets(H[l], threat[l], allwin[l], [&](int a) { return (uint32_t)reply[l][a]; });
+                g = greedy_finish(H[l], PREV[l]);
+            } else {
+                g = greedy_decide(P[l], ME[l], MASK[l], depth, PREV[l]);
+            }
             mask_row(g.cands, dc[l]);
             if (valid) {
                 action_out[b] = g.fallback ? -1 : g.chosen;

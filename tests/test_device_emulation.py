@@ -166,6 +166,10 @@ def test_greedy_vs_oracle_selfplay(boards):
     o = oracle.batch_greedy(state, tm, mask=m, depth=2)
     for x, y in zip(e, o):
         assert np.array_equal(x, y)
+    # the per-board composition (greedy_decide) next to the kernel's pooled one (greedy_replay_sets)
+    for kw in ({"hist": hist}, {"mask": m}):
+        for x, y in zip(emu.greedy(state, tm, depth=2, pooled=False, **kw), oracle.batch_greedy(state, tm, depth=2, **kw)):
+            assert np.array_equal(x, y)
 
 
 def test_c1_thousand_reference_games(golden_dir):
@@ -190,10 +194,11 @@ def test_validate_flags(boards):
 
 
 @pytest.mark.parametrize("depth", [1, 2])
-def test_greedy_restricted_masks(golden_dir, depth):
+@pytest.mark.parametrize("pooled", [True, False])
+def test_greedy_restricted_masks(golden_dir, depth, pooled):
     g = np.load(os.path.join(golden_dir, "greedy_restricted.npz"))
     act, cm, fb = emu.greedy(np.ascontiguousarray(g["squares"]), np.ascontiguousarray(g["to_move"]),
-                             mask=np.ascontiguousarray(g["mask"]), depth=depth)
+                             mask=np.ascontiguousarray(g["mask"]), depth=depth, pooled=pooled)
     assert np.array_equal(act, g[f"chosen_d{depth}"].astype(np.int32))
     assert np.array_equal(cm, g[f"cands_d{depth}"])
     assert np.array_equal(fb, (g[f"chosen_d{depth}"] < 0).astype(np.int8))
