@@ -437,15 +437,29 @@ __global__ __launch_bounds__(64) void k_validate(const int8_t *__restrict__ stat
 
 // gbl_greedy: one decision per board.  Each lane owns a board (depth-1 walk, order-dependent replay,
 // fallback test), but the depth-2 evaluations -- one moved + legal54 + outcomes54 per (board,
-// candidate) pair, ~95 % of the work -- are pooled over the wavefront: the boards' candidate lists
-// are laid back to back in LDS and lane l evaluates pairs l, l+64, ... whoever owns them, so a
+// candidate) pair, ~95 % of the work -- are pooled over the tile: the boards' candidate lists are
+// laid back to back in LDS and lane l evaluates pairs l, l+64, ... whoever owns them, so a
 // wavefront runs ceil(total / 64) evaluations instead of as many as its busiest board has candidates
 // (~50 against a mean of ~33 on the masked-random mix).
-__global__ __launch_bounds__(64) void k_greedy(const int8_t *__restrict__ state, const int8_t *__restrict__ to_move,
-                                               const int8_t *__restrict__ mask_in, const int8_t *__restrict__ hist,
-                                               int depth, int32_t *__restrict__ action_out,
-                                               int8_t *__restrict__ cand_out, int8_t *__restrict__ fallback_out,
-                                               int64_t n, int64_t ntiles)
+// W wavefronts per workgroup share one tile: wavefront 0 owns the boards (loads, depth-1 walk, replay,
+// outputs), all W evaluate pairs, so a tile's serial chain shrinks and every SIMD holds wavefronts in
+// different phases.  W = 1 needs no barrier (depth 1 has no pairs and uses it).
+template <int W>
+__device__ __forceinline__ void pool_fence()
+{
+    if (W > 1)
+        __syncthreads();
+    else
+        wave_lds_fence();
+}
+
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ state,
+                                                   const int8_t *__restrict__ to_move,
+                                                   const int8_t *__restrict__ mask_in,
+                                                   const int8_t *__restrict__ hist, int depth,
+                                                   int32_t *__restrict__ action_out, int8_t *__restrict__ cand_out,
+                                                   int8_t *__restrict__ fallback_out, int64_t n, int64_t ntiles)
 {
     __shared__ uint32_t s_state[image_words<kCells>()];
     __shared__ uint32_t s_mask[image_words<kActions>()];
@@ -455,51 +469,67 @@ __global__ __launch_bounds__(64) void k_greedy(const int8_t *__restrict__ state,
     __shared__ uint16_t s_reply[kTile][kActions];   // greedy_reply() of (board, candidate), where bit 0 is set
     __shared__ unsigned long long s_threat[kTile];  // candidates whose summary has bit 0 / bit 15
     __shared__ unsigned long long s_allwin[kTile];
+    __shared__ int s_total;
     Lane L;
-    if (!lane_setup(L, n, ntiles)) return;
-    uint32_t r[7];
-    load_state(state, s_state, L, r);
-    Planes p = make_planes(r);
-    int me = L.valid ? (to_move[L.b] != 0) : 0;
-    uint64_t mask;
-    if (mask_in) {
-        tile_in<kActions>(mask_in + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
-        wave_lds_fence();
-        uint32_t d[14];
-        row_load<kActions>(s_mask, L.lane, d);
-        mask = mask_bits(d);
-        wave_lds_fence();
-    } else {
-        mask = legal54(p, me);
+    if (!lane_setup(L, n, ntiles)) return;  // the same for every thread of the workgroup
+    const int slot = L.lane;                // 0 .. 64 W - 1
+    const bool owner = slot < kTile;
+    if (W > 1) {
+        L.lane = slot & (kTile - 1);
+        L.valid = L.lane < L.rows;
+        L.b = L.tile * kTile + L.lane;
     }
-    if (!L.valid) mask = 0;
+    GreedyHead h{0ull, 0ull, 0ull, 0, -1};
     uint32_t prev3 = 0x00FFFFFFu;
-    if (hist && L.valid) {
-        const int8_t *h = hist + (L.b * 2 + me) * 3;
-        prev3 = (uint32_t)(uint8_t)h[0] | ((uint32_t)(uint8_t)h[1] << 8) | ((uint32_t)(uint8_t)h[2] << 16);
-    }
-    GreedyHead h = greedy_head(p, me, mask, depth);  // invalid lanes: empty mask, nothing to do
-    if (depth > 1) {
-        s_board[L.lane][0] = p.nz;
-        s_board[L.lane][1] = p.neg;
-        s_board[L.lane][2] = p.odd;
-        s_board[L.lane][3] = (uint32_t)me;
-        s_legal[L.lane] = h.legal_me;
-        s_threat[L.lane] = 0ull;
-        s_allwin[L.lane] = 0ull;
-        const int mine = __popcll(h.todo);
-        int upto = mine;  // inclusive prefix sum of the list lengths over the wavefront
-#pragma unroll
-        for (int d = 1; d < kTile; d <<= 1) {
-            int v = __shfl_up(upto, d);
-            upto += L.lane >= d ? v : 0;
+    int total = 0;
+    if (owner) {
+        uint32_t r[7];
+        load_state(state, s_state, L, r);
+        Planes p = make_planes(r);
+        int me = L.valid ? (to_move[L.b] != 0) : 0;
+        uint64_t mask;
+        if (mask_in) {
+            tile_in<kActions>(mask_in + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
+            wave_lds_fence();
+            uint32_t d[14];
+            row_load<kActions>(s_mask, L.lane, d);
+            mask = mask_bits(d);
+            wave_lds_fence();
+        } else {
+            mask = legal54(p, me);
         }
-        const int total = __shfl(upto, kTile - 1);
-        int k = upto - mine;
-        for (uint64_t it = h.todo; it; it &= it - 1)
-            s_pair[k++] = (uint16_t)((L.lane << 8) | __builtin_ctzll(it));
-        wave_lds_fence();
-        for (int g = L.lane; g < total; g += kTile) {
+        if (!L.valid) mask = 0;
+        if (hist && L.valid) {
+            const int8_t *hp = hist + (L.b * 2 + me) * 3;
+            prev3 = (uint32_t)(uint8_t)hp[0] | ((uint32_t)(uint8_t)hp[1] << 8) | ((uint32_t)(uint8_t)hp[2] << 16);
+        }
+        h = greedy_head(p, me, mask, depth);  // invalid lanes: empty mask, nothing to do
+        if (depth > 1) {
+            s_board[L.lane][0] = p.nz;
+            s_board[L.lane][1] = p.neg;
+            s_board[L.lane][2] = p.odd;
+            s_board[L.lane][3] = (uint32_t)me;
+            s_legal[L.lane] = h.legal_me;
+            s_threat[L.lane] = 0ull;
+            s_allwin[L.lane] = 0ull;
+            const int mine = __popcll(h.todo);
+            int upto = mine;  // inclusive prefix sum of the list lengths over the wavefront
+#pragma unroll
+            for (int d = 1; d < kTile; d <<= 1) {
+                int v = __shfl_up(upto, d);
+                upto += L.lane >= d ? v : 0;
+            }
+            total = __shfl(upto, kTile - 1);
+            if (W > 1 && L.lane == kTile - 1) s_total = total;
+            int k = upto - mine;
+            for (uint64_t it = h.todo; it; it &= it - 1)
+                s_pair[k++] = (uint16_t)((L.lane << 8) | __builtin_ctzll(it));
+        }
+    }
+    if (depth > 1) {
+        pool_fence<W>();
+        if (W > 1) total = s_total;
+        for (int g = slot; g < total; g += kTile * W) {
             const uint32_t pair = s_pair[g], o = pair >> 8, a = pair & 0xFFu;
             const Planes q{s_board[o][0], s_board[o][1], s_board[o][2]};
             const uint32_t sum = greedy_reply(q, (int)s_board[o][3], s_legal[o], a);
@@ -509,10 +539,11 @@ __global__ __launch_bounds__(64) void k_greedy(const int8_t *__restrict__ state,
             }
             if (sum >> 15) atomicOr(&s_allwin[o], 1ull << a);
         }
-        wave_lds_fence();
-        // :103-157 in order, on the owner's lane
-        greedy_replay_sets(h, s_threat[L.lane], s_allwin[L.lane], [&](int a) { return (uint32_t)s_reply[L.lane][a]; });
+        pool_fence<W>();
     }
+    if (!owner) return;
+    if (depth > 1)  // :103-157 in order, on the owner's lane
+        greedy_replay_sets(h, s_threat[L.lane], s_allwin[L.lane], [&](int a) { return (uint32_t)s_reply[L.lane][a]; });
     GreedyResult g = greedy_finish(h, prev3);
     if (cand_out) {
         uint32_t d[14];
@@ -771,8 +802,20 @@ int gbl_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask, c
     if (depth < 1 || depth > 3) return fail(GBL_ERR_ARG, "depth must be 1, 2 or 3");
     GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask, "mask"); GBL_ALIGNED(cand_mask_out, "cand_mask_out");
     Geometry g = geometry(n);
-    hipLaunchKernelGGL(k_greedy, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, state, to_move, mask, hist, depth,
-                       action_out, cand_mask_out, fallback_out, n, g.ntiles);
+    // Wavefronts per tile.  Measured on depth 2 (scripts/bench_greedy.py, 65 536 / 262 144 / 2^20 boards):
+    // 1: 49 / 155 / 518 us, 2: 43 / 139 / 487, 4: 41 / 121 / 451, 8: 40 / 136 / 520, 16: 50 / 176 / 679.
+    static const int forced = [] {
+        const char *e = getenv("GBL_GREEDY_WAVES");  // 1, 2 or 4: A/B runs
+        return e ? atoi(e) : 0;
+    }();
+    const int waves = forced ? forced : depth == 1 ? 1 : 4;
+#define GBL_GREEDY(W)                                                                                             \
+    hipLaunchKernelGGL(k_greedy<W>, dim3(g.grid), dim3(64 * W), 0, (hipStream_t)stream, state, to_move, mask, hist, \
+                       depth, action_out, cand_mask_out, fallback_out, n, g.ntiles)
+    if (waves >= 4) GBL_GREEDY(4);
+    else if (waves == 2) GBL_GREEDY(2);
+    else GBL_GREEDY(1);
+#undef GBL_GREEDY
     GBL_LAUNCHED("gbl_greedy");
 }
 
