@@ -615,6 +615,11 @@ struct GreedyResult {
 // (or nothing is missing), and stays complete for the other side iff it was complete and q is not
 // on it.  The reference lets the LAST matching line decide, so lines are resolved from index 7 down,
 // each destination taking the first verdict it meets.
+//
+// QUIET: the caller guarantees that neither side holds a complete line on p (check_for_winner() == 0).
+// A lift never adds a top piece of the mover, so no line can then be complete for the mover before the
+// drop, and the "nothing missing" term is dropped.
+template <bool QUIET = false>
 __device__ __forceinline__ void outcomes54(const Planes &p, int mover, uint64_t &win, uint64_t &lose)
 {
     uint32_t mine = mover ? (p.nz & p.neg) : (p.nz & ~p.neg);
@@ -652,8 +657,11 @@ __device__ __forceinline__ void outcomes54(const Planes &p, int mover, uint64_t 
             uint32_t miss = Lr & nTm;                         // squares of line l the mover lacks
             uint32_t multi = miss & ((miss | G3) - LOW3);     // != 0 in a field: two or more missing
             uint32_t mg = (multi + F3) & G3, mm = mg - (mg >> 9);
-            uint32_t zg = G3 & ~(miss + F3), zm = zg - (zg >> 9);  // fields with nothing missing
-            uint32_t need = (miss & ~mm) | zm;                // destinations that complete line l
+            uint32_t need = miss & ~mm;                       // destinations that complete line l
+            if (!QUIET) {
+                uint32_t zg = G3 & ~(miss + F3);              // fields with nothing missing: every destination
+                need |= zg - (zg >> 9);
+            }
             uint32_t kg = G3 & ~((Lr & nTo) + F3);            // fields where the other side holds line l
             uint32_t keep = (kg - (kg >> 9)) & ~Lr;           // ... and keeps it: destinations off the line
             uint32_t wv = need & open;
@@ -736,7 +744,7 @@ __device__ __forceinline__ uint32_t greedy_reply(const Planes &p, int me, uint64
     Planes d1 = moved(p, me, a);         // :107-109
     uint64_t legal2 = legal54(d1, opp);  // :112-116
     uint64_t ow, mw;                     // the opponent wins / we win after reply a2, :120-126
-    outcomes54(d1, opp, ow, mw);
+    outcomes54<true>(d1, opp, ow, mw);   // a is a depth-1 result with value 0: nobody holds a line on d1
     ow &= legal2;
     mw &= legal2;
     uint64_t block = ow & legal_me;
