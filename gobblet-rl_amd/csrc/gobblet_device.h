@@ -619,9 +619,14 @@ struct GreedyResult {
 // QUIET: the caller guarantees that neither side holds a complete line on p (check_for_winner() == 0).
 // A lift never adds a top piece of the mover, so no line can then be complete for the mover before the
 // drop, and the "nothing missing" term is dropped.
-template <bool QUIET = false>
+//
+// WINS_ONLY (with QUIET): the caller also guarantees that no lift can complete a line for the other side
+// (see reply_is_plain); then `lose` is 0, every completed line is the mover's, and the order of the
+// lines does not matter.
+template <bool QUIET = false, bool WINS_ONLY = false>
 __device__ __forceinline__ void outcomes54(const Planes &p, int mover, uint64_t &win, uint64_t &lose)
 {
+    static_assert(QUIET || !WINS_ONLY, "WINS_ONLY needs QUIET");
     uint32_t mine = mover ? (p.nz & p.neg) : (p.nz & ~p.neg);
     uint32_t othr = mover ? (p.nz & ~p.neg) : (p.nz & p.neg);
     uint32_t m0 = mine & 0x1FFu, m1 = (mine >> 9) & 0x1FFu, m2 = (mine >> 18) & 0x1FFu;
@@ -651,6 +656,16 @@ __device__ __forceinline__ void outcomes54(const Planes &p, int mover, uint64_t 
         }
         uint32_t nTm = ~(TmR & ~lost), nTo = ~(ToR | gain);  // complements of the tops after the lift
         uint32_t W = 0, Z = 0, open = F3;
+        if (WINS_ONLY) {
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                const uint32_t Lr = L[l] | (L[l] << 10) | (L[l] << 20);
+                uint32_t miss = Lr & nTm;
+                uint32_t multi = miss & ((miss | G3) - LOW3);
+                uint32_t mg = (multi + F3) & G3, mm = mg - (mg >> 9);
+                W |= miss & ~mm;
+            }
+        } else {
 #pragma unroll
         for (int l = 7; l >= 0; --l) {
             const uint32_t Lr = L[l] | (L[l] << 10) | (L[l] << 20);
@@ -670,6 +685,7 @@ __device__ __forceinline__ void outcomes54(const Planes &p, int mover, uint64_t 
             uint32_t xv = keep & open;
             Z |= xv;
             open &= ~xv;
+        }
         }
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
@@ -738,13 +754,46 @@ __device__ __forceinline__ GreedyHead greedy_head(const Planes &p, int me, uint6
 //   bit 8      some winning reply is a legal move of ours on the root position (:141)
 //   bits 9-14  the first such reply
 //   bit 15     every reply wins the game for us            (all(), :146-149; implies bit 0 clear)
+// On a position where nobody holds a line: can a lift by `mover` hand the other side one?  Only by
+// exposing a piece of theirs (a square where the mover's piece lies directly on one) that is the third
+// square of a line they otherwise hold.  False here = outcomes54 may run WINS_ONLY.  (Conservative:
+// pieces the mover cannot lift count too.)
+__device__ __forceinline__ bool reply_is_plain(const Planes &p, int mover)
+{
+    uint32_t mine = mover ? (p.nz & p.neg) : (p.nz & ~p.neg);
+    uint32_t othr = mover ? (p.nz & ~p.neg) : (p.nz & p.neg);
+    uint32_t m1 = (mine >> 9) & 0x1FFu, m2 = (mine >> 18) & 0x1FFu;
+    uint32_t t0 = othr & 0x1FFu, t1 = (othr >> 9) & 0x1FFu, t2 = (othr >> 18) & 0x1FFu;
+    uint32_t o1 = m1 | t1, o2 = m2 | t2;
+    uint32_t To = t2 | (~o2 & (t1 | (~o1 & t0)));          // the other side's tops
+    uint32_t X = (m1 & t0) | (m2 & (t1 | (~o1 & t0)));     // theirs directly below a piece of the mover
+    uint32_t have = To | X;
+    uint32_t nh = ~(have | (have << 10) | (have << 20));
+    constexpr uint32_t LOW3 = 0x00100401u, G3 = LOW3 << 9, F3 = LOW3 * 0x1FFu;
+    constexpr uint32_t LA = 0x007u | (0x038u << 10) | (0x1C0u << 20), LB = 0x049u | (0x092u << 10) | (0x124u << 20);
+    constexpr uint32_t LC = 0x111u | (0x054u << 10) | (0x1FFu << 20);  // third field: a "line" nobody can hold
+    // guard bit of a field stays clear iff none of the line's squares is missing from `have`
+    uint32_t full = (G3 & ~((LA & nh) + F3)) | (G3 & ~((LB & nh) + F3)) | (G3 & ~(((LC & nh) | (1u << 20)) + F3));
+    return full == 0;
+}
+
+// EXACT = false: the cheap evaluation when reply_is_plain() allows it, else kGreedyDefer (the caller
+// evaluates the pair again with EXACT = true).
+constexpr uint32_t kGreedyDefer = 0xFFFFFFFFu;
+
+template <bool EXACT = true>
 __device__ __forceinline__ uint32_t greedy_reply(const Planes &p, int me, uint64_t legal_me, uint32_t a)
 {
     const int opp = 1 - me;
     Planes d1 = moved(p, me, a);         // :107-109
+    if (!EXACT && !reply_is_plain(d1, opp)) return kGreedyDefer;
     uint64_t legal2 = legal54(d1, opp);  // :112-116
     uint64_t ow, mw;                     // the opponent wins / we win after reply a2, :120-126
-    outcomes54<true>(d1, opp, ow, mw);   // a is a depth-1 result with value 0: nobody holds a line on d1
+    // a is a depth-1 result with value 0: nobody holds a line on d1
+    if (EXACT)
+        outcomes54<true, false>(d1, opp, ow, mw);
+    else
+        outcomes54<true, true>(d1, opp, ow, mw);
     ow &= legal2;
     mw &= legal2;
     uint64_t block = ow & legal_me;

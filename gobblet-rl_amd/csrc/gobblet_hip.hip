@@ -469,7 +469,8 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
     __shared__ uint16_t s_reply[kTile][kActions];   // greedy_reply() of (board, candidate), where bit 0 is set
     __shared__ unsigned long long s_threat[kTile];  // candidates whose summary has bit 0 / bit 15
     __shared__ unsigned long long s_allwin[kTile];
-    __shared__ int s_total;
+    __shared__ int s_total, s_deferred;
+    __shared__ uint16_t s_again[kTile * kActions];  // pairs that need the exact evaluation (greedy_reply<true>)
     Lane L;
     if (!lane_setup(L, n, ntiles)) return;  // the same for every thread of the workgroup
     const int slot = L.lane;                // 0 .. 64 W - 1
@@ -520,7 +521,10 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
                 upto += L.lane >= d ? v : 0;
             }
             total = __shfl(upto, kTile - 1);
-            if (W > 1 && L.lane == kTile - 1) s_total = total;
+            if (L.lane == kTile - 1) {
+                s_total = total;
+                s_deferred = 0;
+            }
             int k = upto - mine;
             for (uint64_t it = h.todo; it; it &= it - 1)
                 s_pair[k++] = (uint16_t)((L.lane << 8) | __builtin_ctzll(it));
@@ -529,15 +533,29 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
     if (depth > 1) {
         pool_fence<W>();
         if (W > 1) total = s_total;
-        for (int g = slot; g < total; g += kTile * W) {
-            const uint32_t pair = s_pair[g], o = pair >> 8, a = pair & 0xFFu;
-            const Planes q{s_board[o][0], s_board[o][1], s_board[o][2]};
-            const uint32_t sum = greedy_reply(q, (int)s_board[o][3], s_legal[o], a);
+        auto record = [&](uint32_t o, uint32_t a, uint32_t sum) {
             if (sum & 1u) {
                 s_reply[o][a] = (uint16_t)sum;
                 atomicOr(&s_threat[o], 1ull << a);
             }
             if (sum >> 15) atomicOr(&s_allwin[o], 1ull << a);
+        };
+        // first round: the cheap evaluation; the few pairs where a lift could hand us a line are set aside
+        for (int g = slot; g < total; g += kTile * W) {
+            const uint32_t pair = s_pair[g], o = pair >> 8, a = pair & 0xFFu;
+            const Planes q{s_board[o][0], s_board[o][1], s_board[o][2]};
+            const uint32_t sum = greedy_reply<false>(q, (int)s_board[o][3], s_legal[o], a);
+            if (sum == kGreedyDefer)
+                s_again[atomicAdd(&s_deferred, 1)] = (uint16_t)pair;
+            else
+                record(o, a, sum);
+        }
+        pool_fence<W>();
+        const int again = s_deferred;
+        for (int g = slot; g < again; g += kTile * W) {
+            const uint32_t pair = s_again[g], o = pair >> 8, a = pair & 0xFFu;
+            const Planes q{s_board[o][0], s_board[o][1], s_board[o][2]};
+            record(o, a, greedy_reply<true>(q, (int)s_board[o][3], s_legal[o], a));
         }
         pool_fence<W>();
     }

@@ -118,3 +118,9 @@ def greedy(state, to_move, mask=None, hist=None, depth=2, pooled=True):
 def validate(state):
     n = len(state); out = np.full(n, 77, np.int8)
     lib().emu_validate(_p(state), _p(out), C.c_int64(n)); return out
+
+
+def greedy_stats():
+    """(pairs evaluated, pairs deferred to the exact evaluation, cheap != exact) since the library was loaded."""
+    o = np.zeros(3, np.int64)
+    lib().emu_greedy_stats(_p(o)); return tuple(int(x) for x in o)

@@ -347,6 +347,16 @@ void emu_decode_obs(const int8_t *obs, int8_t *state, int8_t *to_move, int64_t n
     });
 }
 
+// statistics of the pooled flow: pairs evaluated, pairs deferred to the exact evaluation, and pairs whose
+// cheap evaluation differs from the exact one (a bug if ever non-zero)
+static int64_t g_pairs = 0, g_deferred = 0, g_fast_mismatch = 0;
+void emu_greedy_stats(int64_t *out)
+{
+    out[0] = g_pairs;
+    out[1] = g_deferred;
+    out[2] = g_fast_mismatch;
+}
+
 // pooled != 0: the kernel's flow (candidate lists of a tile back to back, every pair evaluated by
 // "lane" g % 64, threat / allwin sets, greedy_replay_sets); pooled == 0: greedy_decide per board.
 void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_in, const int8_t *hist, int depth,
@@ -391,14 +401,30 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
         int total = 0;
         for (int l = 0; l < 64; ++l)
             for (uint64_t it = H[l].todo; it; it &= it - 1) pair[total++] = (uint16_t)((l << 8) | __builtin_ctzll(it));
-        for (int g = 0; pooled && g < total; ++g) {
-            uint32_t o = pair[g] >> 8, a = pair[g] & 0xFFu;
-            uint32_t sum = greedy_reply(P[o], ME[o], H[o].legal_me, a);
+        static uint16_t again[64 * kActions];
+        int deferred = 0;
+        auto record = [&](uint32_t o, uint32_t a, uint32_t sum) {
             if (sum & 1u) {
                 reply[o][a] = (uint16_t)sum;
                 threat[o] |= 1ull << a;
             }
             if (sum >> 15) allwin[o] |= 1ull << a;
+        };
+        for (int g = 0; pooled && g < total; ++g) {
+            uint32_t o = pair[g] >> 8, a = pair[g] & 0xFFu;
+            uint32_t sum = greedy_reply<false>(P[o], ME[o], H[o].legal_me, a);
+            g_pairs++;
+            if (sum == kGreedyDefer) {
+                again[deferred++] = pair[g];
+                g_deferred++;
+            } else {
+                record(o, a, sum);
+                if (sum != greedy_reply<true>(P[o], ME[o], H[o].legal_me, a)) g_fast_mismatch++;  // must stay 0
+            }
+        }
+        for (int g = 0; g < deferred; ++g) {
+            uint32_t o = again[g] >> 8, a = again[g] & 0xFFu;
+            record(o, a, greedy_reply<true>(P[o], ME[o], H[o].legal_me, a));
         }
         for (int l = 0; l < 64; ++l) {
             bool valid = l < t.rows;
