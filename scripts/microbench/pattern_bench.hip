@@ -17,6 +17,7 @@ struct Args {
     int8_t *state, *mask, *obs, *to_move, *done, *winner, *reward;
     int32_t *action;
     int64_t ntiles;
+    int64_t obs_stride, state_stride;  // bytes per tile: 7488 / 1728 as in the product, or padded to 128-byte lines
 };
 
 template <int ROWB, bool NT>
@@ -43,7 +44,7 @@ template <bool SCALARS, bool NT, bool OBS, bool MASK, bool STATE_RW>
 __device__ __forceinline__ void do_tile(const Args &a, int64_t tile, int lane, uint32_t *img)
 {
     if (STATE_RW) {
-        const v4u *gv = reinterpret_cast<const v4u *>(a.state + tile * 1728);
+        const v4u *gv = reinterpret_cast<const v4u *>(a.state + tile * a.state_stride);
         v4u *lv = reinterpret_cast<v4u *>(img);
         v4u x0 = gv[lane], x1 = {0, 0, 0, 0};
         if (lane < 44) x1 = gv[lane + 64];
@@ -55,9 +56,9 @@ __device__ __forceinline__ void do_tile(const Args &a, int64_t tile, int lane, u
         img[lane] = t + 1;  // keep a data dependency load -> stores
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (OBS) tile_out<117, NT>(a.obs + tile * 7488, img, lane);
+    if (OBS) tile_out<117, NT>(a.obs + tile * a.obs_stride, img, lane);
     if (MASK) tile_out<54, NT>(a.mask + tile * 3456, img, lane);
-    if (STATE_RW) tile_out<27, false>(a.state + tile * 1728, img, lane);
+    if (STATE_RW) tile_out<27, false>(a.state + tile * a.state_stride, img, lane);
     if (SCALARS) {
         int64_t b = tile * 64 + lane;
         uint32_t t = img[lane];
@@ -108,10 +109,11 @@ int main(int argc, char **argv)
     for (int64_t boards : {(int64_t)1 << 20, (int64_t)1 << 22}) {
         Args a;
         a.ntiles = boards / 64;
-        CK(hipMalloc(&a.state, boards * 27)); CK(hipMalloc(&a.mask, boards * 54)); CK(hipMalloc(&a.obs, boards * 117));
+        a.obs_stride = 7488; a.state_stride = 1728;
+        CK(hipMalloc(&a.state, boards * 28)); CK(hipMalloc(&a.mask, boards * 54)); CK(hipMalloc(&a.obs, boards * 118));
         CK(hipMalloc(&a.to_move, boards)); CK(hipMalloc(&a.done, boards)); CK(hipMalloc(&a.winner, boards));
         CK(hipMalloc(&a.reward, boards * 2)); CK(hipMalloc(&a.action, boards * 4));
-        CK(hipMemset(a.state, 0, boards * 27));
+        CK(hipMemset(a.state, 0, boards * 28));
         const double FULL = 27 + 27 + 54 + 117 + 1 + 1 + 1 + 2 + 4, NOSC = 27 + 27 + 54 + 117;
         //   WAVES XCD  SCAL  NT    OBS   MASK  ST    TPW
         run<1, true, true, true, true, true, true, 1>("V0 full pattern (as k_rollout), NT", a, boards, FULL);
@@ -125,6 +127,12 @@ int main(int argc, char **argv)
         run<1, true, false, true, true, false, false, 1>("V4 obs only (pure 117 B/board write), NT", a, boards, 117);
         run<1, true, false, false, true, false, false, 1>("V4b obs only, plain stores", a, boards, 117);
         run<1, true, false, true, true, true, false, 1>("V7 obs+mask write only, NT", a, boards, 171);
+        // what would 128-byte aligned tiles be worth?  (hypothetical layout: the product's rows are unpadded)
+        a.obs_stride = 7552; a.state_stride = 1792;
+        run<1, true, true, true, true, true, true, 1>("V8 full pattern, tiles padded to 128 B lines", a, boards, FULL);
+        run<1, true, false, true, true, false, false, 1>("V8b obs only, tiles padded to 128 B lines", a, boards, 117);
+        a.obs_stride = 7488; a.state_stride = 1728;
+        run<1, true, true, true, true, true, true, 1>("V0 again", a, boards, FULL);
         CK(hipFree(a.state)); CK(hipFree(a.mask)); CK(hipFree(a.obs)); CK(hipFree(a.to_move)); CK(hipFree(a.done));
         CK(hipFree(a.winner)); CK(hipFree(a.reward)); CK(hipFree(a.action));
         printf("\n");
