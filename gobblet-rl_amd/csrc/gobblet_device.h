@@ -261,14 +261,19 @@ __device__ __forceinline__ int winner_of(const Planes &p)
     uint32_t o1 = (p.nz >> 9) & 0x1FFu, o2 = (p.nz >> 18) & 0x1FFu;
     uint32_t t1 = ((pos >> 18) & 0x1FFu) | (~o2 & (((pos >> 9) & 0x1FFu) | (~o1 & (pos & 0x1FFu))));
     uint32_t t2 = ((ngv >> 18) & 0x1FFu) | (~o2 & (((ngv >> 9) & 0x1FFu) | (~o1 & (ngv & 0x1FFu))));
-    // board.py:135-153: (0,1,2) (3,4,5) (6,7,8) (0,3,6) (1,4,7) (2,5,8) (0,4,8) (2,4,6)
+    // board.py:135-153: (0,1,2) (3,4,5) (6,7,8) (0,3,6) (1,4,7) (2,5,8) (0,4,8) (2,4,6).
+    // Three lines per word in 10-bit fields (bit 9 = guard): adding 0x1FF to "squares of the line the
+    // side lacks" carries into the guard iff something is missing.  Lines (0,3,6) / (1,4,7) / (2,5) share
+    // a word so that shifting the guards by 9 / 8 / 7 lays the eight match bits out in line order.
     constexpr uint32_t L[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x111u, 0x054u};
-    uint32_t m1 = 0, m2 = 0;
-#pragma unroll
-    for (int l = 0; l < 8; ++l) {
-        m1 |= ((t1 & L[l]) == L[l]) ? (1u << l) : 0u;
-        m2 |= ((t2 & L[l]) == L[l]) ? (1u << l) : 0u;
-    }
+    constexpr uint32_t LOW3 = 0x00100401u, G3 = LOW3 << 9, F3 = LOW3 * 0x1FFu;
+    constexpr uint32_t WA = L[0] | (L[3] << 10) | (L[6] << 20), WB = L[1] | (L[4] << 10) | (L[7] << 20);
+    constexpr uint32_t WC = L[2] | (L[5] << 10), NONE = 1u << 20;  // third field of WC: always "missing"
+    uint32_t n1 = ~(t1 | (t1 << 10) | (t1 << 20)), n2 = ~(t2 | (t2 << 10) | (t2 << 20));
+    uint32_t m1 = ((G3 & ~((WA & n1) + F3)) >> 9) | ((G3 & ~((WB & n1) + F3)) >> 8) |
+                  ((G3 & ~(((WC & n1) | NONE) + F3)) >> 7);
+    uint32_t m2 = ((G3 & ~((WA & n2) + F3)) >> 9) | ((G3 & ~((WB & n2) + F3)) >> 8) |
+                  ((G3 & ~(((WC & n2) | NONE) + F3)) >> 7);
     return m2 > m1 ? -1 : (m1 > m2 ? 1 : 0);
 }
 

@@ -221,3 +221,22 @@ def test_greedy_depth3(golden_dir):
         act, cm, _ = emu.greedy(sq, tm, mask=m, depth=3)
         assert np.array_equal(act[idx], d3[f"chosen_d3_{tag}"].astype(np.int32))
         assert np.array_equal(cm[idx], d3[f"cands_d3_{tag}"])
+
+
+def test_winner_exhaustive_tops():
+    """check_for_winner over every pattern of tops (3^9, at each level) and 100k random stacks: the device
+    code finds the highest-index complete line with packed arithmetic, the oracle walks the 8 lines."""
+    import itertools
+    cfg = np.array(list(itertools.product((0, 1, -1), repeat=9)), np.int8)
+    for lvl in range(3):
+        st = np.zeros((len(cfg), 27), np.int8)
+        st[:, 9 * lvl:9 * lvl + 9] = cfg * (2 * lvl + 1)
+        assert np.array_equal(emu.winner(np.ascontiguousarray(st)), oracle.batch_winner(st)), lvl
+    rng = np.random.default_rng(1)
+    st = np.zeros((100000, 27), np.int8)
+    for lvl, vals in enumerate(((1, 2), (3, 4), (5, 6))):
+        occ = rng.random((len(st), 9)) < 0.45
+        v = rng.choice(vals, size=(len(st), 9)) * rng.choice((1, -1), size=(len(st), 9))
+        st[:, 9 * lvl:9 * lvl + 9] = np.where(occ, v, 0)
+    w = oracle.batch_winner(st)
+    assert np.array_equal(emu.winner(st), w) and len(np.unique(w)) == 3
