@@ -298,10 +298,15 @@ __device__ __forceinline__ uint64_t legal54(const Planes &p, int mover)
     return ((uint64_t)hi << 32) | lo;
 }
 
-// Board.play_turn(mover, a), board.py:118-132, given that `a` is legal:
-// clear the cell holding the piece (if placed), write it at 9*level + pos.
-// Updates the planes and the 7 state dwords.
-__device__ __forceinline__ void apply_move(Planes &p, uint32_t (&r)[7], int mover, uint32_t a)
+// Board.play_turn(mover, a), board.py:118-132, given that `a` is legal: clear the cell holding the
+// piece (if placed), write it at 9*level + pos.  The planes are updated here; the two cells of the
+// 27-byte row that change are returned for whoever holds the row.
+struct MoveCells {
+    uint32_t cold, cnew, val;  // cell to clear (only if `had`), cell to write, signed piece number as a byte
+    bool had;                  // the piece was on the board already
+};
+
+__device__ __forceinline__ MoveCells move_planes(Planes &p, int mover, uint32_t a)
 {
     uint32_t pi = (a * 57u) >> 9;  // a / 9 for a < 54
     uint32_t q = a - 9u * pi;
@@ -313,18 +318,54 @@ __device__ __forceinline__ void apply_move(Planes &p, uint32_t (&r)[7], int move
     p.nz = (p.nz & ~ploc) | bit;
     p.neg = (p.neg & ~ploc & ~bit) | (mover ? bit : 0u);
     p.odd = (p.odd & ~ploc & ~bit) | (first ? bit : 0u);
-    uint32_t cold = ploc ? (uint32_t)__builtin_ctz(ploc) : 63u * 4u;
-    uint32_t val = (mover ? (0u - (pi + 1u)) : (pi + 1u)) & 0xFFu;
-    uint32_t mold = ~(0xFFu << (8u * (cold & 3u)));
-    uint32_t mnew = ~(0xFFu << (8u * (cnew & 3u)));
-    uint32_t vnew = val << (8u * (cnew & 3u));
+    MoveCells m;
+    m.had = ploc != 0;
+    m.cold = m.had ? (uint32_t)__builtin_ctz(ploc) : 0u;
+    m.cnew = cnew;
+    m.val = (mover ? (0u - (pi + 1u)) : (pi + 1u)) & 0xFFu;
+    return m;
+}
+
+// The row in 7 registers (board-level kernels: the row is re-staged into a fresh image anyway).
+struct RegRow {
+    uint32_t (&r)[7];
+    __device__ __forceinline__ void apply(const MoveCells &m)
+    {
+        uint32_t cold = m.had ? m.cold : 63u * 4u;
+        uint32_t mold = ~(0xFFu << (8u * (cold & 3u)));
+        uint32_t mnew = ~(0xFFu << (8u * (m.cnew & 3u)));
+        uint32_t vnew = m.val << (8u * (m.cnew & 3u));
 #pragma unroll
-    for (uint32_t j = 0; j < 7; ++j) {
-        uint32_t x = r[j];
-        x = (j == (cold >> 2)) ? (x & mold) : x;
-        x = (j == (cnew >> 2)) ? ((x & mnew) | vnew) : x;
-        r[j] = x;
+        for (uint32_t j = 0; j < 7; ++j) {
+            uint32_t x = r[j];
+            x = (j == (cold >> 2)) ? (x & mold) : x;
+            x = (j == (m.cnew >> 2)) ? ((x & mnew) | vnew) : x;
+            r[j] = x;
+        }
     }
+    __device__ __forceinline__ void reset()
+    {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) r[j] = 0;
+    }
+};
+
+// The row where the tile load put it, in the LDS image (step kernels: the image goes back out as it
+// is, so a move costs two byte stores and a reset one 27-byte clear instead of rebuilding and
+// re-staging 7 dwords).  Rows are 27 bytes apart: the clear relies on unaligned LDS stores (gfx950).
+struct ImageRow {
+    uint8_t *row;
+    __device__ __forceinline__ void apply(const MoveCells &m)
+    {
+        if (m.had) row[m.cold] = 0;
+        row[m.cnew] = (uint8_t)m.val;
+    }
+    __device__ __forceinline__ void reset() { __builtin_memset(row, 0, kCells); }
+};
+
+__device__ __forceinline__ void apply_move(Planes &p, uint32_t (&r)[7], int mover, uint32_t a)
+{
+    RegRow{r}.apply(move_planes(p, mover, a));
 }
 
 // ---- row encoders ----------------------------------------------------------------------
@@ -487,8 +528,8 @@ struct Ply {
     bool stepped;   // raw_env.step ran, i.e. the reference did `self.turn += 1` (gobblet.py:270)
 };
 
-__device__ __forceinline__ Ply play_ply(Planes &p, uint32_t (&r)[7], int &mover, uint64_t legal, int action,
-                                        int illegal_mode)
+template <typename Row>
+__device__ __forceinline__ Ply play_ply(Planes &p, Row row, int &mover, uint64_t legal, int action, int illegal_mode)
 {
     Ply y{0, 0, 0, false, false};
     bool ok = (uint32_t)action < (uint32_t)kActions && ((legal >> (action & 63)) & 1ull);
@@ -500,7 +541,7 @@ __device__ __forceinline__ Ply play_ply(Planes &p, uint32_t (&r)[7], int &mover,
         return y;
     }
     y.stepped = true;
-    if (ok) apply_move(p, r, mover, (uint32_t)action);  // gobblet.py:244 (illegal: silent no-op, board.py:125-126)
+    if (ok) row.apply(move_planes(p, mover, (uint32_t)action));  // gobblet.py:244 (illegal: silent no-op, board.py:125-126)
     mover ^= 1;                                          // gobblet.py:246,267
     y.winner = winner_of(p);                             // gobblet.py:248-249
     y.r0 = y.winner;                                     // gobblet.py:253-260
@@ -510,22 +551,23 @@ __device__ __forceinline__ Ply play_ply(Planes &p, uint32_t (&r)[7], int &mover,
 }
 
 // Lane body of gbl_step: raw_env.step + the state the next observe() is taken from.
-// In: r / p (planes of r) / mover / was_done / action.  Out: r, p (after the step), mover, dn, y.
-__device__ __forceinline__ void step_lane(uint32_t (&r)[7], Planes &p, int &mover, int was_done, int action,
-                                          int illegal_mode, int auto_reset, int &dn, Ply &y)
+// In: row (RegRow / ImageRow) / p (its planes) / mover / was_done / action.  Out: row, p (after the
+// step), mover, dn, y.
+template <typename Row>
+__device__ __forceinline__ void step_lane(Row row, Planes &p, int &mover, int was_done, int action, int illegal_mode,
+                                          int auto_reset, int &dn, Ply &y)
 {
     y = Ply{0, 0, 0, false, false};
     dn = was_done;
     if (was_done) {
         y.winner = winner_of(p);  // frozen board (reference: _was_dead_step, gobblet.py:232-236): standing result
     } else {
-        y = play_ply(p, r, mover, legal54(p, mover), action, illegal_mode);
+        y = play_ply(p, row, mover, legal54(p, mover), action, illegal_mode);
         dn = y.terminal ? 1 : 0;
         if (y.terminal && auto_reset) {  // raw_env.reset, gobblet.py:275-290
             p = Planes{0u, 0u, 0u};
             mover = 0;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) r[j] = 0;
+            row.reset();
         }
     }
 }

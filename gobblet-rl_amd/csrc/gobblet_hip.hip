@@ -211,13 +211,14 @@ __global__ __launch_bounds__(64) void k_observe(const int8_t *__restrict__ state
     tile_out<kObs, true>(obs + L.tile * (kTile * kObs), s_obs, L.lane, L.rows);
 }
 
-// Rows of a tile -> HBM through ONE LDS image that is reused: first the 117-byte observation rows,
-// then (image free again -- the LDS reads of tile_out are issued before the next writes) the mask
-// rows and the state rows side by side.  7.5 KB of LDS per wave instead of 12.7 KB: more resident
-// waves per CU to cover the store latency.
-constexpr int kOutImageWords = image_words<kObs>() > image_words<kActions>() + image_words<kCells>()
-                                   ? image_words<kObs>()
-                                   : image_words<kActions>() + image_words<kCells>();
+// Rows of a tile -> HBM through ONE LDS image that is reused.  On entry it holds the tile's state rows
+// where the load put them, already patched by the plies (ImageRow): they go out as they are.  Then the
+// image is free (the LDS reads of tile_out are issued before the next writes) for the 117-byte
+// observation rows, and after those for the mask rows.  7.5 KB of LDS per wave instead of 12.7 KB: more
+// resident waves per CU to cover the store latency.
+constexpr int kOutImageWords = image_words<kObs>();
+static_assert(image_words<kObs>() >= image_words<kActions>() && image_words<kObs>() >= image_words<kCells>(),
+              "the observation image is the largest");
 
 // NT: which row streams are stored with the non-temporal hint -- bit 0 observation, bit 1 mask, bit 2
 // state.  Measured (profiles/r01): the write-once observation stream always gains from it; the mask
@@ -225,10 +226,13 @@ constexpr int kOutImageWords = image_words<kObs>() > image_words<kActions>() + i
 // (2^22 boards: 169 -> 141 us) and loses ~2 % below that; the state rows are re-read next ply and stay
 // cached.  The host picks the variant from the batch size (nt_policy()).
 template <bool WITH_MASK, bool WITH_OBS, int NT>
-__device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, const uint32_t (&r)[7], bool mask_zero,
-                                           const Planes &p, int observer, int8_t *__restrict__ state,
-                                           int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out)
+__device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, bool mask_zero, const Planes &p, int observer,
+                                           int8_t *__restrict__ state, int8_t *__restrict__ mask_out,
+                                           int8_t *__restrict__ obs_out)
 {
+    wave_lds_fence();  // every lane's byte patches are in the image
+    tile_out<kCells, (NT & 4) != 0>(state + L.tile * (kTile * kCells), img, L.lane, L.rows);
+    wave_lds_fence();
     if (WITH_OBS) {
         obs_image_zero(img, L.lane);
         wave_lds_fence();
@@ -237,19 +241,15 @@ __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, const u
         tile_out<kObs, (NT & 1) != 0>(obs_out + L.tile * (kTile * kObs), img, L.lane, L.rows);
         wave_lds_fence();
     }
-    uint32_t *img_mask = img, *img_state = img + image_words<kActions>();
-    row_stage<kCells>(img_state, L.lane, r);
     if (WITH_MASK) {
-        // the next mover's legal mask is computed only now, behind the observation stores: the sooner a
-        // wave's first stores are in flight, the shorter the launch's ramp-up
+        // the next mover's legal mask is computed only now, behind the state and observation stores: the
+        // sooner a wave's first stores are in flight, the shorter the launch's ramp-up
         uint32_t d[14];
         mask_row(mask_zero ? 0ull : legal54(p, observer), d);
-        row_stage<kActions>(img_mask, L.lane, d);
+        row_stage<kActions>(img, L.lane, d);
+        wave_lds_fence();
+        tile_out<kActions, (NT & 2) != 0>(mask_out + L.tile * (kTile * kActions), img, L.lane, L.rows);
     }
-    wave_lds_fence();
-    tile_out<kCells, (NT & 4) != 0>(state + L.tile * (kTile * kCells), img_state, L.lane, L.rows);
-    if (WITH_MASK)
-        tile_out<kActions, (NT & 2) != 0>(mask_out + L.tile * (kTile * kActions), img_mask, L.lane, L.rows);
 }
 
 // Diagnostic build only (-DGBL_STAMPS): per-wavefront s_memtime stamps of the fused kernel's phases,
@@ -302,10 +302,10 @@ __global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t 
     Planes p = make_planes(r);
     Ply y;
     int dn;
-    step_lane(r, p, mover, was_done, action, illegal_mode, auto_reset, dn, y);
-    wave_lds_fence();  // every lane holds its row: the image may be reused
+    step_lane(ImageRow{reinterpret_cast<uint8_t *>(s_img) + L.lane * kCells}, p, mover, was_done, action, illegal_mode,
+              auto_reset, dn, y);
     // gobblet.py:209: the mask belongs to the agent to move; a frozen board has nobody to move
-    store_rows<WITH_MASK, WITH_OBS, NT>(s_img, L, r, dn && !auto_reset, p, mover, state, mask_out, obs_out);
+    store_rows<WITH_MASK, WITH_OBS, NT>(s_img, L, dn && !auto_reset, p, mover, state, mask_out, obs_out);
     if (L.valid) {
         to_move[L.b] = (int8_t)mover;
         done[L.b] = (int8_t)dn;
@@ -341,6 +341,7 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
     mover = L.valid && mover != 0;
     GBL_STAMP_DEP(1, r[0] + (uint32_t)mover);
     Planes p = make_planes(r);
+    const ImageRow row{reinterpret_cast<uint8_t *>(s_img) + L.lane * kCells};  // the board's row, patched in place
     uint32_t games = 0, w1 = 0, w2 = 0;  // wave-uniform tallies (ballot + popcount)
     Ply y{0, 0, 0, false, false};
     int dn = 0, action = -1, tcount = 0;  // tcount: turn delta, or the absolute turn once a reset happened
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
     for (uint32_t t = 0; t < plies; ++t) {
         action = pick54(legal54(p, mover), draw);
         if (t + 1 < plies) draw = draw32(seed, env_base + (uint64_t)L.b, ply0 + t + 1);
-        step_lane(r, p, mover, 0, action, illegal_mode, 1, dn, y);
+        step_lane(row, p, mover, 0, action, illegal_mode, 1, dn, y);
         tcount = next_turn(tcount, y, 1);
         treset = treset || y.terminal;
         if (counters) {
@@ -358,8 +359,7 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
         }
     }
     GBL_STAMP_DEP(2, p.nz + (uint32_t)action);
-    wave_lds_fence();
-    store_rows<WITH_MASK, WITH_OBS, NT>(s_img, L, r, false, p, mover, state, mask_out, obs_out);
+    store_rows<WITH_MASK, WITH_OBS, NT>(s_img, L, false, p, mover, state, mask_out, obs_out);
     GBL_STAMP(3);
     if (L.valid) {
         to_move[L.b] = (int8_t)mover;

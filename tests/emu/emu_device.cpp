@@ -91,6 +91,19 @@ void load_rows(const int8_t *state, const TileCtx &t, uint32_t (*r)[7])
     }
 }
 
+// as the step kernels do: the tile's image stays, every lane reads its row from it (all lanes before
+// any lane patches its row -- the wave runs in lockstep), and is later stored as it is
+void load_rows_keep(const int8_t *state, const TileCtx &t, uint32_t (*r)[7], uint32_t *img)
+{
+    in_all<kCells>(state + t.tile * (kTile * kCells), img, t.rows);
+    for (int l = 0; l < 64; ++l) {
+        row_load<kCells>(img, l, r[l]);
+        r[l][6] &= 0x00FFFFFFu;
+        if (l >= t.rows)
+            for (int j = 0; j < 7; ++j) r[l][j] = 0;
+    }
+}
+
 template <typename F>
 void for_tiles(int64_t n, F f)
 {
@@ -223,7 +236,8 @@ void emu_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actio
         uint32_t r[64][7], dm[64][14];
         Planes pl[64];
         int who[64];
-        load_rows(state, t, r);
+        Image<kCells> is;
+        load_rows_keep(state, t, r, is.p());
         for (int l = 0; l < 64; ++l) {
             bool valid = l < t.rows;
             int64_t b = t.tile * 64 + l;
@@ -236,7 +250,8 @@ void emu_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actio
             Planes p = make_planes(r[l]);
             Ply y;
             int dn;
-            step_lane(r[l], p, mover, was_done, action, illegal_mode, auto_reset, dn, y);
+            step_lane(ImageRow{reinterpret_cast<uint8_t *>(is.p()) + l * kCells}, p, mover, was_done, action,
+                      illegal_mode, auto_reset, dn, y);
             mask_row(next_mask(p, mover, dn, auto_reset), dm[l]);
             pl[l] = p; who[l] = mover;
             if (valid) {
@@ -246,8 +261,6 @@ void emu_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actio
                 if (reward_out) { reward_out[2 * b] = (int8_t)y.r0; reward_out[2 * b + 1] = (int8_t)y.r1; }
             }
         }
-        Image<kCells> is;
-        stage_all<kCells, 7>(is.p(), r);
         out_all<kCells>(state + t.tile * (kTile * kCells), is.p(), t.rows);
         if (mask_out) {
             Image<kActions> im;
@@ -270,7 +283,8 @@ void emu_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_
         uint32_t r[64][7], dm[64][14];
         Planes pl[64];
         int who[64];
-        load_rows(state, t, r);
+        Image<kCells> is;
+        load_rows_keep(state, t, r, is.p());
         for (int l = 0; l < 64; ++l) {
             bool valid = l < t.rows;
             int64_t b = t.tile * 64 + l;
@@ -281,7 +295,8 @@ void emu_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_
             for (uint32_t k = 0; k < plies; ++k) {
                 uint64_t legal = legal54(p, mover);
                 action = sample54(legal, seed, env_base + (uint64_t)b, ply0 + k);
-                step_lane(r[l], p, mover, 0, action, illegal_mode, 1, dn, y);
+                step_lane(ImageRow{reinterpret_cast<uint8_t *>(is.p()) + l * kCells}, p, mover, 0, action, illegal_mode,
+                          1, dn, y);
                 if (valid && counters) {
                     counters[0] += 1;
                     counters[1] += y.terminal;
@@ -299,8 +314,6 @@ void emu_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_
                 if (reward_out) { reward_out[2 * b] = (int8_t)y.r0; reward_out[2 * b + 1] = (int8_t)y.r1; }
             }
         }
-        Image<kCells> is;
-        stage_all<kCells, 7>(is.p(), r);
         out_all<kCells>(state + t.tile * (kTile * kCells), is.p(), t.rows);
         if (mask_out) {
             Image<kActions> im;
