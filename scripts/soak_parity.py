@@ -74,6 +74,15 @@ while time.time() < t_end:
         og = oracle.batch_greedy(s[:m].copy(), tm[:m].copy(), hist=hist, depth=depth)
         assert np.array_equal(act.cpu().numpy(), og[0]) and np.array_equal(cm.cpu().numpy(), og[1])
         assert np.array_equal(fb.cpu().numpy(), og[2])
+    # greedy handed a random subset of the legal moves (guards and early breaks of the depth-1/2 loops)
+    sub = (oracle.batch_legal_mask(s[:m], tm[:m]) * (master.random((m, 54)) < master.choice([0.1, 0.5, 0.9]))).astype(np.int8)
+    sub = np.ascontiguousarray(sub)
+    nat.check(nat.lib().gbl_greedy(st.data_ptr(), who.data_ptr(), t(sub).data_ptr(), h.data_ptr(), 2, act.data_ptr(),
+                                   cm.data_ptr(), fb.data_ptr(), m, None))
+    torch.cuda.synchronize()
+    og = oracle.batch_greedy(s[:m].copy(), tm[:m].copy(), mask=sub, hist=hist, depth=2)
+    assert np.array_equal(act.cpu().numpy(), og[0]) and np.array_equal(cm.cpu().numpy(), og[1])
+    assert np.array_equal(fb.cpu().numpy(), og[2])
     rounds += 1
     boards_checked += n
     print(f"round {rounds}: n={n} illegal={illegal} auto_reset={auto} obs={with_obs} plies={k0}+3 OK", flush=True)
