@@ -12,6 +12,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from . import _native as nat
 from .board import BatchedBoard
 from .greedy_policy import GreedyGobbletPolicy  # noqa: F401  (gobblet_v1.py:2 re-exports it)
 
@@ -133,10 +134,18 @@ class Board:
     """One Gobblet board with the reference ``Board`` interface (board.py:4-242), evaluated on the GPU.
 
     ``squares`` is a host numpy float64[27] exactly like the reference's (callers read it, assign whole
-    arrays and single cells: greedy_policy.py:71, manual_policy.py:60,194-196); it is uploaded to the
-    1-board ``BatchedBoard`` backend before every query.  ``backend`` exists so that the host logic can be
-    tested without a GPU by injecting a stand-in; the default is the HIP engine and there is no fallback.
+    arrays and single cells: greedy_policy.py:71, manual_policy.py:60,194-196).  Whenever a query finds
+    that its content changed, the position is uploaded to the 1-board ``BatchedBoard`` backend and
+    EVERYTHING the reference derives from a position -- winner, flat board, covered cells, both agents'
+    legal masks and observations -- is computed by the board kernels back to back and fetched with one
+    device-to-host copy; later queries on the same position are answered from that.  ``play_turn`` runs
+    on the device and primes the same cache for the new position, so one ply of the AEC loop costs one
+    round trip.  ``backend`` exists so that the host logic can be tested without a GPU by injecting a
+    stand-in; the default is the HIP engine and there is no fallback.
     """
+
+    _PARTS = (("squares", 27), ("winner", 1), ("flat", 9), ("covered", 27), ("mask0", 54), ("mask1", 54),
+              ("obs0", 117), ("obs1", 117))
 
     def __init__(self, squares=None, device="cuda:0", backend=None):
         self.squares = np.zeros(27)           # board.py:33
@@ -144,15 +153,71 @@ class Board:
         if squares is not None:
             self.squares = np.array(squares, dtype=np.float64).reshape(27)
         self._backend = backend if backend is not None else BatchedBoard(1, device)
+        dev = getattr(self._backend, "device", "cpu")
+        self._agents = (torch.zeros(1, dtype=torch.int8, device=dev), torch.ones(1, dtype=torch.int8, device=dev))
+        self._key, self._cache = None, None
+        self._packed = None
+        if isinstance(self._backend, BatchedBoard):
+            # one device buffer for the position and everything derived from it (every part 16-byte aligned, as
+            # the C-ABI wants): the kernels write straight into it and it travels to the host in one copy
+            self._offsets, at = {}, 0
+            for name, size in self._PARTS:
+                self._offsets[name] = at
+                at += -(-size // 16) * 16
+            self._packed = torch.zeros(at, dtype=torch.int8, device=dev)
+            self._backend._squares = self._packed[:27].view(1, 27)
+            self._action = torch.zeros(1, dtype=torch.int32, device=dev)
         self.winning_combinations = self._backend.winning_combinations  # board.py:135-153
         self.calculate_winners = self._backend.calculate_winners
         self.setup = self._backend.setup
 
-    def _sync(self):
+    def _position(self):
         sq = np.asarray(self.squares)
         if sq.shape != (27,) or not np.all(sq == np.round(sq)) or np.abs(sq).max(initial=0) > 6:
             raise ValueError("Board.squares must be 27 integers in [-6, 6]")
-        self._backend.squares = torch.from_numpy(sq.astype(np.int8))[None]
+        return sq.astype(np.int8)
+
+    def _pull(self):
+        """All derived quantities of the backend's current position: 7 launches, one copy to the host."""
+        b = self._backend
+        if self._packed is not None:
+            L, st, sq, o = b._lib, b._stream(), self._packed.data_ptr(), self._offsets
+            at = {k: sq + v for k, v in o.items()}
+            a0, a1 = self._agents[0].data_ptr(), self._agents[1].data_ptr()
+            nat.check(L.gbl_winner(sq, at["winner"], 1, st), "gbl_winner")
+            nat.check(L.gbl_flatboard(sq, at["flat"], 1, st), "gbl_flatboard")
+            nat.check(L.gbl_covered(sq, at["covered"], 1, st), "gbl_covered")
+            nat.check(L.gbl_legal_mask(sq, a0, at["mask0"], 1, st), "gbl_legal_mask")
+            nat.check(L.gbl_legal_mask(sq, a1, at["mask1"], 1, st), "gbl_legal_mask")
+            nat.check(L.gbl_observe(sq, None, 0, at["obs0"], 1, st), "gbl_observe")
+            nat.check(L.gbl_observe(sq, None, 1, at["obs1"], 1, st), "gbl_observe")
+            host = self._packed.cpu().numpy()
+            out = {name: host[o[name]:o[name] + size] for name, size in self._PARTS}
+            self._key, self._cache = out["squares"].tobytes(), out
+            return out
+        parts = [b.squares, b.check_for_winner(), b.get_flatboard(), b.check_covered(), b.legal_mask(self._agents[0]),
+                 b.legal_mask(self._agents[1]), b.observation(self._agents[0]), b.observation(self._agents[1])]
+        host = torch.cat([x.reshape(-1).to(torch.int8) for x in parts]).cpu().numpy()
+        out, at = {}, 0
+        for name, size in self._PARTS:
+            out[name] = host[at:at + size]
+            at += size
+        self._key, self._cache = out["squares"].tobytes(), out
+        return out
+
+    def _evaluate(self):
+        sq = self._position()
+        if self._cache is None or sq.tobytes() != self._key:
+            if self._packed is not None:
+                self._packed[:27].copy_(torch.from_numpy(sq))
+            else:
+                self._backend.squares = torch.from_numpy(sq)[None]
+            self._pull()
+        return self._cache
+
+    def _sync(self):
+        """The backend holding this position (for callers that want the batched API itself)."""
+        self._evaluate()
         return self._backend
 
     # decoders, board.py:42-79
@@ -167,35 +232,44 @@ class Board:
         return 0 if agent_index == 0 else 1  # board.py:86: anything but 0 plays as player_2
 
     def is_legal(self, action, agent_index=0):  # board.py:82-115
-        return bool(self._sync().is_legal(int(action), self._agent(agent_index))[0])
+        action = int(action)
+        return 0 <= action < 54 and bool(self._evaluate()["mask%d" % self._agent(agent_index)][action])
 
     def play_turn(self, agent_index, action):  # board.py:118-132
         if agent_index not in (0, 1):
             raise ValueError("agent_index must be 0 or 1")
-        b = self._sync()
-        b.play_turn(int(agent_index), int(action))
-        self.squares = b.squares[0].cpu().numpy().astype(np.float64)
+        self._evaluate()  # the device holds this position
+        if self._packed is not None:
+            self._action.fill_(int(action) if 0 <= int(action) < 54 else -1)  # out of range = illegal = no-op
+            self._backend.play_turn(self._agents[int(agent_index)], self._action)
+        else:
+            self._backend.play_turn(self._agents[int(agent_index)], int(action))
+        self.squares = self._pull()["squares"].astype(np.float64)
 
-    def get_action(self, pos, piece_size, agent_index):  # board.py:50-60
-        return int(self._sync().get_action(int(pos), int(piece_size), self._agent(agent_index))[0])
+    def get_action(self, pos, piece_size, agent_index):  # board.py:50-60: the first legal of the size's two pieces
+        for piece in (2 * int(piece_size) - 2, 2 * int(piece_size) - 1):
+            action = int(pos) + 9 * piece
+            if self.is_legal(action, agent_index):
+                return action
+        return -1
 
     def get_flatboard(self):  # board.py:159-177
-        return self._sync().get_flatboard()[0].cpu().numpy().astype(np.float64)
+        return self._evaluate()["flat"].astype(np.float64)
 
     def check_for_winner(self):  # board.py:183-194
-        return int(self._sync().check_for_winner()[0])
+        return int(self._evaluate()["winner"][0])
 
     def check_game_over(self):  # board.py:196-201
         return self.check_for_winner() in (1, -1)
 
     def check_covered(self):  # board.py:203-220
-        return self._sync().check_covered()[0].cpu().numpy().astype(np.float64)
+        return self._evaluate()["covered"].astype(np.float64)
 
     def legal_moves(self, agent_index):
-        return np.flatnonzero(self._sync().legal_mask(self._agent(agent_index))[0].cpu().numpy()).tolist()
+        return np.flatnonzero(self._evaluate()["mask%d" % self._agent(agent_index)]).tolist()
 
     def observation(self, agent_index):
-        return self._sync().observation(int(self._agent(agent_index)))[0].cpu().numpy()
+        return self._evaluate()["obs%d" % self._agent(agent_index)].reshape(3, 3, 13).copy()
 
     def print(self):  # board.py:155-156
         print(self.get_flatboard().reshape(3, 3).transpose())
