@@ -406,15 +406,19 @@ __device__ __forceinline__ void obs_scatter(uint32_t *img, int lane, const Plane
     uint32_t pos = p.nz & ~p.neg, ngv = p.nz & p.neg;
     uint32_t own = observer ? ngv : pos, opp = observer ? pos : ngv;
     uint32_t X[4] = {own & p.odd, own & ~p.odd, opp & p.odd, opp & ~p.odd};  // A B C D
+    uint32_t one = 1;
+#ifndef GBL_HOST_EMU
+    asm volatile("" : "+v"(one));  // one register for the 21 stores (else the constant is re-materialised per store)
+#endif
 #pragma unroll
     for (int ch = 0; ch < 12; ++ch) {
         int k = (ch % 6) / 2;
         uint32_t grp = (X[(ch < 6 ? 0 : 2) + (ch & 1)] >> (9 * k)) & 0x1FFu;
-        if (grp) row[13 * __builtin_ctz(grp) + ch] = 1;
+        if (grp) row[13 * __builtin_ctz(grp) + ch] = (uint8_t)one;
     }
     if (observer) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) row[13 * q + 12] = 1;
+        for (int q = 0; q < 9; ++q) row[13 * q + 12] = (uint8_t)one;
     }
 }
 
@@ -508,7 +512,8 @@ __device__ __forceinline__ int pick54(uint64_t m, uint32_t r)
     uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
     uint32_t nlo = __popc(lo), n = nlo + __popc(hi);
     uint32_t k = __umulhi(r, n);
-    int a = (k < nlo) ? (int)kth_bit32(lo, k) : 32 + (int)kth_bit32(hi, k - nlo);
+    bool low = k < nlo;  // pick the word first: one bit search instead of two
+    int a = (int)kth_bit32(low ? lo : hi, low ? k : k - nlo) + (low ? 0 : 32);
     return n ? a : -1;
 }
 
