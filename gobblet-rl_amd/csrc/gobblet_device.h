@@ -470,8 +470,12 @@ __device__ __forceinline__ uint32_t validate_row(const uint32_t (&r)[7])
 }
 
 // ---- Philox4x32-10 (Salmon et al., SC'11); known answers are checked in tests/ ---------------
-__device__ __forceinline__ uint32_t philox_first(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                                 uint32_t k1)
+struct Draw4 {
+    uint32_t w[4];
+};
+
+__device__ __forceinline__ Draw4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1)
 {
 #pragma unroll
     for (int rnd = 0; rnd < 10; ++rnd) {
@@ -481,7 +485,7 @@ __device__ __forceinline__ uint32_t philox_first(uint32_t c0, uint32_t c1, uint3
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    return c0;
+    return Draw4{{c0, c1, c2, c3}};
 }
 
 // index of the k-th (0-based) set bit of w; k < popcount(w)
@@ -501,10 +505,24 @@ __device__ __forceinline__ uint32_t kth_bit32(uint32_t w, uint32_t k)
 
 // masked-uniform draw (see gbl_sample in include/gobblet_hip.h), in two halves: the 32-bit draw
 // depends only on (seed, board id, ply) -- a kernel can compute it while its tile is still in
-// flight -- and the pick needs the mask.  -1 if m == 0.
+// flight -- and the pick needs the mask.  One Philox block serves four consecutive plies of a board
+// (word ply & 3 of the block with counter ply >> 2): a kernel that plays several plies per launch
+// runs the generator once per four.
+__device__ __forceinline__ Draw4 draw_block(uint64_t seed, uint64_t env_id, uint32_t ply)
+{
+    return philox4x32_10((uint32_t)env_id, (uint32_t)(env_id >> 32), ply >> 2, 0u, (uint32_t)seed,
+                         (uint32_t)(seed >> 32));
+}
+
+__device__ __forceinline__ uint32_t draw_word(const Draw4 &d, uint32_t ply)
+{
+    uint32_t lo = (ply & 1u) ? d.w[1] : d.w[0], hi = (ply & 1u) ? d.w[3] : d.w[2];
+    return (ply & 2u) ? hi : lo;
+}
+
 __device__ __forceinline__ uint32_t draw32(uint64_t seed, uint64_t env_id, uint32_t ply)
 {
-    return philox_first((uint32_t)env_id, (uint32_t)(env_id >> 32), ply, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return draw_word(draw_block(seed, env_id, ply), ply);
 }
 
 __device__ __forceinline__ int pick54(uint64_t m, uint32_t r)

@@ -336,8 +336,8 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
     uint32_t r[7];
     // The first ply's random draw does not depend on the board: it is computed while the tile's loads
     // are in flight (between their issue and the LDS commit), off the wave's serial path.
-    uint32_t draw = 0;
-    load_state(state, s_img, L, r, [&] { draw = draw32(seed, env_base + (uint64_t)L.b, ply0); });
+    Draw4 block{{0u, 0u, 0u, 0u}};
+    load_state(state, s_img, L, r, [&] { block = draw_block(seed, env_base + (uint64_t)L.b, ply0); });
     mover = L.valid && mover != 0;
     GBL_STAMP_DEP(1, r[0] + (uint32_t)mover);
     Planes p = make_planes(r);
@@ -347,8 +347,9 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
     int dn = 0, action = -1, tcount = 0;  // tcount: turn delta, or the absolute turn once a reset happened
     bool treset = false;
     for (uint32_t t = 0; t < plies; ++t) {
-        action = pick54(legal54(p, mover), draw);
-        if (t + 1 < plies) draw = draw32(seed, env_base + (uint64_t)L.b, ply0 + t + 1);
+        const uint32_t ply = ply0 + t;
+        action = pick54(legal54(p, mover), draw_word(block, ply));
+        if (t + 1 < plies && ((ply + 1) & 3u) == 0) block = draw_block(seed, env_base + (uint64_t)L.b, ply + 1);
         step_lane(row, p, mover, 0, action, illegal_mode, 1, dn, y);
         tcount = next_turn(tcount, y, 1);
         treset = treset || y.terminal;

@@ -123,8 +123,9 @@ int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *action
 /* Masked-uniform action sampling -- the rule behind "masked-random actions"
  * (examples/example_basic.py:58-61, random_admissible_policy_rllib.py:23-30:
  * uniform over legal actions) -- with a counter-based RNG so CPU and GPU draw
- * the same action: r = Philox4x32-10(ctr = (env_lo, env_hi, ply, 0),
- * key = (seed_lo, seed_hi))[0]; k = (r * nlegal) >> 32; the k-th legal action
+ * the same action: r = word (ply & 3) of Philox4x32-10(ctr = (env_lo, env_hi,
+ * ply >> 2, 0), key = (seed_lo, seed_hi)) -- one generator block serves four
+ * consecutive plies of a board; k = (r * nlegal) >> 32; the k-th legal action
  * in ascending order (-1 if the mask is empty).  env id = env_base + b. */
 int gbl_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply,
                void *stream);

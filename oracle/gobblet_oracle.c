@@ -261,7 +261,8 @@ void gbo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 /* The masked-uniform sampling rule ("masked-random actions" in the configs;
  * reference sites examples/example_basic.py:58-61,
  * random_admissible_policy_rllib.py:23-30: uniform over legal actions).
- * Draw r = philox(ctr=(env_lo, env_hi, ply, 0), key=(seed_lo, seed_hi))[0],
+ * Draw r = philox(ctr=(env_lo, env_hi, ply >> 2, 0), key=(seed_lo, seed_hi))[ply & 3]
+ * (one generator block serves four consecutive plies of a board),
  * k = (r * nlegal) >> 32, return the k-th legal action in ascending order.
  * Returns -1 when the mask is empty. */
 int gbo_sample_action(const int8_t *mask, uint64_t seed, uint64_t env_id, uint32_t ply)
@@ -269,11 +270,11 @@ int gbo_sample_action(const int8_t *mask, uint64_t seed, uint64_t env_id, uint32
     int n = 0;
     for (int a = 0; a < GBO_ACTIONS; ++a) n += (mask[a] != 0);
     if (n == 0) return -1;
-    uint32_t ctr[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), ply, 0u};
+    uint32_t ctr[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), ply >> 2, 0u};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t out[4];
     gbo_philox4x32_10(ctr, key, out);
-    int k = (int)(((uint64_t)out[0] * (uint64_t)n) >> 32);
+    int k = (int)(((uint64_t)out[ply & 3u] * (uint64_t)n) >> 32);
     for (int a = 0; a < GBO_ACTIONS; ++a)
         if (mask[a] != 0 && k-- == 0) return a;
     return -1;
