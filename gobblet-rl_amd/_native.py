@@ -48,6 +48,7 @@ SIGNATURES = {
     "gbl_rollout": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u64, _u64, _u32, _u32, _int, _vp, _vp, _vp]),
     "gbl_decode_obs": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "gbl_greedy": (_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp]),
+    "gbl_greedy_act": (_int, [_vp, _vp, _vp, _vp, _int, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _i64, _vp]),
 }
 
 

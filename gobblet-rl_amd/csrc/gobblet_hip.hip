@@ -460,8 +460,13 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
                                                    const int8_t *__restrict__ mask_in,
                                                    const int8_t *__restrict__ hist, int depth,
                                                    int32_t *__restrict__ action_out, int8_t *__restrict__ cand_out,
-                                                   int8_t *__restrict__ fallback_out, int64_t n, int64_t ntiles)
+                                                   int8_t *__restrict__ fallback_out, int64_t n, int64_t ntiles,
+                                                   int8_t *__restrict__ hist_rw, int32_t *__restrict__ final_out,
+                                                   uint64_t seed, uint64_t env_base, uint32_t call)
 {
+    // hist_rw != NULL: gbl_greedy_act -- the history is read from and appended to hist_rw, and final_out gets
+    // the action the policy returns (the fallback draw included); hist is then unused.
+    if (hist_rw) hist = hist_rw;
     __shared__ uint32_t s_state[image_words<kCells>()];
     __shared__ uint32_t s_mask[image_words<kActions>()];
     __shared__ uint32_t s_board[kTile][4];          // planes nz, neg, odd and the agent to move
@@ -483,12 +488,12 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
     }
     GreedyHead h{0ull, 0ull, 0ull, 0, -1};
     uint32_t prev3 = 0x00FFFFFFu;
-    int total = 0;
+    int total = 0, me = 0;
     if (owner) {
         uint32_t r[7];
         load_state(state, s_state, L, r);
         Planes p = make_planes(r);
-        int me = L.valid ? (to_move[L.b] != 0) : 0;
+        me = L.valid ? (to_move[L.b] != 0) : 0;
         uint64_t mask;
         if (mask_in) {
             tile_in<kActions>(mask_in + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
@@ -572,8 +577,17 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
         tile_out<kActions>(cand_out + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
     }
     if (L.valid) {
-        action_out[L.b] = g.fallback ? -1 : g.chosen;
+        if (action_out) action_out[L.b] = g.fallback ? -1 : g.chosen;
         if (fallback_out) fallback_out[L.b] = g.fallback ? 1 : 0;
+        if (hist_rw) {
+            // :211-217 with the library's sampler, then :219
+            const int fin = g.fallback ? pick54(g.cands, draw32(seed, env_base + (uint64_t)L.b, call)) : g.chosen;
+            final_out[L.b] = fin;
+            int8_t *hp = hist_rw + (L.b * 2 + me) * 3;
+            hp[0] = (int8_t)(prev3 >> 8);
+            hp[1] = (int8_t)(prev3 >> 16);
+            hp[2] = (int8_t)fin;
+        }
     }
 }
 
@@ -813,6 +827,34 @@ int gbl_validate(const int8_t *state, int8_t *flags, int64_t n, void *stream)
     GBL_LAUNCHED("gbl_validate");
 }
 
+namespace {
+// Wavefronts per tile.  Measured on depth 2 (scripts/bench_greedy.py, 65 536 / 262 144 / 2^20 boards):
+// 1: 49 / 155 / 518 us, 2: 43 / 139 / 487, 4: 41 / 121 / 451, 8: 40 / 136 / 520, 16: 50 / 176 / 679.
+int greedy_waves(int depth)
+{
+    static const int forced = [] {
+        const char *e = getenv("GBL_GREEDY_WAVES");  // 1, 2 or 4: A/B runs
+        return e ? atoi(e) : 0;
+    }();
+    return forced ? forced : depth == 1 ? 1 : 4;
+}
+
+void launch_greedy(int waves, const Geometry &g, hipStream_t stream, const int8_t *state, const int8_t *to_move,
+                   const int8_t *mask, const int8_t *hist, int depth, int32_t *action_out, int8_t *cand_mask_out,
+                   int8_t *fallback_out, int64_t n, int8_t *hist_rw, int32_t *final_out, uint64_t seed,
+                   uint64_t env_base, uint32_t call)
+{
+#define GBL_GREEDY(W)                                                                                            \
+    hipLaunchKernelGGL(k_greedy<W>, dim3(g.grid), dim3(64 * W), 0, stream, state, to_move, mask, hist, depth,      \
+                       action_out, cand_mask_out, fallback_out, n, g.ntiles, hist_rw, final_out, seed, env_base, \
+                       call)
+    if (waves >= 4) GBL_GREEDY(4);
+    else if (waves == 2) GBL_GREEDY(2);
+    else GBL_GREEDY(1);
+#undef GBL_GREEDY
+}
+}  // namespace
+
 int gbl_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask, const int8_t *hist, int depth,
                int32_t *action_out, int8_t *cand_mask_out, int8_t *fallback_out, int64_t n, void *stream)
 {
@@ -820,22 +862,22 @@ int gbl_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask, c
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(action_out, "action_out");
     if (depth < 1 || depth > 3) return fail(GBL_ERR_ARG, "depth must be 1, 2 or 3");
     GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask, "mask"); GBL_ALIGNED(cand_mask_out, "cand_mask_out");
-    Geometry g = geometry(n);
-    // Wavefronts per tile.  Measured on depth 2 (scripts/bench_greedy.py, 65 536 / 262 144 / 2^20 boards):
-    // 1: 49 / 155 / 518 us, 2: 43 / 139 / 487, 4: 41 / 121 / 451, 8: 40 / 136 / 520, 16: 50 / 176 / 679.
-    static const int forced = [] {
-        const char *e = getenv("GBL_GREEDY_WAVES");  // 1, 2 or 4: A/B runs
-        return e ? atoi(e) : 0;
-    }();
-    const int waves = forced ? forced : depth == 1 ? 1 : 4;
-#define GBL_GREEDY(W)                                                                                             \
-    hipLaunchKernelGGL(k_greedy<W>, dim3(g.grid), dim3(64 * W), 0, (hipStream_t)stream, state, to_move, mask, hist, \
-                       depth, action_out, cand_mask_out, fallback_out, n, g.ntiles)
-    if (waves >= 4) GBL_GREEDY(4);
-    else if (waves == 2) GBL_GREEDY(2);
-    else GBL_GREEDY(1);
-#undef GBL_GREEDY
+    launch_greedy(greedy_waves(depth), geometry(n), (hipStream_t)stream, state, to_move, mask, hist, depth, action_out,
+                  cand_mask_out, fallback_out, n, nullptr, nullptr, 0, 0, 0);
     GBL_LAUNCHED("gbl_greedy");
+}
+
+int gbl_greedy_act(const int8_t *state, const int8_t *to_move, const int8_t *mask, int8_t *hist, int depth,
+                   uint64_t seed, uint64_t env_base, uint32_t call, int32_t *action_out, int32_t *chosen_out,
+                   int8_t *cand_mask_out, int8_t *fallback_out, int64_t n, void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(hist, "hist"); GBL_NEED(action_out, "action_out");
+    if (depth < 1 || depth > 3) return fail(GBL_ERR_ARG, "depth must be 1, 2 or 3");
+    GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask, "mask"); GBL_ALIGNED(cand_mask_out, "cand_mask_out");
+    launch_greedy(greedy_waves(depth), geometry(n), (hipStream_t)stream, state, to_move, mask, nullptr, depth, chosen_out,
+                  cand_mask_out, fallback_out, n, hist, action_out, seed, env_base, call);
+    GBL_LAUNCHED("gbl_greedy_act");
 }
 
 }  // extern "C"

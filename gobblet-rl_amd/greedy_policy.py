@@ -64,22 +64,17 @@ class GreedyGobbletPolicy:
         """The same decision from ``squares`` (N,27) + ``to_move`` (N,) directly (no observation round trip)."""
         n = state.shape[0]
         self._ensure(n)
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
         act = torch.empty(n, dtype=torch.int32, device=self.device)
         cand = torch.empty((n, nat.ACTIONS), dtype=torch.int8, device=self.device)
         fb = torch.empty(n, dtype=torch.int8, device=self.device)
-        nat.check(self._lib.gbl_greedy(state.data_ptr(), to_move.data_ptr(), nat.ptr(mask),
-                                       self.prev_actions.data_ptr(), self.depth, act.data_ptr(), cand.data_ptr(),
-                                       fb.data_ptr(), n, self._stream()), "gbl_greedy")
-        # :211-217 fallback: uniform over actions_depth1
-        drawn = torch.empty(n, dtype=torch.int32, device=self.device)
-        nat.check(self._lib.gbl_sample(cand.data_ptr(), drawn.data_ptr(), n, self.seed, 0, self._calls,
-                                       self._stream()), "gbl_sample")
+        # one launch: the search, the :211-217 fallback draw (uniform over actions_depth1, keyed by seed / board /
+        # call index) and the :219 history append for the acting agent
+        nat.check(self._lib.gbl_greedy_act(state.data_ptr(), to_move.data_ptr(), nat.ptr(mask),
+                                           self.prev_actions.data_ptr(), self.depth, self.seed, 0, self._calls,
+                                           out.data_ptr(), act.data_ptr(), cand.data_ptr(), fb.data_ptr(), n,
+                                           self._stream()), "gbl_greedy_act")
         self.last_chosen, self.last_candidates, self.last_fallback = act, cand, fb
-        out = torch.where(fb.bool(), drawn, act)
-        # :219 history append for the acting agent
-        idx = torch.arange(n, device=self.device)
-        h = self.prev_actions[idx, to_move.long()]
-        self.prev_actions[idx, to_move.long()] = torch.cat([h[:, 1:], out.to(torch.int8)[:, None]], dim=1)
         self._calls += 1
         return out
 

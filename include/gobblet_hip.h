@@ -164,6 +164,18 @@ int gbl_decode_obs(const int8_t *obs, int8_t *state, int8_t *to_move, int64_t n,
 int gbl_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask, const int8_t *hist, int depth,
                int32_t *action_out, int8_t *cand_mask_out, int8_t *fallback_out, int64_t n, void *stream);
 
+/* One whole policy step of GreedyGobbletPolicy.compute_action, greedy_policy.py:38-221, in one launch:
+ * gbl_greedy, then where it reports the fallback (:211-217) the gbl_sample rule over the candidate set
+ * with (seed, env_base + b, call) in place of numpy's global RNG, then the history append of :219
+ * (hist[b][agent to move] shifts left by one and takes the returned action).
+ *   hist      : int8[n][2][3], read AND updated (required)
+ *   action_out  int32[n] : the action the policy returns (-1 only if the candidate set is empty)
+ *   chosen_out  int32[n] : gbl_greedy's action_out (chosen, or -1 where the fallback fired; may be NULL)
+ *   cand_mask_out / fallback_out : as gbl_greedy (may be NULL) */
+int gbl_greedy_act(const int8_t *state, const int8_t *to_move, const int8_t *mask, int8_t *hist, int depth,
+                   uint64_t seed, uint64_t env_base, uint32_t call, int32_t *action_out, int32_t *chosen_out,
+                   int8_t *cand_mask_out, int8_t *fallback_out, int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

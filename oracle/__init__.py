@@ -103,6 +103,9 @@ def lib() -> C.CDLL:
         L.gbo_greedy_work.argtypes = [_i64p, C.c_int]
         L.gbo_batch_greedy.restype = None
         L.gbo_batch_greedy.argtypes = [_i8p, _i8p, _i8p, _i8p, C.c_int, _i32p, _i8p, _i8p, C.c_int64]
+        L.gbo_batch_greedy_act.restype = None
+        L.gbo_batch_greedy_act.argtypes = [_i8p, _i8p, _i8p, _i8p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _i32p,
+                                           _i32p, _i8p, _i8p, C.c_int64]
     return _lib
 
 
@@ -286,6 +289,16 @@ def batch_greedy(state, to_move, mask=None, hist=None, depth=2):
     lib().gbo_batch_greedy(_p(state), _p(to_move), _p(mask), _p(hist), int(depth), _p(act, C.c_int32), _p(cm),
                            _p(fb), n)
     return act, cm, fb
+
+
+def batch_greedy_act(state, to_move, hist, seed, env_base, call, mask=None, depth=2):
+    """One policy step: (returned action, chosen-or--1, candidate mask, fallback flag); ``hist`` (n,2,3) int8 is
+    updated in place."""
+    n = state.shape[0]
+    act = np.zeros(n, np.int32); ch = np.zeros(n, np.int32); cm = np.zeros((n, ACTIONS), np.int8); fb = np.zeros(n, np.int8)
+    lib().gbo_batch_greedy_act(_p(state), _p(to_move), _p(mask), _p(hist), int(depth), int(seed), int(env_base),
+                               int(call), _p(act, C.c_int32), _p(ch, C.c_int32), _p(cm), _p(fb), n)
+    return act, ch, cm, fb
 
 
 def greedy_work(reset=True):

@@ -732,3 +732,27 @@ void gbo_batch_greedy(const int8_t *state, const int8_t *to_move, const int8_t *
         if (fallback_out) fallback_out[b] = (int8_t)fb;
     }
 }
+
+/* One policy step (the C-ABI's gbl_greedy_act): gbo_batch_greedy, the fallback draw of
+ * greedy_policy.py:211-217 with gbo_sample_action over the candidate set keyed
+ * (seed, env_base + b, call), and the history append of :219 (hist is updated in place). */
+void gbo_batch_greedy_act(const int8_t *state, const int8_t *to_move, const int8_t *mask_in, int8_t *hist, int depth,
+                          uint64_t seed, uint64_t env_base, uint32_t call, int32_t *action_out, int32_t *chosen_out,
+                          int8_t *cand_mask_out, int8_t *fallback_out, int64_t n)
+{
+    for (int64_t b = 0; b < n; ++b) {
+        int32_t chosen;
+        int8_t cm[GBO_ACTIONS], fb;
+        gbo_batch_greedy(state + b * GBO_CELLS, to_move + b, mask_in ? mask_in + b * GBO_ACTIONS : NULL,
+                         hist + b * 6, depth, &chosen, cm, &fb, 1);
+        int fin = fb ? gbo_sample_action(cm, seed, env_base + (uint64_t)b, call) : chosen;
+        action_out[b] = fin;
+        if (chosen_out) chosen_out[b] = chosen;
+        if (cand_mask_out) memcpy(cand_mask_out + b * GBO_ACTIONS, cm, GBO_ACTIONS);
+        if (fallback_out) fallback_out[b] = fb;
+        int8_t *h = hist + (b * 2 + (to_move[b] != 0)) * 3; /* prev_actions[agent_index].append(...), last three kept */
+        h[0] = h[1];
+        h[1] = h[2];
+        h[2] = (int8_t)fin;
+    }
+}

@@ -111,13 +111,23 @@ def greedy(state, to_move, mask=None, hist=None, depth=2, pooled=True):
     n = len(state)
     act = np.full(n, 77, np.int32); cm = np.full((n, 54), 77, np.int8); fb = np.full(n, 77, np.int8)
     lib().emu_greedy(_p(state), _p(to_move), _p(mask), _p(hist), C.c_int(depth), _p(act), _p(cm), _p(fb), C.c_int64(n),
-                     C.c_int(int(pooled)))
+                     C.c_int(int(pooled)), None, None, C.c_uint64(0), C.c_uint64(0), C.c_uint32(0))
     return act, cm, fb
 
 
 def validate(state):
     n = len(state); out = np.full(n, 77, np.int8)
     lib().emu_validate(_p(state), _p(out), C.c_int64(n)); return out
+
+
+def greedy_act(state, to_move, hist, seed, env_base, call, mask=None, depth=2):
+    """gbl_greedy_act: (returned action, chosen-or--1, candidate mask, fallback); hist (n,2,3) updated in place."""
+    n = len(state)
+    out = np.full(n, 77, np.int32); act = np.full(n, 77, np.int32); cm = np.full((n, 54), 77, np.int8)
+    fb = np.full(n, 77, np.int8)
+    lib().emu_greedy(_p(state), _p(to_move), _p(mask), None, C.c_int(depth), _p(act), _p(cm), _p(fb), C.c_int64(n),
+                     C.c_int(1), _p(hist), _p(out), C.c_uint64(seed), C.c_uint64(env_base), C.c_uint32(call))
+    return out, act, cm, fb
 
 
 def greedy_stats():

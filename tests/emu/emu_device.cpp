@@ -373,8 +373,10 @@ void emu_greedy_stats(int64_t *out)
 // pooled != 0: the kernel's flow (candidate lists of a tile back to back, every pair evaluated by
 // "lane" g % 64, threat / allwin sets, greedy_replay_sets); pooled == 0: greedy_decide per board.
 void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_in, const int8_t *hist, int depth,
-                int32_t *action_out, int8_t *cand_out, int8_t *fallback_out, int64_t n, int pooled)
+                int32_t *action_out, int8_t *cand_out, int8_t *fallback_out, int64_t n, int pooled, int8_t *hist_rw,
+                int32_t *final_out, uint64_t seed, uint64_t env_base, uint32_t call)
 {
+    if (hist_rw) hist = hist_rw;  // gbl_greedy_act: history read from and appended to hist_rw
     for_tiles(n, [&](TileCtx t) {
         uint32_t r[64][7], dc[64][14];
         Planes P[64];
@@ -451,8 +453,16 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
             }
             mask_row(g.cands, dc[l]);
             if (valid) {
-                action_out[b] = g.fallback ? -1 : g.chosen;
+                if (action_out) action_out[b] = g.fallback ? -1 : g.chosen;
                 if (fallback_out) fallback_out[b] = g.fallback ? 1 : 0;
+                if (hist_rw) {
+                    int fin = g.fallback ? pick54(g.cands, draw32(seed, env_base + (uint64_t)b, call)) : g.chosen;
+                    final_out[b] = fin;
+                    int8_t *hp = hist_rw + (b * 2 + ME[l]) * 3;
+                    hp[0] = (int8_t)(PREV[l] >> 8);
+                    hp[1] = (int8_t)(PREV[l] >> 16);
+                    hp[2] = (int8_t)fin;
+                }
             }
         }
         if (cand_out) {

@@ -240,3 +240,24 @@ def test_winner_exhaustive_tops():
         st[:, 9 * lvl:9 * lvl + 9] = np.where(occ, v, 0)
     w = oracle.batch_winner(st)
     assert np.array_equal(emu.winner(st), w) and len(np.unique(w)) == 3
+
+
+def test_greedy_policy_step_selfplay():
+    """gbl_greedy_act's flow (decision + fallback draw + history append) against the oracle's, as two greedy
+    agents play 24 plies on 1500 boards: the histories fill up, so the 3-move repeat guard and the fallback
+    draw both fire."""
+    n, seed, base = 1500, 5, 77
+    s1, t1, d1 = oracle.batch_reset(n)
+    h_emu = np.full((n, 2, 3), -1, np.int8); h_ora = h_emu.copy()
+    fallbacks = 0
+    for call in range(24):
+        depth = 2 if call % 3 else 1
+        e = emu.greedy_act(s1, t1, h_emu, seed, base, call, depth=depth)
+        o = oracle.batch_greedy_act(s1, t1, h_ora, seed, base, call, depth=depth)
+        for x, y in zip(e, o):
+            assert np.array_equal(x, y), call
+        assert np.array_equal(h_emu, h_ora)
+        fallbacks += int(o[3].sum())
+        a = np.where(d1 != 0, 0, o[0]).astype(np.int32)
+        oracle.batch_step(s1, t1, d1, a, auto_reset=True)
+    assert fallbacks > 100 and (h_ora >= 0).all()

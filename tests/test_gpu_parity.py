@@ -267,6 +267,38 @@ def test_greedy_depth3(G, golden_dir):
     assert np.array_equal(npy(a), g["chosen_d2"].astype(np.int32)) and not npy(pol.last_fallback).any()
 
 
+def test_greedy_policy_step_vs_oracle(G):
+    """gbl_greedy_act (decision + fallback draw + history append in one launch) against the oracle while two
+    greedy agents play 24 plies on 5000 boards; then the host class, which is built on it."""
+    from gobblet_rl_amd import _native as nat
+    n, seed, base = 5000, 5, 1 << 33
+    s1, t1, d1 = oracle.batch_reset(n)
+    h_ora = np.full((n, 2, 3), -1, np.int8)
+    h_dev = t(h_ora)
+    out = torch.empty(n, dtype=torch.int32, device=DEV); ch = torch.empty(n, dtype=torch.int32, device=DEV)
+    cm = torch.empty((n, 54), dtype=torch.int8, device=DEV); fb = torch.empty(n, dtype=torch.int8, device=DEV)
+    fallbacks = 0
+    for call in range(24):
+        depth = 2 if call % 3 else 1
+        st, who = t(s1), t(t1)
+        nat.check(nat.lib().gbl_greedy_act(st.data_ptr(), who.data_ptr(), None, h_dev.data_ptr(), depth, seed, base, call,
+                                           out.data_ptr(), ch.data_ptr(), cm.data_ptr(), fb.data_ptr(), n, None))
+        torch.cuda.synchronize()
+        o = oracle.batch_greedy_act(s1, t1, h_ora, seed, base, call, depth=depth)
+        for x, y in zip((out, ch, cm, fb), o):
+            assert np.array_equal(npy(x), y), call
+        assert np.array_equal(npy(h_dev), h_ora)
+        fallbacks += int(o[3].sum())
+        oracle.batch_step(s1, t1, d1, np.where(d1 != 0, 0, o[0]).astype(np.int32), auto_reset=True)
+    assert fallbacks > 300
+    # NULL optional outputs
+    nat.check(nat.lib().gbl_greedy_act(st.data_ptr(), who.data_ptr(), None, h_dev.data_ptr(), 2, seed, base, 99,
+                                       out.data_ptr(), None, None, None, n, None))
+    torch.cuda.synchronize()
+    o = oracle.batch_greedy_act(s1 * 0 + npy(st), npy(who), h_ora, seed, base, 99, depth=2)
+    assert np.array_equal(npy(out), o[0]) and np.array_equal(npy(h_dev), h_ora)
+
+
 def test_greedy_vs_oracle_selfplay(G):
     from gobblet_rl_amd import _native as nat
     state, tm, dn = selfplay(3000, 26, seed=8)
