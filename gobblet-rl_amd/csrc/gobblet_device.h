@@ -778,6 +778,7 @@ struct GreedyHead {
     uint64_t cands;     // actions_depth1 as a 54-bit set, :77-79
     uint64_t todo;      // depth-1 results with value 0, in insertion (= ascending) order: the depth-2 loop's list
     uint64_t legal_me;  // board.is_legal(agent_index, a) on the root position, :85 and :141
+    uint64_t dup;       // candidates in todo whose reply summary equals that of candidate a - 9 (see greedy_head)
     int ncands, chosen;
 };
 
@@ -814,6 +815,17 @@ __device__ __forceinline__ GreedyHead greedy_head(const Planes &p, int me, uint6
     }
     // :103; depth 3 adds :160-208, whose only assignment repeats :157 -- no effect
     h.todo = depth > 1 ? (seen & ~win1 & ~lose1) : 0ull;
+    // The two pieces of a size are interchangeable: while both are still in hand, placing piece 2k+1 on q
+    // gives the opponent exactly the position that placing piece 2k there does (the planes differ in one
+    // `odd` bit of OUR piece, which none of the opponent's legality / outcome terms reads), so candidate
+    // a + 9 has the reply summary of candidate a.  27 % of the candidates on the masked-random mix.
+    uint32_t mine = me ? (p.nz & p.neg) : (p.nz & ~p.neg);
+    h.dup = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        uint64_t both = (h.todo >> (18 * k)) & (h.todo >> (18 * k + 9)) & 0x1FFull;
+        if (((mine >> (9 * k)) & 0x1FFu) == 0) h.dup |= both << (18 * k + 9);
+    }
     return h;
 }
 
@@ -915,6 +927,8 @@ template <typename ReplyOf>
 __device__ __forceinline__ void greedy_replay_sets(GreedyHead &h, uint64_t threat, uint64_t allwin, ReplyOf reply_of)
 {
     uint64_t todo = h.todo;
+    threat |= (threat << 9) & h.dup;  // twin placements share their partner's summary (reply_of must serve them too)
+    allwin |= (allwin << 9) & h.dup;
     allwin &= todo;
     if (allwin) todo &= below_eq(__builtin_ctzll(allwin));  // :151: nothing after the break is looked at
     const uint64_t calm = todo & ~threat;
@@ -941,7 +955,8 @@ __device__ __forceinline__ GreedyResult greedy_decide(const Planes &p, int me, u
     for (uint64_t it = h.todo; it;) {
         int a = __builtin_ctzll(it);
         it &= it - 1;
-        if (greedy_replay(h, a, greedy_reply(p, me, h.legal_me, (uint32_t)a))) break;
+        const uint32_t twin = ((h.dup >> a) & 1ull) ? (uint32_t)a - 9u : (uint32_t)a;  // same summary, see greedy_head
+        if (greedy_replay(h, a, greedy_reply(p, me, h.legal_me, twin))) break;
     }
     return greedy_finish(h, prev3);
 }

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
         L.valid = L.lane < L.rows;
         L.b = L.tile * kTile + L.lane;
     }
-    GreedyHead h{0ull, 0ull, 0ull, 0, -1};
+    GreedyHead h{0ull, 0ull, 0ull, 0ull, 0, -1};
     uint32_t prev3 = 0x00FFFFFFu;
     int total = 0, me = 0;
     if (owner) {
@@ -519,7 +519,8 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
             s_legal[L.lane] = h.legal_me;
             s_threat[L.lane] = 0ull;
             s_allwin[L.lane] = 0ull;
-            const int mine = __popcll(h.todo);
+            const uint64_t work = h.todo & ~h.dup;  // twin placements are not evaluated a second time
+            const int mine = __popcll(work);
             int upto = mine;  // inclusive prefix sum of the list lengths over the wavefront
 #pragma unroll
             for (int d = 1; d < kTile; d <<= 1) {
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
                 s_deferred = 0;
             }
             int k = upto - mine;
-            for (uint64_t it = h.todo; it; it &= it - 1)
+            for (uint64_t it = work; it; it &= it - 1)
                 s_pair[k++] = (uint16_t)((L.lane << 8) | __builtin_ctzll(it));
         }
     }
@@ -567,7 +568,9 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
     }
     if (!owner) return;
     if (depth > 1)  // :103-157 in order, on the owner's lane
-        greedy_replay_sets(h, s_threat[L.lane], s_allwin[L.lane], [&](int a) { return (uint32_t)s_reply[L.lane][a]; });
+        greedy_replay_sets(h, s_threat[L.lane], s_allwin[L.lane], [&](int a) {
+            return (uint32_t)s_reply[L.lane][((h.dup >> a) & 1ull) ? a - 9 : a];
+        });
     GreedyResult g = greedy_finish(h, prev3);
     if (cand_out) {
         uint32_t d[14];

@@ -415,7 +415,8 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
         uint64_t threat[64] = {0}, allwin[64] = {0};
         int total = 0;
         for (int l = 0; l < 64; ++l)
-            for (uint64_t it = H[l].todo; it; it &= it - 1) pair[total++] = (uint16_t)((l << 8) | __builtin_ctzll(it));
+            for (uint64_t it = H[l].todo & ~H[l].dup; it; it &= it - 1)
+                pair[total++] = (uint16_t)((l << 8) | __builtin_ctzll(it));
         static uint16_t again[64 * kActions];
         int deferred = 0;
         auto record = [&](uint32_t o, uint32_t a, uint32_t sum) {
@@ -446,7 +447,9 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
             int64_t b = t.tile * 64 + l;
             GreedyResult g;
             if (pooled) {
-                greedy_replay_sets(H[l], threat[l], allwin[l], [&](int a) { return (uint32_t)reply[l][a]; });
+                greedy_replay_sets(H[l], threat[l], allwin[l], [&](int a) {
+                    return (uint32_t)reply[l][((H[l].dup >> a) & 1ull) ? a - 9 : a];
+                });
                 g = greedy_finish(H[l], PREV[l]);
             } else {
                 g = greedy_decide(P[l], ME[l], MASK[l], depth, PREV[l]);
