@@ -33,10 +33,28 @@ def counter_mean(db, kernel, counter):
     return sum(v) / len(v), len(v)
 
 
+def greedy(dst):
+    src = os.path.join(ROOT, "gpurun_out", "c5")
+    for a, b in (("d2", "c5_greedy_depth2_65536"), ("d1", "c5_greedy_depth1_65536"), ("d2_1m", "c5_greedy_depth2_1048576"),
+                 ("policy", "c5_greedy_policy_step_65536")):
+        shutil.copy(os.path.join(src, a + ".json"), os.path.join(dst, b + ".json"))
+    open(os.path.join(dst, "c5_greedy_kernel_stats.csv"), "w").write(
+        capture(rocpd_summary.stats, os.path.join(src, "stats", "p_results.db")))
+    sq = ("# k_greedy<4> depth 2 (pairs pooled over a tile, 4 wavefronts per tile, cheap + exact reply evaluation, twin "
+          "placements evaluated once), 65536 boards = 1024 tiles; rocprofv3 --pmc, summed over instances per dispatch\n")
+    sq += capture(rocpd_summary.counters, "k_greedy", [os.path.join(src, "pmc1", "p_results.db"),
+                                                       os.path.join(src, "pmc2", "p_results.db")])
+    open(os.path.join(dst, "c5_greedy_sq_counters.csv"), "w").write(sq)
+    print(sq)
+    print(open(os.path.join(dst, "c5_greedy_kernel_stats.csv")).read()[:400])
+
+
 def main():
     rnd = sys.argv[1]
     dst = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(dst, exist_ok=True)
+    if len(sys.argv) > 2 and sys.argv[2] == "greedy":
+        return greedy(dst)
     for name in ("bench_default", "bench_maskonly", "bench_stepmode", "bench_4194304_boards", "bench_2097152_boards"):
         shutil.copy(os.path.join(SRC, name + ".json"), os.path.join(dst, "final_" + name + ".json"))
     for name in ("bench_c3_262144_boards", "bench_c2_4096_boards", "playouts"):
