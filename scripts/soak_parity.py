@@ -83,6 +83,17 @@ while time.time() < t_end:
     og = oracle.batch_greedy(s[:m].copy(), tm[:m].copy(), mask=sub, hist=hist, depth=2)
     assert np.array_equal(act.cpu().numpy(), og[0]) and np.array_equal(cm.cpu().numpy(), og[1])
     assert np.array_equal(fb.cpu().numpy(), og[2])
+    # whole policy steps (decision + fallback draw + history append), three calls so that histories matter
+    hd, ho = t(hist), hist.copy()
+    fin = torch.empty(m, dtype=torch.int32, device=DEV)
+    for call in range(3):
+        nat.check(nat.lib().gbl_greedy_act(st.data_ptr(), who.data_ptr(), None, hd.data_ptr(), 2, seed, base, call,
+                                           fin.data_ptr(), act.data_ptr(), cm.data_ptr(), fb.data_ptr(), m, None))
+        torch.cuda.synchronize()
+        og = oracle.batch_greedy_act(s[:m].copy(), tm[:m].copy(), ho, seed, base, call, depth=2)
+        assert np.array_equal(fin.cpu().numpy(), og[0]) and np.array_equal(act.cpu().numpy(), og[1])
+        assert np.array_equal(cm.cpu().numpy(), og[2]) and np.array_equal(fb.cpu().numpy(), og[3])
+        assert np.array_equal(hd.cpu().numpy(), ho)
     rounds += 1
     boards_checked += n
     print(f"round {rounds}: n={n} illegal={illegal} auto_reset={auto} obs={with_obs} plies={k0}+3 OK", flush=True)
