@@ -319,17 +319,20 @@ __global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t 
 // gbl_rollout: `plies` masked-random plies (sample + step + auto-reset) per launch; the board lives
 // in registers between plies and the outputs of the LAST ply are stored.  plies = 1 is the fused
 // "sample + step" ply of the benchmark pipeline.
-template <bool WITH_MASK, bool WITH_OBS, int NT>
+// DEV_PLY: the ply index is ply0 + *ply_dev (gbl_rollout_at, graph replay).  A template parameter because even
+// the never-taken runtime test costs the by-value kernel 0.3 us: it sits in front of the hoisted draw.
+template <bool WITH_MASK, bool WITH_OBS, int NT, bool DEV_PLY>
 __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8_t *__restrict__ to_move,
                                                 int8_t *__restrict__ done, int32_t *__restrict__ actions_out,
                                                 int8_t *__restrict__ winner_out, int8_t *__restrict__ reward_out,
                                                 int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out, int64_t n,
                                                 int64_t ntiles, uint64_t seed, uint64_t env_base, uint32_t ply0,
                                                 uint32_t plies, int illegal_mode, int64_t *__restrict__ counters,
-                                                int32_t *__restrict__ turn)
+                                                int32_t *__restrict__ turn, const uint32_t *__restrict__ ply_dev)
 {
     __shared__ uint32_t s_img[kOutImageWords];
     GBL_STAMP(0);
+    if (DEV_PLY) ply0 += *ply_dev;
     Lane L;
     if (!lane_setup(L, n, ntiles)) return;
     int mover = to_move[L.valid ? L.b : n - 1];  // issued before the tile loads, branch-free (see k_step)
@@ -386,10 +389,15 @@ __global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8
     GBL_STAMP_FLUSH(L.tile);
 }
 
+// gbl_counter_add: the device-resident ply / call counter of the *_at entry points
+__global__ void k_counter_add(uint32_t *ctr, uint32_t by) { *ctr += by; }
+
 // gbl_sample: mask rows -> one action per board
 __global__ __launch_bounds__(64) void k_sample(const int8_t *__restrict__ mask, int32_t *__restrict__ actions, int64_t n,
-                                               int64_t ntiles, uint64_t seed, uint64_t env_base, uint32_t ply)
+                                               int64_t ntiles, uint64_t seed, uint64_t env_base, uint32_t ply,
+                                               const uint32_t *__restrict__ ply_dev)
 {
+    if (ply_dev) ply += *ply_dev;
     __shared__ uint32_t s_mask[image_words<kActions>()];
     Lane L;
     if (!lane_setup(L, n, ntiles)) return;
@@ -462,8 +470,10 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
                                                    int32_t *__restrict__ action_out, int8_t *__restrict__ cand_out,
                                                    int8_t *__restrict__ fallback_out, int64_t n, int64_t ntiles,
                                                    int8_t *__restrict__ hist_rw, int32_t *__restrict__ final_out,
-                                                   uint64_t seed, uint64_t env_base, uint32_t call)
+                                                   uint64_t seed, uint64_t env_base, uint32_t call,
+                                                   const uint32_t *__restrict__ call_dev)
 {
+    if (call_dev) call += *call_dev;
     // hist_rw != NULL: gbl_greedy_act -- the history is read from and appended to hist_rw, and final_out gets
     // the action the policy returns (the fallback draw included); hist is then unused.
     if (hist_rw) hist = hist_rw;
@@ -761,21 +771,43 @@ int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *action
     GBL_LAUNCHED("gbl_step");
 }
 
-int gbl_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply,
-               void *stream)
+int gbl_sample_at(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply,
+                  const uint32_t *ply_dev, void *stream)
 {
     GBL_CHECK_N(n);
     GBL_NEED(mask, "mask"); GBL_NEED(actions, "actions");
     GBL_ALIGNED(mask, "mask");
     Geometry g = geometry(n);
     hipLaunchKernelGGL(k_sample, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, mask, actions, n, g.ntiles, seed,
-                       env_base, ply);
+                       env_base, ply, ply_dev);
     GBL_LAUNCHED("gbl_sample");
+}
+
+int gbl_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply,
+               void *stream)
+{
+    return gbl_sample_at(mask, actions, n, seed, env_base, ply, nullptr, stream);
+}
+
+int gbl_counter_add(uint32_t *counter, uint32_t by, void *stream)
+{
+    GBL_NEED(counter, "counter");
+    hipLaunchKernelGGL(k_counter_add, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, by);
+    GBL_LAUNCHED("gbl_counter_add");
 }
 
 int gbl_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_out, int8_t *winner_out,
                 int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, uint64_t seed, uint64_t env_base,
                 uint32_t ply0, uint32_t plies, int illegal_mode, int64_t *counters, int32_t *turn, void *stream)
+{
+    return gbl_rollout_at(state, to_move, done, actions_out, winner_out, reward_out, mask_out, obs_out, n, seed, env_base,
+                          ply0, nullptr, plies, illegal_mode, counters, turn, stream);
+}
+
+int gbl_rollout_at(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_out, int8_t *winner_out,
+                   int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, uint64_t seed, uint64_t env_base,
+                   uint32_t ply0, const uint32_t *ply_dev, uint32_t plies, int illegal_mode, int64_t *counters,
+                   int32_t *turn, void *stream)
 {
     GBL_CHECK_N(n);
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done");
@@ -790,10 +822,13 @@ int gbl_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_o
     Geometry g = geometry(n);
     hipStream_t s = (hipStream_t)stream;
     const int nt = nt_policy(n);
-#define GBL_ROLL_NT(M, O, NT)                                                                                       \
-    hipLaunchKernelGGL((k_rollout<M, O, NT>), dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions_out,      \
+#define GBL_ROLL_K(M, O, NT, D)                                                                                     \
+    hipLaunchKernelGGL((k_rollout<M, O, NT, D>), dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions_out,   \
                        winner_out, reward_out, mask_out, obs_out, n, g.ntiles, seed, env_base, ply0, plies,         \
-                       illegal_mode, counters, turn)
+                       illegal_mode, counters, turn, ply_dev)
+#define GBL_ROLL_NT(M, O, NT)                                   \
+    if (ply_dev) GBL_ROLL_K(M, O, NT, true);                    \
+    else GBL_ROLL_K(M, O, NT, false)
 #define GBL_ROLL(M, O)                                          \
     switch (nt) {                                               \
     case 0: GBL_ROLL_NT(M, O, 0); break;                        \
@@ -807,7 +842,8 @@ int gbl_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_o
     else GBL_ROLL(false, false)
 #undef GBL_ROLL
 #undef GBL_ROLL_NT
-    GBL_LAUNCHED("gbl_rollout");
+#undef GBL_ROLL_K
+    GBL_LAUNCHED("gbl_rollout");  // (also gbl_rollout_at)
 }
 
 int gbl_decode_obs(const int8_t *obs, int8_t *state, int8_t *to_move, int64_t n, void *stream)
@@ -845,12 +881,12 @@ int greedy_waves(int depth)
 void launch_greedy(int waves, const Geometry &g, hipStream_t stream, const int8_t *state, const int8_t *to_move,
                    const int8_t *mask, const int8_t *hist, int depth, int32_t *action_out, int8_t *cand_mask_out,
                    int8_t *fallback_out, int64_t n, int8_t *hist_rw, int32_t *final_out, uint64_t seed,
-                   uint64_t env_base, uint32_t call)
+                   uint64_t env_base, uint32_t call, const uint32_t *call_dev = nullptr)
 {
 #define GBL_GREEDY(W)                                                                                            \
     hipLaunchKernelGGL(k_greedy<W>, dim3(g.grid), dim3(64 * W), 0, stream, state, to_move, mask, hist, depth,      \
                        action_out, cand_mask_out, fallback_out, n, g.ntiles, hist_rw, final_out, seed, env_base, \
-                       call)
+                       call, call_dev)
     if (waves >= 4) GBL_GREEDY(4);
     else if (waves == 2) GBL_GREEDY(2);
     else GBL_GREEDY(1);
@@ -874,12 +910,20 @@ int gbl_greedy_act(const int8_t *state, const int8_t *to_move, const int8_t *mas
                    uint64_t seed, uint64_t env_base, uint32_t call, int32_t *action_out, int32_t *chosen_out,
                    int8_t *cand_mask_out, int8_t *fallback_out, int64_t n, void *stream)
 {
+    return gbl_greedy_act_at(state, to_move, mask, hist, depth, seed, env_base, call, nullptr, action_out, chosen_out,
+                             cand_mask_out, fallback_out, n, stream);
+}
+
+int gbl_greedy_act_at(const int8_t *state, const int8_t *to_move, const int8_t *mask, int8_t *hist, int depth,
+                      uint64_t seed, uint64_t env_base, uint32_t call, const uint32_t *call_dev, int32_t *action_out,
+                      int32_t *chosen_out, int8_t *cand_mask_out, int8_t *fallback_out, int64_t n, void *stream)
+{
     GBL_CHECK_N(n);
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(hist, "hist"); GBL_NEED(action_out, "action_out");
     if (depth < 1 || depth > 3) return fail(GBL_ERR_ARG, "depth must be 1, 2 or 3");
     GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask, "mask"); GBL_ALIGNED(cand_mask_out, "cand_mask_out");
     launch_greedy(greedy_waves(depth), geometry(n), (hipStream_t)stream, state, to_move, mask, nullptr, depth, chosen_out,
-                  cand_mask_out, fallback_out, n, hist, action_out, seed, env_base, call);
+                  cand_mask_out, fallback_out, n, hist, action_out, seed, env_base, call, call_dev);
     GBL_LAUNCHED("gbl_greedy_act");
 }
 

@@ -34,7 +34,7 @@ class GreedyGobbletPolicy:
             raise nat.GobbletHipError("GreedyGobbletPolicy needs a GPU device (there is no CPU fallback)")
         self._lib = nat.lib()
         self.prev_actions = None  # int8 (N, 2, 3) on device: last three own actions per agent, -1 = none
-        self._calls = 0
+        self._calls, self._calls_dev = 0, None  # call index (keys the fallback draw); see device_calls()
         # outputs of the last call (device tensors): chosen-or--1, candidate set, fallback flag
         self.last_chosen = self.last_candidates = self.last_fallback = None
 
@@ -47,6 +47,21 @@ class GreedyGobbletPolicy:
 
     def reset_history(self):
         self.prev_actions = None
+
+    def device_calls(self, enable: bool = True) -> None:
+        """Keep the call index in device memory (like ``BatchedGobblet.device_ply``): a captured hipGraph that
+        ends with ``advance_calls()`` then draws fresh fallback actions on every replay."""
+        if enable and self._calls_dev is None:
+            self._calls_dev = torch.full((1,), self._calls, dtype=torch.int32, device=self.device)
+            self._calls = 0
+        elif not enable and self._calls_dev is not None:
+            self._calls, self._calls_dev = self._calls + int(self._calls_dev.item()), None
+
+    def advance_calls(self) -> None:
+        if self._calls_dev is not None and self._calls:
+            nat.check(self._lib.gbl_counter_add(self._calls_dev.data_ptr(), self._calls, self._stream()),
+                      "gbl_counter_add")
+            self._calls = 0
 
     def compute_actions(self, obs, mask=None) -> torch.Tensor:
         """obs: int8 (N,3,3,13); mask: int8 (N,54) or None (derive the legal mask from the board)."""
@@ -70,10 +85,10 @@ class GreedyGobbletPolicy:
         fb = torch.empty(n, dtype=torch.int8, device=self.device)
         # one launch: the search, the :211-217 fallback draw (uniform over actions_depth1, keyed by seed / board /
         # call index) and the :219 history append for the acting agent
-        nat.check(self._lib.gbl_greedy_act(state.data_ptr(), to_move.data_ptr(), nat.ptr(mask),
-                                           self.prev_actions.data_ptr(), self.depth, self.seed, 0, self._calls,
-                                           out.data_ptr(), act.data_ptr(), cand.data_ptr(), fb.data_ptr(), n,
-                                           self._stream()), "gbl_greedy_act")
+        nat.check(self._lib.gbl_greedy_act_at(state.data_ptr(), to_move.data_ptr(), nat.ptr(mask),
+                                              self.prev_actions.data_ptr(), self.depth, self.seed, 0, self._calls,
+                                              nat.ptr(self._calls_dev), out.data_ptr(), act.data_ptr(),
+                                              cand.data_ptr(), fb.data_ptr(), n, self._stream()), "gbl_greedy_act")
         self.last_chosen, self.last_candidates, self.last_fallback = act, cand, fb
         self._calls += 1
         return out

@@ -54,12 +54,50 @@ class BatchedGobblet:
         self.turn = torch.zeros(n, dtype=torch.int32, device=dev) if track_turn else None
         # rollout tallies, striped (include/gobblet_hip.h); totals via the ``counters`` property
         self._counters = torch.zeros((nat.COUNTER_STRIPES, nat.COUNTER_STRIDE), dtype=torch.int64, device=dev)
-        self.ply = 0  # lockstep ply counter (keys the sampler)
+        self._ply, self._ply_dev = 0, None  # lockstep ply counter (keys the sampler), see ``ply`` / ``device_ply``
         self.reset()
 
     @property
     def squares(self) -> torch.Tensor:
         return self.board.squares
+
+    # -- the sampler's ply index ----------------------------------------------------------------------
+    @property
+    def ply(self) -> int:
+        """Plies played in lockstep since reset; keys the masked-random sampler together with seed and board id."""
+        return self._ply + (int(self._ply_dev.item()) if self._ply_dev is not None else 0)
+
+    @ply.setter
+    def ply(self, value: int) -> None:
+        if self._ply_dev is not None:
+            self._ply_dev.fill_(int(value))
+            self._ply = 0
+        else:
+            self._ply = int(value)
+
+    def device_ply(self, enable: bool = True) -> None:
+        """Keep the ply index in device memory so that a captured hipGraph draws fresh random numbers on
+        every replay: a kernel then uses (plies enqueued since the last ``advance_ply()``) + a device-resident
+        base, and ``advance_ply()`` -- the last call of the captured sequence -- adds the former to the latter::
+
+            env.device_ply()
+            with torch.cuda.graph(g):
+                for _ in range(K):
+                    env.rollout(1)
+                env.advance_ply()
+            g.replay(); g.replay()   # 2K different plies
+
+        Eager calls work unchanged in this mode."""
+        if enable and self._ply_dev is None:
+            self._ply_dev = torch.full((1,), self._ply, dtype=torch.int32, device=self.device)
+            self._ply = 0
+        elif not enable and self._ply_dev is not None:
+            self._ply, self._ply_dev = self.ply, None
+
+    def advance_ply(self) -> None:
+        if self._ply_dev is not None and self._ply:
+            nat.check(self._lib.gbl_counter_add(self._ply_dev.data_ptr(), self._ply, self._stream()), "gbl_counter_add")
+            self._ply = 0
 
     @property
     def counters(self) -> torch.Tensor:
@@ -148,7 +186,7 @@ class BatchedGobblet:
                                      a.data_ptr(), self.winner.data_ptr(), self.rewards.data_ptr(),
                                      self.action_mask.data_ptr(), nat.ptr(self.observation), nat.ptr(self.turn), n,
                                      self.illegal_mode, int(self.auto_reset), self._stream()), "gbl_step")
-        self.ply += 1
+        self._ply += 1
         return self.observe(), self.rewards, self.done, self.winner
 
     # -- masked-uniform sampling (examples/example_basic.py:58-61) ----------------------------------------
@@ -156,8 +194,9 @@ class BatchedGobblet:
         """One uniformly random legal action per board from the current action_mask, keyed by
         (seed, env_base + b, ply)."""
         out = self.actions if out is None else out
-        nat.check(self._lib.gbl_sample(self.action_mask.data_ptr(), out.data_ptr(), self.num_envs, self.seed,
-                                       self.env_base, self.ply, self._stream()), "gbl_sample")
+        nat.check(self._lib.gbl_sample_at(self.action_mask.data_ptr(), out.data_ptr(), self.num_envs, self.seed,
+                                          self.env_base, self._ply, nat.ptr(self._ply_dev), self._stream()),
+                  "gbl_sample")
         return out
 
     def rollout(self, plies: int = 1, count: bool = False):
@@ -167,12 +206,12 @@ class BatchedGobblet:
         microseconds per launch).  ``rollout(1)`` is one ply of the benchmark pipeline with every
         output materialised."""
         n = self.num_envs
-        nat.check(self._lib.gbl_rollout(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
-                                        self.actions.data_ptr(), self.winner.data_ptr(), self.rewards.data_ptr(),
-                                        self.action_mask.data_ptr(), nat.ptr(self.observation), n, self.seed,
-                                        self.env_base, self.ply, int(plies), self.illegal_mode,
-                                        self._counters.data_ptr() if count else None, nat.ptr(self.turn),
-                                        self._stream()),
+        nat.check(self._lib.gbl_rollout_at(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
+                                           self.actions.data_ptr(), self.winner.data_ptr(), self.rewards.data_ptr(),
+                                           self.action_mask.data_ptr(), nat.ptr(self.observation), n, self.seed,
+                                           self.env_base, self._ply, nat.ptr(self._ply_dev), int(plies),
+                                           self.illegal_mode, self._counters.data_ptr() if count else None,
+                                           nat.ptr(self.turn), self._stream()),
                   "gbl_rollout")
-        self.ply += int(plies)
+        self._ply += int(plies)
         return self.observe(), self.rewards, self.done, self.winner

@@ -176,6 +176,22 @@ int gbl_greedy_act(const int8_t *state, const int8_t *to_move, const int8_t *mas
                    uint64_t seed, uint64_t env_base, uint32_t call, int32_t *action_out, int32_t *chosen_out,
                    int8_t *cand_mask_out, int8_t *fallback_out, int64_t n, void *stream);
 
+/* Graph-replay forms of the three entry points that draw random numbers.  seed / env_base / ply travel by value,
+ * so a captured hipGraph would replay the same draws; here the index is  ply + *ply_dev  (call + *call_dev) with
+ * the base in device memory, and gbl_counter_add -- one more node at the end of the captured sequence -- moves
+ * it on, so every replay draws afresh.  A NULL pointer makes them the by-value forms. */
+int gbl_sample_at(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply,
+                  const uint32_t *ply_dev, void *stream);
+int gbl_rollout_at(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_out, int8_t *winner_out,
+                   int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, uint64_t seed, uint64_t env_base,
+                   uint32_t ply0, const uint32_t *ply_dev, uint32_t plies, int illegal_mode, int64_t *counters,
+                   int32_t *turn, void *stream);
+int gbl_greedy_act_at(const int8_t *state, const int8_t *to_move, const int8_t *mask, int8_t *hist, int depth,
+                      uint64_t seed, uint64_t env_base, uint32_t call, const uint32_t *call_dev, int32_t *action_out,
+                      int32_t *chosen_out, int8_t *cand_mask_out, int8_t *fallback_out, int64_t n, void *stream);
+/* *counter += by, enqueued on the stream (device uint32). */
+int gbl_counter_add(uint32_t *counter, uint32_t by, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,12 +59,12 @@ def main():
         shutil.copy(os.path.join(SRC, name + ".json"), os.path.join(dst, "final_" + name + ".json"))
     for name in ("bench_c3_262144_boards", "bench_c2_4096_boards", "playouts"):
         shutil.copy(os.path.join(SRC, name + ".json"), os.path.join(dst, name + ".json"))
-    for mode, kernel in (("fused", "k_rollout<true, true, 1>"), ("step", "k_step<true, true, 1>")):
+    for mode, kernel in (("fused", "k_rollout<true, true, 1, false>"), ("step", "k_step<true, true, 1>")):
         out = "final_%s_kernel_stats.csv" % ("fused" if mode == "fused" else "stepmode")
         open(os.path.join(dst, out), "w").write(capture(rocpd_summary.stats, os.path.join(SRC, mode + "_stats", "p_results.db")))
     traffic = {}
     rows = ["kernel,counter,dispatches,mean_value_KB"]
-    for mode, kernel in (("fused", "k_rollout<true, true, 1>"), ("step", "k_step<true, true, 1>")):
+    for mode, kernel in (("fused", "k_rollout<true, true, 1, false>"), ("step", "k_step<true, true, 1>")):
         kb = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             kb[c], n = counter_mean(os.path.join(SRC, f"{mode}_pmc_{c}", "p_results.db"), kernel, c)
@@ -79,7 +79,7 @@ def main():
     open(os.path.join(dst, "final_pmc_summary.csv"), "w").write("\n".join(rows) + "\n")
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     sq = "# k_rollout<true, true, 1>, 2^20 boards, one ply per launch; rocprofv3 --pmc (two passes), per dispatch\n"
-    sq += capture(rocpd_summary.counters, "k_rollout<true, true, 1>", [os.path.join(SRC, "fused_sq1", "p_results.db"),
+    sq += capture(rocpd_summary.counters, "k_rollout<true, true, 1, false>", [os.path.join(SRC, "fused_sq1", "p_results.db"),
                                                                      os.path.join(SRC, "fused_sq2", "p_results.db")])
     open(os.path.join(dst, "final_fused_sq_counters.csv"), "w").write(sq)
     print(open(os.path.join(dst, "final_pmc_summary.csv")).read())

@@ -644,3 +644,52 @@ def test_example_scripts_run(G):
             assert r.stdout.count("Reward:") == 2 and "Reward: 1" in r.stdout and "Reward: -1" in r.stdout
         else:
             assert "env-steps/s" in r.stdout and "games finished" in r.stdout
+
+
+def test_graph_replay_draws_fresh_plies(G):
+    """A captured hipGraph of K rollout plies + advance_ply(), replayed R times, plays K*R DIFFERENT plies: the
+    ply index lives on the device (gbl_rollout_at / gbl_counter_add).  Compared with the oracle's K*R plies; the
+    same for sample + step, and for greedy policy steps (fallback draws keyed by a device-resident call index)."""
+    n, K, R, seed, base = 3000, 3, 4, 11, 500
+    env = G.BatchedGobblet(n, DEV, auto_reset=True, seed=seed, env_base=base)
+    env.rollout(2)                       # some history first: the device counter starts at 2
+    env.device_ply()
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        env.rollout(1); env.advance_ply()   # warm-up on the side stream (ply 2)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            for _ in range(K):
+                env.rollout(1)
+            env.advance_ply()
+        for _ in range(R):
+            g.replay()
+    torch.cuda.current_stream().wait_stream(s_)
+    torch.cuda.synchronize()
+    s, tm, dn = oracle.batch_reset(n)
+    o = oracle.batch_rollout(s, tm, dn, seed, base, 0, 3 + K * R)
+    assert env.ply == 3 + K * R
+    assert np.array_equal(npy(env.squares), s) and np.array_equal(npy(env.action_mask), o["mask"])
+    assert np.array_equal(npy(env.actions), o["actions"]) and np.array_equal(npy(env.observation), o["obs"])
+    # eager calls in device mode, then back to the host counter: the stream of draws just continues
+    env.step(env.sample_actions())
+    env.device_ply(False)
+    env.rollout(2)
+    a = oracle.batch_sample(oracle.batch_legal_mask(s, tm), seed, base, 3 + K * R)
+    oracle.batch_step(s, tm, dn, a, auto_reset=True)
+    oracle.batch_rollout(s, tm, dn, seed, base, 4 + K * R, 2)
+    assert env.ply == 6 + K * R and np.array_equal(npy(env.squares), s)
+    # greedy policy steps: the call index on the device
+    pol = G.GreedyGobbletPolicy(depth=2, seed=3, device=DEV)
+    pol.device_calls()
+    st, who = env.squares.clone(), env.to_move.clone()
+    outs = []
+    for _ in range(3):
+        outs.append(npy(pol.compute_actions_from_state(st, who)).copy())
+        pol.advance_calls()
+    hist = np.full((n, 2, 3), -1, np.int8)
+    for call in range(3):
+        og = oracle.batch_greedy_act(npy(st), npy(who), hist, 3, 0, call, depth=2)
+        assert np.array_equal(outs[call], og[0]), call
+    assert np.array_equal(npy(pol.prev_actions), hist)
