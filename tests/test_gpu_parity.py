@@ -636,7 +636,9 @@ def test_example_scripts_run(G):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     runs = [["examples/example_basic.py", "--seed", "3", "--render_mode", "text"],
             ["examples/example_batched.py", "--boards", "65536", "--plies", "40", "--policy", "random"],
-            ["examples/example_batched.py", "--boards", "4096", "--plies", "12", "--policy", "greedy"]]
+            ["examples/example_batched.py", "--boards", "4096", "--plies", "12", "--policy", "greedy"],
+            ["examples/example_batched.py", "--boards", "65536", "--plies", "40", "--policy", "random", "--graph", "8"],
+            ["examples/example_batched.py", "--boards", "4096", "--plies", "12", "--policy", "greedy", "--graph", "4"]]
     for cmd in runs:
         r = subprocess.run([sys.executable] + cmd, cwd=root, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
