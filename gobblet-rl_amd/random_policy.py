@@ -16,7 +16,21 @@ class RandomAdmissiblePolicy:
         if self.device.type != "cuda":
             raise nat.GobbletHipError("RandomAdmissiblePolicy needs a GPU device (there is no CPU fallback)")
         self._lib = nat.lib()
-        self._calls = 0
+        self._calls, self._calls_dev = 0, None
+
+    def device_calls(self, enable: bool = True) -> None:
+        """Call index in device memory, for hipGraph replay (see ``BatchedGobblet.device_ply``)."""
+        if enable and self._calls_dev is None:
+            self._calls_dev = torch.full((1,), self._calls, dtype=torch.int32, device=self.device)
+            self._calls = 0
+        elif not enable and self._calls_dev is not None:
+            self._calls, self._calls_dev = self._calls + int(self._calls_dev.item()), None
+
+    def advance_calls(self) -> None:
+        if self._calls_dev is not None and self._calls:
+            nat.check(self._lib.gbl_counter_add(self._calls_dev.data_ptr(), self._calls,
+                                                nat.current_stream(self.device)), "gbl_counter_add")
+            self._calls = 0
 
     def compute_actions(self, obs_batch, **kwargs) -> torch.Tensor:
         """obs_batch: {"action_mask": (N,54) int8, ...} (RLlib-style) or the mask tensor itself -> int32 (N,)."""
@@ -24,7 +38,7 @@ class RandomAdmissiblePolicy:
         mask = torch.as_tensor(mask).to(device=self.device, dtype=torch.int8).reshape(-1, nat.ACTIONS).contiguous()
         n = mask.shape[0]
         out = torch.empty(n, dtype=torch.int32, device=self.device)
-        nat.check(self._lib.gbl_sample(mask.data_ptr(), out.data_ptr(), n, self.seed, self.env_base, self._calls,
-                                       nat.current_stream(self.device)), "gbl_sample")
+        nat.check(self._lib.gbl_sample_at(mask.data_ptr(), out.data_ptr(), n, self.seed, self.env_base, self._calls,
+                                          nat.ptr(self._calls_dev), nat.current_stream(self.device)), "gbl_sample")
         self._calls += 1
         return out
