@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the batched Gobblet hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--boards B] [--mode fused|step] [--graph 0|1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--boards B | --boards-per-gpu B]
+                    [--mode fused|step] [--graph 0|1] [--no-obs] [--no-configs] [--no-cpu-baseline]
 
 One "step" = one lockstep ply of the benchmark pipeline over this rank's shard of boards:
     mode fused (default): gbl_rollout(plies=1) -- masked-uniform sampling + raw_env.step + observe
@@ -9,22 +10,27 @@ One "step" = one lockstep ply of the benchmark pipeline over this rank's shard o
                  every ply are materialised in HBM (a consumer can read them after each launch).
     mode step  : gbl_sample (action from the mask buffer) + gbl_step (externally supplied
                  actions: the drop-in form of raw_env.step + observe) -- two launches per ply.
-By default the K timed plies are replayed as one hipGraph (captured and instantiated before the
-timed region; every kernel node carries its own ply index); --graph 0 launches eagerly.
-Workload: 2^20 boards per GPU, all reset, 64 warm-up plies of masked-random
-play with auto-reset (stationary mix of game phases), then K timed plies; synthetic data, RNG
-keyed (seed=0, global board id, ply) so results do not depend on the number of GPUs.  Boards shard
-by contiguous global index, one shard per rank, no collective on the step path ("weak" scaling:
-the per-GPU shard is fixed).  For N>1 launch with torchrun (the driver does), one rank per GPU.
+Workload (BASELINE.json metric / BASELINE.md C4): 2^20 boards IN TOTAL, sharded by contiguous global index
+over the N GPUs (131 072 per GPU at N = 8; "strong" scaling), all reset, W warm-up plies of masked-random play
+with auto-reset (stationary mix of game phases), then K timed plies; synthetic data, RNG keyed (seed=0, global
+board id, ply) so results do not depend on N.  No collective on the step path: RCCL carries the barriers around
+the timed region and one MAX-reduce of the elapsed time.  --boards-per-gpu B fixes the per-GPU shard instead
+("weak" scaling).  For N>1 launch with torchrun (the driver does), one rank per GPU.
+By default the K timed plies are replayed as one hipGraph whose kernel nodes take the ply index from a
+device-resident counter (gbl_rollout_at + gbl_counter_add), so the graph is replayed once UNTIMED first (its
+first launch carries one-off costs) and the timed replay still plays K fresh plies; --graph 0 launches eagerly.
 
 Prints ONE JSON line on rank 0 (see the task's bench contract) including
-    roofline     -- dominant kernel (k_step / k_rollout): algorithmic 234 B per env-step
-                     x boards per launch / mean launch duration from HIP events
-                    recorded on the launch stream inside the timed region, vs 8 TB/s HBM peak
-    cpu_baseline -- the CPU oracle (a C port of the reference algorithm; kind "port") doing the
-                    same pipeline on the host cores, on a bounded sample (rank 0, N=1 only).
+    roofline     -- dominant kernel (k_rollout / k_step): algorithmic 234 B per env-step x boards
+                    per launch / mean launch duration from HIP events on the launch stream, vs 8 TB/s HBM peak
+    cpu_baseline -- the CPU oracle (a C port of the reference algorithm; kind "port") doing the same pipeline
+                    on the host cores, on a bounded sample (rank 0, N=1 only)
+    configs      -- (N=1 only) the other sizes BASELINE.json names, each a short run with its own roofline:
+                    4 096 and 262 144 boards, the 131 072-board shard of C4 at 8 GPUs, 2^22 boards (beyond the
+                    Infinity Cache), MASK_ONLY at 2^20, and config 5 (65 536 boards x depth-2 greedy).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -37,6 +43,8 @@ if ROOT not in sys.path:
 ALGO_BYTES_FULL = 234      # reads 33 + writes 201 per env-step
 ALGO_BYTES_MASK_ONLY = 117  # same without the 117-byte observation
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; max shader clock (MI355X_MICROARCH.md)
+TOTAL_BOARDS = 1 << 20
 
 
 def parse():
@@ -44,14 +52,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--boards", type=int, default=1 << 20, help="boards per GPU (weak scaling, the default)")
-    ap.add_argument("--total-boards", type=int, default=0,
-                    help="fixed TOTAL board count split over the GPUs instead (strong scaling, e.g. 1048576)")
+    ap.add_argument("--boards", "--total-boards", dest="boards", type=int, default=TOTAL_BOARDS,
+                    help="TOTAL boards, split over the GPUs (strong scaling: BASELINE.md C4)")
+    ap.add_argument("--boards-per-gpu", type=int, default=0, help="fixed per-GPU shard instead (weak scaling)")
     ap.add_argument("--mode", choices=["step", "fused"], default="fused")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the K timed plies as one hipGraph; 0: eager launches")
     ap.add_argument("--no-obs", action="store_true",
                     help="MASK_ONLY variant (BASELINE.md: 117 algorithmic bytes per env-step): no observation tensor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the sub-records of the other BASELINE configs")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the multi-rank path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
@@ -106,6 +115,156 @@ def cpu_baseline(boards, warmup, target_s):
             "value_1core": n1 * 4 / d1}
 
 
+def kernel_source_hash():
+    """Identifies the kernel sources a committed profile was taken from (profiles/pmc_traffic.json records it)."""
+    h = hashlib.sha256()
+    for f in ("gobblet_hip.hip", "gobblet_device.h"):
+        h.update(open(os.path.join(ROOT, "gobblet-rl_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_counter(key, field):
+    """A per-launch counter value from profiles/pmc_traffic.json (rocprofv3 --pmc passes of this very command,
+    committed with the hash of the kernel sources they were measured on), or (None, reason) when there is none
+    or the kernels have changed since."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path)).get(key)
+    except Exception:  # noqa: BLE001
+        return None, "profiles/pmc_traffic.json missing"
+    if not rec or field not in rec:
+        return None, f"no committed counters for {key}"
+    if rec.get("kernel_source_hash") != kernel_source_hash():
+        return None, f"stale: {rec.get('source', 'profiles/pmc_traffic.json')} was measured on other kernel sources"
+    return rec[field], f"{rec.get('source', 'profiles/pmc_traffic.json')} @ kernel sources {rec['kernel_source_hash']}"
+
+
+class Pipeline:
+    """One shard of boards and its per-ply launch sequence, with the ply index in device memory."""
+
+    def __init__(self, G, torch, boards, env_base, dev, no_obs=False, mode="fused"):
+        self.G, self.torch, self.nat, self.lib = G, torch, G._native, G._native.lib()
+        self.boards, self.dev, self.mode, self.no_obs = boards, dev, mode, no_obs
+        env = self.env = G.BatchedGobblet(boards, dev, illegal_mode="noop", auto_reset=True, seed=0, env_base=env_base,
+                                          with_observation=not no_obs)
+        self.P = dict(sq=env.squares.data_ptr(), tm=env.to_move.data_ptr(), dn=env.done.data_ptr(),
+                      ac=env.actions.data_ptr(), wi=env.winner.data_ptr(), rw=env.rewards.data_ptr(),
+                      mk=env.action_mask.data_ptr(), ob=None if no_obs else env.observation.data_ptr())
+        self.ctr = torch.zeros(1, dtype=torch.int32, device=dev)  # plies played so far (keys the sampler)
+        self.algo_bytes = ALGO_BYTES_MASK_ONLY if no_obs else ALGO_BYTES_FULL
+
+    def enqueue(self, k, stream, ev=None):
+        """Ply number (counter + k) on `stream`; ev = (start, stop) events bracketing the dominant kernel."""
+        P, lib, env, n = self.P, self.lib, self.env, self.boards
+        if self.mode == "step":
+            rc = lib.gbl_sample_at(P["mk"], P["ac"], n, env.seed, env.env_base, k, self.ctr.data_ptr(), stream)
+            self.nat.check(rc, "gbl_sample_at")
+            if ev:
+                ev[0].record()
+            rc = lib.gbl_step(P["sq"], P["tm"], P["dn"], P["ac"], P["wi"], P["rw"], P["mk"], P["ob"], None, n, 0, 1, stream)
+        else:
+            if ev:
+                ev[0].record()
+            rc = lib.gbl_rollout_at(P["sq"], P["tm"], P["dn"], P["ac"], P["wi"], P["rw"], P["mk"], P["ob"], n, env.seed,
+                                    env.env_base, k, self.ctr.data_ptr(), 1, 0, None, None, stream)
+        self.nat.check(rc, "ply launch")
+        if ev:
+            ev[1].record()
+
+    def advance(self, k, stream):
+        self.nat.check(self.lib.gbl_counter_add(self.ctr.data_ptr(), k, stream), "gbl_counter_add")
+
+    def eager(self, k, events=None):
+        s = self.nat.current_stream(self.dev)
+        for i in range(k):
+            self.enqueue(i, s, events[i] if events else None)
+        self.advance(k, s)
+
+    def capture(self, k):
+        torch = self.torch
+        g = torch.cuda.CUDAGraph()
+        # thread_local: calls made by other threads of this process (e.g. RCCL's watchdog polling its
+        # events in the multi-GPU runs) must not invalidate the capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            cs = self.nat.current_stream(self.dev)
+            for i in range(k):
+                self.enqueue(i, cs)
+            self.advance(k, cs)
+        return g
+
+    def events(self, k):
+        E = self.torch.cuda.Event
+        return [(E(enable_timing=True), E(enable_timing=True)) for _ in range(k)]
+
+    def kernel_roofline(self, mean_kernel_s, launches, timing):
+        achieved = self.algo_bytes * self.boards / mean_kernel_s / 1e9
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": ("k_step" if self.mode == "step" else "k_rollout (plies=1)")
+                          + ("<mask>" if self.no_obs else "<mask,obs>"),
+                "algorithmic_bytes_per_env_step": self.algo_bytes, "env_steps_per_launch": self.boards,
+                "mean_launch_us": mean_kernel_s * 1e6, "launches_timed": launches, "timing": timing}
+
+
+def short_run(G, torch, dev, boards, K, W, no_obs=False):
+    """A sub-record: W warm-up plies, K plies as a hipGraph replayed once untimed, then timed between HIP events."""
+    p = Pipeline(G, torch, boards, 0, dev, no_obs=no_obs)
+    p.eager(W)
+    g = p.capture(K)
+    g.replay()
+    torch.cuda.synchronize(dev)
+    a, b = p.events(1)[0]
+    a.record()
+    g.replay()
+    b.record()
+    torch.cuda.synchronize(dev)
+    s = a.elapsed_time(b) / 1e3
+    rec = {"workload": f"{boards} boards x 1 GPU, masked-random actions, auto-reset, "
+                       f"{'MASK_ONLY' if no_obs else 'FULL'} outputs every ply, {K} plies as one hipGraph",
+           "value": boards * K / s, "unit": "env-steps/s", "us_per_step": s / K * 1e6,
+           "roofline": p.kernel_roofline(s / K, K, "HIP events around the graph replay / K (includes kernel boundaries)")}
+    del g, p
+    return rec
+
+
+def greedy_run(G, torch, dev, boards=65536, iters=50):
+    """BASELINE config 5: `boards` positions of the stationary masked-random mix x depth-2 greedy lookahead,
+    one gbl_greedy launch per call.  Bound: integer VALU issue, not HBM (144 B of I/O per decision)."""
+    nat, L = G._native, G._native.lib()
+    env = G.BatchedGobblet(boards, dev, auto_reset=True, seed=0)
+    env.rollout(64)
+    act = torch.empty(boards, dtype=torch.int32, device=dev)
+    cm = torch.empty((boards, 54), dtype=torch.int8, device=dev)
+    fb = torch.empty(boards, dtype=torch.int8, device=dev)
+
+    def run():
+        nat.check(L.gbl_greedy(env.squares.data_ptr(), env.to_move.data_ptr(), None, None, 2, act.data_ptr(),
+                               cm.data_ptr(), fb.data_ptr(), boards, nat.current_stream(dev)), "gbl_greedy")
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        run()
+    b.record()
+    torch.cuda.synchronize(dev)
+    s = a.elapsed_time(b) / 1e3 / iters
+    insts, src = committed_counter(f"greedy:{boards}", "SQ_INSTS_VALU")
+    roof = {"bound": "valu", "unit": "wave64 VALU instructions/s", "peak": SIMDS * CLOCK_GHZ * 1e9 / 4,
+            "achieved": None, "frac": None, "kernel": "k_greedy (depth 2)", "mean_launch_us": s * 1e6,
+            "launches_timed": iters, "timing": "HIP events around back-to-back eager launches / count",
+            "valu_instructions_per_launch": insts, "valu_instructions_source": src,
+            "note": "frac = VALU-busy share of the SIMDs: executed VALU instructions (rocprofv3 SQ_INSTS_VALU, committed "
+                    "profile) x 4 cycles / (1024 SIMDs x launch time x 2.4 GHz); HBM traffic is ~144 B per decision"}
+    if insts:
+        roof["achieved"] = insts / s
+        roof["frac"] = roof["achieved"] / roof["peak"]
+    return {"workload": f"{boards} boards (stationary masked-random mix, both movers, empty history) x depth-2 greedy "
+                        f"lookahead, one launch per call", "value": boards / s, "unit": "decisions/s",
+            "us_per_step": s * 1e6, "roofline": roof}
+
+
 def main():
     args = parse()
     import torch
@@ -128,62 +287,30 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # RCCL; used only for barriers + one MAX-reduce
+            dist.init_process_group("nccl", device_id=dev)  # RCCL; used only for barriers + small reductions of timings
         else:
             dist.init_process_group("gloo")
 
     import gobblet_rl_amd as G
 
-    if args.total_boards:
-        env_base, boards = G.shard_bounds(args.total_boards, world, rank)
+    if args.boards_per_gpu:
+        boards, env_base, total = args.boards_per_gpu, rank * args.boards_per_gpu, args.boards_per_gpu * world
     else:
-        boards, env_base = args.boards, rank * args.boards
-    env = G.BatchedGobblet(boards, dev, illegal_mode="noop", auto_reset=True, seed=0, env_base=env_base,
-                           with_observation=not args.no_obs)
-    algo_bytes = ALGO_BYTES_MASK_ONLY if args.no_obs else ALGO_BYTES_FULL
+        env_base, boards = G.shard_bounds(args.boards, world, rank)
+        total = args.boards
     K, W = args.steps, args.warmup
-    lib, nat = G._native.lib(), G._native
-    P = dict(sq=env.squares.data_ptr(), tm=env.to_move.data_ptr(), dn=env.done.data_ptr(),
-             ac=env.actions.data_ptr(), wi=env.winner.data_ptr(), rw=env.rewards.data_ptr(),
-             mk=env.action_mask.data_ptr(), ob=None if args.no_obs else env.observation.data_ptr())
-
-    def enqueue_ply(ply, stream, ev=None):
-        """One ply of the pipeline on `stream`; ev = (start, stop) events bracketing the dominant kernel."""
-        if args.mode == "step":
-            lib.gbl_sample(P["mk"], P["ac"], boards, env.seed, env.env_base, ply, stream)
-            if ev:
-                ev[0].record()
-            rc = lib.gbl_step(P["sq"], P["tm"], P["dn"], P["ac"], P["wi"], P["rw"], P["mk"], P["ob"], None, boards, 0, 1,
-                              stream)
-        else:
-            if ev:
-                ev[0].record()
-            rc = lib.gbl_rollout(P["sq"], P["tm"], P["dn"], P["ac"], P["wi"], P["rw"], P["mk"], P["ob"], boards,
-                                 env.seed, env.env_base, ply, 1, 0, None, None, stream)
-        if ev:
-            ev[1].record()
-        return rc
-
-    # warm-up plies (untimed): decorrelate game phases, warm caches / code objects
-    for k in range(W):
-        nat.check(enqueue_ply(k, nat.current_stream(dev)), "warm-up")
+    p = Pipeline(G, torch, boards, env_base, dev, no_obs=args.no_obs, mode=args.mode)
+    p.eager(W)  # warm-up plies (untimed): decorrelate game phases, warm caches / code objects
     torch.cuda.synchronize(dev)
 
     graph = None
     if args.graph:
-        # the K timed plies as ONE hipGraph (every kernel node carries its own ply index);
-        # capture + instantiate happen here, outside the timed region; the replay is timed
-        graph = torch.cuda.CUDAGraph()
-        # thread_local: calls made by other threads of this process (e.g. RCCL's watchdog polling its
-        # events in the multi-GPU runs) must not invalidate the capture
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            cs = nat.current_stream(dev)
-            for k in range(K):
-                nat.check(enqueue_ply(W + k, cs), "capture")
+        graph = p.capture(K)
+        graph.replay()  # untimed: the first launch of an instantiated graph carries one-off costs
         torch.cuda.synchronize(dev)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))]
+        ev = p.events(1)
     else:
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        ev = p.events(K)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -193,76 +320,78 @@ def main():
         graph.replay()
         ev[0][1].record()
     else:
-        stream = nat.current_stream(dev)
-        for k in range(K):
-            rc = enqueue_ply(W + k, stream, ev[k])
-        nat.check(rc, "timed plies")
+        p.eager(K, ev)
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+
+    # dominant-kernel time for the roofline: HIP events on the launch stream
+    if graph is None:
+        mean_kernel_s = sum(a.elapsed_time(b) for a, b in ev) / K / 1e3
+        launches, timing = K, "HIP event pair around every launch of the dominant kernel"
+    elif args.mode == "fused":
+        mean_kernel_s = ev[0][0].elapsed_time(ev[0][1]) / K / 1e3
+        launches, timing = K, "HIP events around the graph replay / K (includes kernel boundaries)"
+    else:
+        # two kernels per ply in the graph: time gbl_step on its own with event pairs, eagerly, after the timed region
+        k2 = min(K, 64)
+        ev2 = p.events(k2)
+        p.eager(k2, ev2)
+        torch.cuda.synchronize(dev)
+        mean_kernel_s = sum(a.elapsed_time(b) for a, b in ev2) / k2 / 1e3
+        launches, timing = k2, "HIP event pair around each of %d eager gbl_step launches after the timed replay" % k2
+    per_rank_us = [mean_kernel_s * 1e6]
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        cpu = args.dist_backend != "nccl"
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if cpu else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    if graph is not None:
-        # events bracket the whole replay: K dominant-kernel launches (+ K sampler launches in step
-        # mode, which are subtracted pro rata by their share of algorithmic bytes: 58 of 292)
-        share = 1.0 if args.mode == "fused" else algo_bytes / (algo_bytes + 58.0)
-        mean_kernel_s = kernel_ms[0] * share / K / 1e3
-        launches = K
-    else:
-        launches = len(kernel_ms)
-        mean_kernel_s = sum(kernel_ms) / launches / 1e3
-    units_per_launch = boards
-    achieved = algo_bytes * units_per_launch / mean_kernel_s / 1e9
+        mine = torch.tensor([mean_kernel_s * 1e6], dtype=torch.float64, device="cpu" if cpu else dev)
+        allk = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allk, mine)
+        per_rank_us = [float(x.item()) for x in allk]
 
     if rank == 0:
-        all_boards = args.total_boards if args.total_boards else boards * world
-        total_steps = all_boards * K
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from a committed rocprofv3 --pmc run of this command
-            try:
-                tj = json.load(open(tpath))
-                key = f"{args.mode}{'-noobs' if args.no_obs else ''}:{boards}"
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
+        roof = p.kernel_roofline(mean_kernel_s, launches, timing)
+        roof["traffic"], roof["traffic_source"] = committed_counter(
+            f"{args.mode}{'-noobs' if args.no_obs else ''}:{boards}", "hbm_bytes_per_launch")
+        variant = "MASK_ONLY" if args.no_obs else "FULL"
         out = {
-            "metric": "env-steps/sec at 2^20 parallel boards per GPU, masked-random play, bit-exact mask/winner/obs",
-            "value": total_steps / elapsed,
+            "metric": "env-steps/sec at 2^20 parallel boards, 1/2/4/8 MI355X; bit-exact mask/winner",
+            "value": total * K / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if args.total_boards else "weak",
+            "scaling": "weak" if args.boards_per_gpu else "strong",
             "vs_baseline": None,
             "dtype": "int8",
             "data": "synthetic",
-            "config": {"workload": f"{boards} boards per GPU x {world} GPU(s), masked-random actions, auto-reset, "
-                                   f"{'MASK_ONLY' if args.no_obs else 'FULL'} outputs (state+mask{'' if args.no_obs else '+obs'}+winner+reward+done) every ply",
-                       "boards_per_gpu": boards, "total_boards": all_boards, "mode": args.mode,
+            "config": {"workload": f"{total} boards in total = {boards} per GPU x {world} GPU(s) (BASELINE.md C4), masked-random "
+                                   f"actions, auto-reset, {variant} outputs (state+mask{'' if args.no_obs else '+obs'}"
+                                   f"+winner+reward+done) every ply",
+                       "boards_per_gpu": boards, "total_boards": total, "mode": args.mode,
                        "launches_per_step": 2 if args.mode == "step" else 1,
-                       "sharding": f"contiguous board ranges, {world} shard(s), no collective on the step path"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("k_step" if args.mode == "step" else "k_rollout (plies=1)")
-                                   + ("<mask>" if args.no_obs else "<mask,obs>"),
-                         "algorithmic_bytes_per_env_step": algo_bytes,
-                         "env_steps_per_launch": units_per_launch,
-                         "mean_launch_us": mean_kernel_s * 1e6, "launches_timed": launches,
-                         "timing": ("HIP events around the graph replay / K (includes kernel boundaries)"
-                                    if graph is not None else "HIP event pair around every launch")},
+                       "sharding": f"contiguous board ranges, {world} shard(s), no collective on the step path",
+                       "launch": ("hipGraph replay of K plies (device-resident ply index; one untimed warm replay of "
+                                  "the same graph = K more untimed plies before the timed one)") if graph is not None else "eager",
+                       "kernel_us_per_rank": per_rank_us, "kernel_us_max": max(per_rank_us)},
+            "roofline": roof,
         }
+        if world == 1 and not args.no_configs:
+            cfg = {}
+            for name, n, k, noobs in (("c2_4096", 4096, 200, False), ("c3_262144", 262144, 200, False),
+                                      ("c4_shard_131072", 131072, 200, False), ("large_4194304", 1 << 22, 40, False),
+                                      ("maskonly_1048576", 1 << 20, 100, True)):
+                cfg[name] = short_run(G, torch, dev, n, k, W, no_obs=noobs)
+            cfg["c5_greedy_65536"] = greedy_run(G, torch, dev)
+            out["configs"] = cfg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(boards, W, args.cpu_seconds)
-        out["config"]["launch"] = "hipGraph replay of K plies" if graph is not None else "eager"
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -22,12 +22,20 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GOBBLET_HIP_LIB") or os.path.join(CSRC, "libgobblet_hip.so")
 SOURCES = [os.path.join(CSRC, "gobblet_hip.hip"), os.path.join(CSRC, "gobblet_device.h"),
            os.path.join(_HERE, "..", "include", "gobblet_hip.h")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mcode-object-version=5"]
+# -amdgpu-kernarg-preload-count: the first 16 dwords of a kernel's arguments arrive in SGPRs with the wave
+# launch (the kernels order their arguments for that), so a wavefront's first loads do not wait for a
+# kernel-argument fetch; firmware without the feature runs the compiler's fallback prologue
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mcode-object-version=5",
+               "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 OK, ERR_ARG, ERR_ALIGN, ERR_HIP = 0, -1, -2, -3
 ILLEGAL_NOOP, ILLEGAL_TERMINATE = 0, 1
 CELLS, ACTIONS, OBS_BYTES = 27, 54, 117
 COUNTER_STRIPES, COUNTER_STRIDE = 64, 16
+# gbl_board_eval record (include/gobblet_hip.h GBL_REC_*): field -> (byte offset, bytes)
+REC_BYTES = 432
+REC_FIELDS = {"squares": (0, 27), "winner": (28, 1), "flat": (32, 9), "covered": (44, 27), "mask0": (72, 54),
+              "mask1": (128, 54), "obs0": (184, 117), "obs1": (304, 117)}
 
 # every symbol include/gobblet_hip.h declares: (name, restype, argtypes)
 _vp, _i64, _u64, _u32, _int = C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_int
@@ -43,6 +51,7 @@ SIGNATURES = {
     "gbl_covered": (_int, [_vp, _vp, _i64, _vp]),
     "gbl_validate": (_int, [_vp, _vp, _i64, _vp]),
     "gbl_observe": (_int, [_vp, _vp, _int, _vp, _i64, _vp]),
+    "gbl_board_eval": (_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "gbl_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
     "gbl_sample": (_int, [_vp, _vp, _i64, _u64, _u64, _u32, _vp]),
     "gbl_rollout": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u64, _u64, _u32, _u32, _int, _vp, _vp, _vp]),

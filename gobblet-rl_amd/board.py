@@ -165,6 +165,26 @@ class BatchedBoard:
         nat.check(self._lib.gbl_covered(self._squares.data_ptr(), out.data_ptr(), n, self._stream()), "gbl_covered")
         return out
 
+    # -- everything the reference derives from a position, in one launch ---------------------------------
+    def evaluate(self, agent_index=None, action=None, out: torch.Tensor | None = None) -> dict:
+        """``gbl_board_eval``: optionally ``play_turn(agent_index, action)`` first, then per board the winner,
+        flat board, covered cells, both agents' legal masks and both observations -- one launch instead of seven.
+        Returns views into one int8 ``(N, 432)`` record tensor (``"record"``) keyed "squares", "winner", "flat",
+        "covered", "mask0", "mask1", "obs0", "obs1"."""
+        n = self.num_envs
+        rec = out if out is not None else torch.empty((n, nat.REC_BYTES), dtype=torch.int8, device=self.device)
+        a = ag = None
+        if action is not None:
+            a = _as_i32(action, n, self.device, "action")
+            ag = _as_i8(agent_index, n, self.device, "agent_index")
+        nat.check(self._lib.gbl_board_eval(self._squares.data_ptr(), nat.ptr(ag), nat.ptr(a), rec.data_ptr(), n,
+                                           self._stream()), "gbl_board_eval")
+        views = {k: rec[:, o:o + size] for k, (o, size) in nat.REC_FIELDS.items()}
+        views["winner"] = views["winner"][:, 0]
+        views["obs0"], views["obs1"] = views["obs0"].reshape(n, 3, 3, 13), views["obs1"].reshape(n, 3, 3, 13)
+        views["record"] = rec
+        return views
+
     # -- state contract (for callers that assign ``squares``) --------------------------------------------
     def validate(self, raise_on_error: bool = True) -> torch.Tensor:
         """int8 (N,) flags: bit 0 = a cell holds a value its level cannot hold, bit 1 = a piece number

@@ -400,9 +400,16 @@ __device__ __forceinline__ void obs_image_zero(uint32_t *img, int lane)
     if (REM && lane < REM) lv[lane + 64 * FULL] = z;
 }
 
+__device__ __forceinline__ void obs_scatter_row(uint8_t *row, const Planes &p, int observer);
+
 __device__ __forceinline__ void obs_scatter(uint32_t *img, int lane, const Planes &p, int observer)
 {
-    uint8_t *row = reinterpret_cast<uint8_t *>(img) + lane * kObs;
+    obs_scatter_row(reinterpret_cast<uint8_t *>(img) + lane * kObs, p, observer);
+}
+
+// row: the board's 117 observation bytes, zero on entry
+__device__ __forceinline__ void obs_scatter_row(uint8_t *row, const Planes &p, int observer)
+{
     uint32_t pos = p.nz & ~p.neg, ngv = p.nz & p.neg;
     uint32_t own = observer ? ngv : pos, opp = observer ? pos : ngv;
     uint32_t X[4] = {own & p.odd, own & ~p.odd, opp & p.odd, opp & ~p.odd};  // A B C D
@@ -414,7 +421,13 @@ __device__ __forceinline__ void obs_scatter(uint32_t *img, int lane, const Plane
     for (int ch = 0; ch < 12; ++ch) {
         int k = (ch % 6) / 2;
         uint32_t grp = (X[(ch < 6 ? 0 : 2) + (ch & 1)] >> (9 * k)) & 0x1FFu;
+#ifdef GBL_X_OBS_UNCOND
+        // branch-free: a piece that is not on the board writes a 0 to square 8 of its own channel, which
+        // no other piece can set
+        row[13 * __builtin_ctz(grp | 0x100u) + ch] = (uint8_t)(grp < 1u ? grp : 1u);
+#else
         if (grp) row[13 * __builtin_ctz(grp) + ch] = (uint8_t)one;
+#endif
     }
     if (observer) {
 #pragma unroll
@@ -479,10 +492,11 @@ __device__ __forceinline__ Draw4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 {
 #pragma unroll
     for (int rnd = 0; rnd < 10; ++rnd) {
-        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32: 2.9 cycles of SIMD time at full occupancy, the
+        // same as v_mul_hi_u32 or v_mul_lo_u32 alone -- scripts/microbench/valu_rates.hip) instead of two
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     return Draw4{{c0, c1, c2, c3}};
@@ -508,9 +522,13 @@ __device__ __forceinline__ uint32_t kth_bit32(uint32_t w, uint32_t k)
 // flight -- and the pick needs the mask.  One Philox block serves four consecutive plies of a board
 // (word ply & 3 of the block with counter ply >> 2): a kernel that plays several plies per launch
 // runs the generator once per four.
-__device__ __forceinline__ Draw4 draw_block(uint64_t seed, uint64_t env_id, uint32_t ply)
+// `stream` (counter word 3) separates the consumers of one (seed, board) pair: kStreamEnv = the masked-random
+// actions of gbl_sample / gbl_rollout, kStreamGreedy = the greedy policy's fallback draw (gbl_greedy_act).
+constexpr uint32_t kStreamEnv = 0u, kStreamGreedy = 1u;
+
+__device__ __forceinline__ Draw4 draw_block(uint64_t seed, uint64_t env_id, uint32_t ply, uint32_t stream = kStreamEnv)
 {
-    return philox4x32_10((uint32_t)env_id, (uint32_t)(env_id >> 32), ply >> 2, 0u, (uint32_t)seed,
+    return philox4x32_10((uint32_t)env_id, (uint32_t)(env_id >> 32), ply >> 2, stream, (uint32_t)seed,
                          (uint32_t)(seed >> 32));
 }
 
@@ -520,9 +538,9 @@ __device__ __forceinline__ uint32_t draw_word(const Draw4 &d, uint32_t ply)
     return (ply & 2u) ? hi : lo;
 }
 
-__device__ __forceinline__ uint32_t draw32(uint64_t seed, uint64_t env_id, uint32_t ply)
+__device__ __forceinline__ uint32_t draw32(uint64_t seed, uint64_t env_id, uint32_t ply, uint32_t stream = kStreamEnv)
 {
-    return draw_word(draw_block(seed, env_id, ply), ply);
+    return draw_word(draw_block(seed, env_id, ply, stream), ply);
 }
 
 __device__ __forceinline__ int pick54(uint64_t m, uint32_t r)

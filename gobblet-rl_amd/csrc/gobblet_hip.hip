@@ -33,14 +33,23 @@ struct Geometry {
     uint32_t grid;
 };
 
-inline Geometry geometry(int64_t n)
+// waves: wavefronts per workgroup, each with a tile of its own (the step kernels; see kStepWaves)
+inline Geometry geometry(int64_t n, int waves = 1)
 {
     Geometry g;
     g.ntiles = (n + kTile - 1) / kTile;
-    int64_t chunk = (g.ntiles + 7) / 8;
+    int64_t groups = (g.ntiles + waves - 1) / waves;
+    int64_t chunk = (groups + 7) / 8;
     g.grid = (uint32_t)(chunk * 8);
     return g;
 }
+
+// Wavefronts per workgroup of the step kernels.  The wavefronts of a workgroup are independent (a tile and an LDS
+// image each, no barrier); a workgroup is only the unit of dispatch.
+#ifndef GBL_WG_WAVES
+#define GBL_WG_WAVES 1
+#endif
+constexpr int kStepWaves = GBL_WG_WAVES;
 
 // Non-temporal store policy of the step kernels (see store_rows): stream the observation always, the
 // mask too once one ply's footprint exceeds the 256 MiB Infinity Cache.  GBL_NT_POLICY (environment,
@@ -67,11 +76,17 @@ struct Lane {
     bool valid;
 };
 
+template <int W = 1>
 __device__ __forceinline__ bool lane_setup(Lane &L, int64_t n, int64_t ntiles)
 {
-    L.tile = xcd_tile(blockIdx.x, ntiles);
+    if (W == 1) {
+        L.tile = xcd_tile(blockIdx.x, ntiles);
+        L.lane = threadIdx.x;
+    } else {  // W consecutive tiles per workgroup, one per wavefront
+        L.tile = xcd_tile(blockIdx.x, (ntiles + W - 1) / W) * W + (threadIdx.x >> 6);
+        L.lane = threadIdx.x & 63;
+    }
     if (L.tile >= ntiles) return false;
-    L.lane = threadIdx.x;
     int64_t left = n - L.tile * kTile;
     L.rows = left < kTile ? (int)left : kTile;
     L.valid = L.lane < L.rows;
@@ -211,14 +226,95 @@ __global__ __launch_bounds__(64) void k_observe(const int8_t *__restrict__ state
     tile_out<kObs, true>(obs + L.tile * (kTile * kObs), s_obs, L.lane, L.rows);
 }
 
+// gbl_board_eval: optional Board.play_turn, then one record per board with everything the reference derives
+// from the position (the seven board-level kernels above in one launch; the single-environment facade's ply).
+// Every field of a record starts on a dword, records are 432 bytes apart, so a lane writes its record into
+// the LDS image with plain dword stores; the observations are scattered sparsely as in k_observe.
+static_assert(GBL_REC_BYTES % 16 == 0 && GBL_REC_OBS1 + kObs <= GBL_REC_BYTES, "record layout");
+static_assert(GBL_REC_SQUARES % 4 == 0 && GBL_REC_WINNER % 4 == 0 && GBL_REC_FLAT % 4 == 0 && GBL_REC_COVERED % 4 == 0 &&
+              GBL_REC_MASK0 % 4 == 0 && GBL_REC_MASK1 % 4 == 0 && GBL_REC_OBS0 % 4 == 0 && GBL_REC_OBS1 % 4 == 0,
+              "record fields are dword aligned");
+
+__global__ __launch_bounds__(64) void k_board_eval(int8_t *__restrict__ state, const int8_t *__restrict__ agent,
+                                                   const int32_t *__restrict__ actions, int8_t *__restrict__ rec,
+                                                   int64_t n, int64_t ntiles)
+{
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    __shared__ uint32_t s_rec[image_words<GBL_REC_BYTES>()];
+    Lane L;
+    if (!lane_setup(L, n, ntiles)) return;
+    uint32_t r[7];
+    load_state(state, s_state, L, r);
+    Planes p = make_planes(r);
+    if (actions) {  // board.py:118-132
+        const int a = L.valid ? actions[L.b] : -1;
+        const int mover = L.valid ? (agent[L.b] != 0) : 0;
+        const uint64_t m = legal54(p, mover);
+        if ((uint32_t)a < (uint32_t)kActions && ((m >> (a & 63)) & 1ull)) apply_move(p, r, mover, (uint32_t)a);
+        wave_lds_fence();  // every lane has read its row before the image is rebuilt
+        row_stage<kCells>(s_state, L.lane, r);
+        wave_lds_fence();
+        tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
+    }
+    {  // zero the record image (padding bytes and the observation planes' zeros)
+        constexpr int NV = kTile * GBL_REC_BYTES / 16;
+        static_assert(NV % 64 == 0, "whole vectors per lane");
+        uint4 *lv = reinterpret_cast<uint4 *>(s_rec);
+        const uint4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NV / 64; ++i) lv[L.lane + 64 * i] = z;
+    }
+    wave_lds_fence();
+    uint32_t *row = s_rec + L.lane * (GBL_REC_BYTES / 4);
+    r[6] &= 0x00FFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) row[GBL_REC_SQUARES / 4 + j] = r[j];
+    row[GBL_REC_WINNER / 4] = (uint32_t)winner_of(p) & 0xFFu;
+    uint32_t f[3], c[7], m0[14], m1[14];
+    flat_row(p, r, f);
+    covered_row(p, c);
+    mask_row(legal54(p, 0), m0);
+    mask_row(legal54(p, 1), m1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) row[GBL_REC_FLAT / 4 + j] = f[j];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) row[GBL_REC_COVERED / 4 + j] = c[j];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+        row[GBL_REC_MASK0 / 4 + j] = m0[j];
+        row[GBL_REC_MASK1 / 4 + j] = m1[j];
+    }
+    obs_scatter_row(reinterpret_cast<uint8_t *>(row) + GBL_REC_OBS0, p, 0);
+    obs_scatter_row(reinterpret_cast<uint8_t *>(row) + GBL_REC_OBS1, p, 1);
+    wave_lds_fence();
+    // records out: 16-byte vectors, four in flight per lane (tile_out would hold all 27 in registers)
+    const int nv = L.rows * (GBL_REC_BYTES / 16);
+    uint4 *gv = reinterpret_cast<uint4 *>(rec + L.tile * (int64_t)(kTile * GBL_REC_BYTES));
+    const uint4 *lv = reinterpret_cast<const uint4 *>(s_rec);
+    for (int i0 = 0; i0 < nv; i0 += 256) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = lv[min(i0 + 64 * u + L.lane, nv - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + 64 * u + L.lane < nv) gv[i0 + 64 * u + L.lane] = v[u];
+    }
+}
+
 // Rows of a tile -> HBM through ONE LDS image that is reused.  On entry it holds the tile's state rows
 // where the load put them, already patched by the plies (ImageRow): they go out as they are.  Then the
 // image is free (the LDS reads of tile_out are issued before the next writes) for the 117-byte
 // observation rows, and after those for the mask rows.  7.5 KB of LDS per wave instead of 12.7 KB: more
 // resident waves per CU to cover the store latency.
-constexpr int kOutImageWords = image_words<kObs>();
-static_assert(image_words<kObs>() >= image_words<kActions>() && image_words<kObs>() >= image_words<kCells>(),
-              "the observation image is the largest");
+template <bool WITH_MASK, bool WITH_OBS>
+constexpr int out_image_words()
+{
+    return WITH_OBS ? image_words<kObs>() : WITH_MASK ? image_words<kActions>() : image_words<kCells>();
+}
+static_assert(image_words<kObs>() >= image_words<kActions>() && image_words<kActions>() >= image_words<kCells>(),
+              "the largest row stream of a variant sizes its image");
+static_assert(image_words<kObs>() % 4 == 0 && image_words<kActions>() % 4 == 0 && image_words<kCells>() % 4 == 0,
+              "images of the wavefronts of a workgroup lie back to back, 16-byte aligned");
 
 // NT: which row streams are stored with the non-temporal hint -- bit 0 observation, bit 1 mask, bit 2
 // state.  Measured (profiles/r01): the write-once observation stream always gains from it; the mask
@@ -256,8 +352,9 @@ __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, bool ma
 // written to a side buffer that nothing else reads (scripts/microbench/phase_stamps.py).  In the real
 // build the macros expand to nothing.
 #ifdef GBL_STAMPS
-__device__ unsigned long long g_stamps[1 << 17][8];
+__device__ unsigned long long g_stamps[1 << 17][12];
 #define GBL_STAMP(i) unsigned long long st_##i = __builtin_amdgcn_s_memtime()
+#define GBL_STAMP_REAL(i) unsigned long long rt_##i = __builtin_amdgcn_s_memrealtime()
 #define GBL_STAMP_DEP(i, v)                                  \
     asm volatile("" ::"v"(v));                               \
     unsigned long long st_##i = __builtin_amdgcn_s_memtime()
@@ -269,26 +366,33 @@ __device__ unsigned long long g_stamps[1 << 17][8];
         unsigned long long *o_ = g_stamps[tile];                                                           \
         o_[0] = st_0; o_[1] = st_1; o_[2] = st_2; o_[3] = st_3; o_[4] = st_4; o_[5] = st_5;               \
         o_[6] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); /* HW_REG_HW_ID */                   \
+        o_[7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); /* HW_REG_XCC_ID */                 \
+        o_[8] = rt_0; o_[9] = __builtin_amdgcn_s_memrealtime(); /* 100 MHz, chip-wide */                  \
     }
 #else
 #define GBL_STAMP(i)
+#define GBL_STAMP_REAL(i)
 #define GBL_STAMP_DEP(i, v)
 #define GBL_STAMP_DRAIN(i)
 #define GBL_STAMP_FLUSH(tile)
 #endif
 
 // gbl_step: fused raw_env.step + observe(next mover) over a tile of boards.
+// (argument order: what a wavefront needs first comes first -- the first 16 dwords are preloaded into SGPRs at
+// wave launch, -amdgpu-kernarg-preload-count, so the tile loads do not wait for a kernel-argument fetch)
 template <bool WITH_MASK, bool WITH_OBS, int NT>
-__global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t *__restrict__ to_move,
+__global__ __launch_bounds__(64 * kStepWaves) void k_step(int8_t *__restrict__ state, int8_t *__restrict__ to_move,
                                              int8_t *__restrict__ done, const int32_t *__restrict__ actions,
+                                             int64_t n, int64_t ntiles, int illegal_mode, int auto_reset,
                                              int8_t *__restrict__ winner_out, int8_t *__restrict__ reward_out,
                                              int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out,
-                                             int32_t *__restrict__ turn, int64_t n, int64_t ntiles, int illegal_mode,
-                                             int auto_reset)
+                                             int32_t *__restrict__ turn)
 {
-    __shared__ uint32_t s_img[kOutImageWords];
+    constexpr int kImg = out_image_words<WITH_MASK, WITH_OBS>();
+    __shared__ uint32_t s_imgs[kStepWaves * kImg];
+    uint32_t *const s_img = s_imgs + (kStepWaves > 1 ? (threadIdx.x >> 6) * kImg : 0);
     Lane L;
-    if (!lane_setup(L, n, ntiles)) return;
+    if (!lane_setup<kStepWaves>(L, n, ntiles)) return;
     // Per-board scalars first, from a clamped index and with no branch around them (a branch would
     // pin their s_waitcnt to the load): they are in flight together with the tile's loads -- one HBM
     // round trip per wave instead of two.
@@ -322,19 +426,23 @@ __global__ __launch_bounds__(64) void k_step(int8_t *__restrict__ state, int8_t 
 // DEV_PLY: the ply index is ply0 + *ply_dev (gbl_rollout_at, graph replay).  A template parameter because even
 // the never-taken runtime test costs the by-value kernel 0.3 us: it sits in front of the hoisted draw.
 template <bool WITH_MASK, bool WITH_OBS, int NT, bool DEV_PLY>
-__global__ __launch_bounds__(64) void k_rollout(int8_t *__restrict__ state, int8_t *__restrict__ to_move,
+__global__ __launch_bounds__(64 * kStepWaves) void k_rollout(int8_t *__restrict__ state, int8_t *__restrict__ to_move,
+                                                int64_t n, int64_t ntiles, uint64_t seed, uint64_t env_base,
+                                                const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies,
                                                 int8_t *__restrict__ done, int32_t *__restrict__ actions_out,
                                                 int8_t *__restrict__ winner_out, int8_t *__restrict__ reward_out,
-                                                int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out, int64_t n,
-                                                int64_t ntiles, uint64_t seed, uint64_t env_base, uint32_t ply0,
-                                                uint32_t plies, int illegal_mode, int64_t *__restrict__ counters,
-                                                int32_t *__restrict__ turn, const uint32_t *__restrict__ ply_dev)
+                                                int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out,
+                                                int illegal_mode, int64_t *__restrict__ counters,
+                                                int32_t *__restrict__ turn)
 {
-    __shared__ uint32_t s_img[kOutImageWords];
+    constexpr int kImg = out_image_words<WITH_MASK, WITH_OBS>();
+    __shared__ uint32_t s_imgs[kStepWaves * kImg];
+    uint32_t *const s_img = s_imgs + (kStepWaves > 1 ? (threadIdx.x >> 6) * kImg : 0);
     GBL_STAMP(0);
+    GBL_STAMP_REAL(0);
     if (DEV_PLY) ply0 += *ply_dev;
     Lane L;
-    if (!lane_setup(L, n, ntiles)) return;
+    if (!lane_setup<kStepWaves>(L, n, ntiles)) return;
     int mover = to_move[L.valid ? L.b : n - 1];  // issued before the tile loads, branch-free (see k_step)
     uint32_t r[7];
     // The first ply's random draw does not depend on the board: it is computed while the tile's loads
@@ -594,7 +702,7 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
         if (fallback_out) fallback_out[L.b] = g.fallback ? 1 : 0;
         if (hist_rw) {
             // :211-217 with the library's sampler, then :219
-            const int fin = g.fallback ? pick54(g.cands, draw32(seed, env_base + (uint64_t)L.b, call)) : g.chosen;
+            const int fin = g.fallback ? pick54(g.cands, draw32(seed, env_base + (uint64_t)L.b, call, kStreamGreedy)) : g.chosen;
             final_out[L.b] = fin;
             int8_t *hp = hist_rw + (L.b * 2 + me) * 3;
             hp[0] = (int8_t)(prev3 >> 8);
@@ -634,7 +742,7 @@ extern "C" {
 #ifdef GBL_STAMPS
 int gbl_debug_stamps(unsigned long long *host_out, int64_t ntiles)
 {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), (size_t)ntiles * 8 * sizeof(unsigned long long));
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), (size_t)ntiles * 12 * sizeof(unsigned long long));
 }
 #endif
 
@@ -736,6 +844,20 @@ int gbl_observe(const int8_t *state, const int8_t *to_move, int agent_sel, int8_
     GBL_LAUNCHED("gbl_observe");
 }
 
+int gbl_board_eval(int8_t *state, const int8_t *agent_index, const int32_t *actions, int8_t *record_out, int64_t n,
+                   void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(record_out, "record_out");
+    if (actions) GBL_NEED(agent_index, "agent_index (with actions)");
+    GBL_ALIGNED(state, "state"); GBL_ALIGNED(record_out, "record_out");
+    if (actions && (reinterpret_cast<uintptr_t>(actions) & 3u)) return fail(GBL_ERR_ALIGN, "actions must be 4-byte aligned");
+    Geometry g = geometry(n);
+    hipLaunchKernelGGL(k_board_eval, dim3(g.grid), dim3(64), 0, (hipStream_t)stream, state, agent_index, actions,
+                       record_out, n, g.ntiles);
+    GBL_LAUNCHED("gbl_board_eval");
+}
+
 int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out,
              int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int64_t n, int illegal_mode,
              int auto_reset, void *stream)
@@ -748,13 +870,13 @@ int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *action
     if (reward_out && (reinterpret_cast<uintptr_t>(reward_out) & 1u))
         return fail(GBL_ERR_ALIGN, "reward_out must be 2-byte aligned");
     if (turn && (reinterpret_cast<uintptr_t>(turn) & 3u)) return fail(GBL_ERR_ALIGN, "turn must be 4-byte aligned");
-    Geometry g = geometry(n);
+    Geometry g = geometry(n, kStepWaves);
     hipStream_t s = (hipStream_t)stream;
     auto_reset = auto_reset != 0;
     const int nt = nt_policy(n);
 #define GBL_STEP_NT(M, O, NT)                                                                                       \
-    hipLaunchKernelGGL((k_step<M, O, NT>), dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions, winner_out, \
-                       reward_out, mask_out, obs_out, turn, n, g.ntiles, illegal_mode, auto_reset)
+    hipLaunchKernelGGL((k_step<M, O, NT>), dim3(g.grid), dim3(64 * kStepWaves), 0, s, state, to_move, done, actions, \
+                       n, g.ntiles, illegal_mode, auto_reset, winner_out, reward_out, mask_out, obs_out, turn)
 #define GBL_STEP(M, O)                                          \
     switch (nt) {                                               \
     case 0: GBL_STEP_NT(M, O, 0); break;                        \
@@ -819,13 +941,13 @@ int gbl_rollout_at(int8_t *state, int8_t *to_move, int8_t *done, int32_t *action
         return fail(GBL_ERR_ALIGN, "reward_out must be 2-byte aligned");
     if (counters && (reinterpret_cast<uintptr_t>(counters) & 127u))
         return fail(GBL_ERR_ALIGN, "counters must be 128-byte aligned");
-    Geometry g = geometry(n);
+    Geometry g = geometry(n, kStepWaves);
     hipStream_t s = (hipStream_t)stream;
     const int nt = nt_policy(n);
 #define GBL_ROLL_K(M, O, NT, D)                                                                                     \
-    hipLaunchKernelGGL((k_rollout<M, O, NT, D>), dim3(g.grid), dim3(64), 0, s, state, to_move, done, actions_out,   \
-                       winner_out, reward_out, mask_out, obs_out, n, g.ntiles, seed, env_base, ply0, plies,         \
-                       illegal_mode, counters, turn, ply_dev)
+    hipLaunchKernelGGL((k_rollout<M, O, NT, D>), dim3(g.grid), dim3(64 * kStepWaves), 0, s, state, to_move, n,      \
+                       g.ntiles, seed, env_base, ply_dev, ply0, plies, done, actions_out, winner_out, reward_out,   \
+                       mask_out, obs_out, illegal_mode, counters, turn)
 #define GBL_ROLL_NT(M, O, NT)                                   \
     if (ply_dev) GBL_ROLL_K(M, O, NT, true);                    \
     else GBL_ROLL_K(M, O, NT, false)

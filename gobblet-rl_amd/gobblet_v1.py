@@ -130,6 +130,12 @@ except Exception:  # noqa: BLE001
         Discrete, Box, Dict = _Discrete, _Box, _Dict
 
 
+def _new_backend(device):
+    """The 1-board engine behind ``Board``: always the HIP library.  (Module-level so that the CPU-only
+    host-logic tests can monkeypatch it; nothing in the package does.)"""
+    return BatchedBoard(1, device)
+
+
 class Board:
     """One Gobblet board with the reference ``Board`` interface (board.py:4-242), evaluated on the GPU.
 
@@ -137,36 +143,32 @@ class Board:
     arrays and single cells: greedy_policy.py:71, manual_policy.py:60,194-196).  Whenever a query finds
     that its content changed, the position is uploaded to the 1-board ``BatchedBoard`` backend and
     EVERYTHING the reference derives from a position -- winner, flat board, covered cells, both agents'
-    legal masks and observations -- is computed by the board kernels back to back and fetched with one
-    device-to-host copy; later queries on the same position are answered from that.  ``play_turn`` runs
-    on the device and primes the same cache for the new position, so one ply of the AEC loop costs one
-    round trip.  ``backend`` exists so that the host logic can be tested without a GPU by injecting a
-    stand-in; the default is the HIP engine and there is no fallback.
+    legal masks and observations -- is computed in ONE launch (``gbl_board_eval``) and fetched with one
+    device-to-host copy; later queries on the same position are answered from that.  ``play_turn`` is fused
+    in front of the same launch and primes the cache for the new position, so one ply of the AEC loop costs one
+    launch and one round trip.  The engine is always the HIP library (``_new_backend``); there is no fallback and no
+    public way to swap it.
     """
 
-    _PARTS = (("squares", 27), ("winner", 1), ("flat", 9), ("covered", 27), ("mask0", 54), ("mask1", 54),
-              ("obs0", 117), ("obs1", 117))
+    _PARTS = tuple((k, size) for k, (_, size) in nat.REC_FIELDS.items())
 
-    def __init__(self, squares=None, device="cuda:0", backend=None):
+    def __init__(self, squares=None, device="cuda:0"):
         self.squares = np.zeros(27)           # board.py:33
         self.squares_preview = np.zeros(27)   # board.py:34
         if squares is not None:
             self.squares = np.array(squares, dtype=np.float64).reshape(27)
-        self._backend = backend if backend is not None else BatchedBoard(1, device)
+        self._backend = _new_backend(device)
         dev = getattr(self._backend, "device", "cpu")
         self._agents = (torch.zeros(1, dtype=torch.int8, device=dev), torch.ones(1, dtype=torch.int8, device=dev))
         self._key, self._cache = None, None
-        self._packed = None
+        self._record = None
         if isinstance(self._backend, BatchedBoard):
-            # one device buffer for the position and everything derived from it (every part 16-byte aligned, as
-            # the C-ABI wants): the kernels write straight into it and it travels to the host in one copy
-            self._offsets, at = {}, 0
-            for name, size in self._PARTS:
-                self._offsets[name] = at
-                at += -(-size // 16) * 16
-            self._packed = torch.zeros(at, dtype=torch.int8, device=dev)
-            self._backend._squares = self._packed[:27].view(1, 27)
+            # the engine's one-launch evaluation (gbl_board_eval) writes a 432-byte record per board; the host gets
+            # it with one asynchronous copy into pinned memory
+            self._record = torch.zeros((1, nat.REC_BYTES), dtype=torch.int8, device=dev)
+            self._host = torch.zeros((1, nat.REC_BYTES), dtype=torch.int8).pin_memory()
             self._action = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._upload = torch.zeros(27, dtype=torch.int8).pin_memory()
         self.winning_combinations = self._backend.winning_combinations  # board.py:135-153
         self.calculate_winners = self._backend.calculate_winners
         self.setup = self._backend.setup
@@ -177,24 +179,22 @@ class Board:
             raise ValueError("Board.squares must be 27 integers in [-6, 6]")
         return sq.astype(np.int8)
 
-    def _pull(self):
-        """All derived quantities of the backend's current position: 7 launches, one copy to the host."""
+    def _pull(self, agent_index=None, action=None):
+        """All derived quantities of the backend's position (after an optional play_turn): ONE launch, one copy."""
         b = self._backend
-        if self._packed is not None:
-            L, st, sq, o = b._lib, b._stream(), self._packed.data_ptr(), self._offsets
-            at = {k: sq + v for k, v in o.items()}
-            a0, a1 = self._agents[0].data_ptr(), self._agents[1].data_ptr()
-            nat.check(L.gbl_winner(sq, at["winner"], 1, st), "gbl_winner")
-            nat.check(L.gbl_flatboard(sq, at["flat"], 1, st), "gbl_flatboard")
-            nat.check(L.gbl_covered(sq, at["covered"], 1, st), "gbl_covered")
-            nat.check(L.gbl_legal_mask(sq, a0, at["mask0"], 1, st), "gbl_legal_mask")
-            nat.check(L.gbl_legal_mask(sq, a1, at["mask1"], 1, st), "gbl_legal_mask")
-            nat.check(L.gbl_observe(sq, None, 0, at["obs0"], 1, st), "gbl_observe")
-            nat.check(L.gbl_observe(sq, None, 1, at["obs1"], 1, st), "gbl_observe")
-            host = self._packed.cpu().numpy()
-            out = {name: host[o[name]:o[name] + size] for name, size in self._PARTS}
+        if self._record is not None:
+            if action is None:
+                b.evaluate(out=self._record)
+            else:
+                b.evaluate(self._agents[int(agent_index)], action, out=self._record)
+            self._host.copy_(self._record, non_blocking=True)
+            torch.cuda.current_stream(b.device).synchronize()
+            host = self._host.numpy()[0]
+            out = {name: host[o:o + size].copy() for name, (o, size) in nat.REC_FIELDS.items()}
             self._key, self._cache = out["squares"].tobytes(), out
             return out
+        if action is not None:
+            b.play_turn(self._agents[int(agent_index)], action)
         parts = [b.squares, b.check_for_winner(), b.get_flatboard(), b.check_covered(), b.legal_mask(self._agents[0]),
                  b.legal_mask(self._agents[1]), b.observation(self._agents[0]), b.observation(self._agents[1])]
         host = torch.cat([x.reshape(-1).to(torch.int8) for x in parts]).cpu().numpy()
@@ -208,8 +208,9 @@ class Board:
     def _evaluate(self):
         sq = self._position()
         if self._cache is None or sq.tobytes() != self._key:
-            if self._packed is not None:
-                self._packed[:27].copy_(torch.from_numpy(sq))
+            if self._record is not None:
+                self._upload.numpy()[:] = sq
+                self._backend.squares[0].copy_(self._upload, non_blocking=True)
             else:
                 self._backend.squares = torch.from_numpy(sq)[None]
             self._pull()
@@ -239,12 +240,9 @@ class Board:
         if agent_index not in (0, 1):
             raise ValueError("agent_index must be 0 or 1")
         self._evaluate()  # the device holds this position
-        if self._packed is not None:
-            self._action.fill_(int(action) if 0 <= int(action) < 54 else -1)  # out of range = illegal = no-op
-            self._backend.play_turn(self._agents[int(agent_index)], self._action)
-        else:
-            self._backend.play_turn(self._agents[int(agent_index)], int(action))
-        self.squares = self._pull()["squares"].astype(np.float64)
+        action = int(action) if 0 <= int(action) < 54 else -1  # out of range = illegal = no-op
+        # the move and the new position's record in one launch
+        self.squares = self._pull(agent_index, action)["squares"].astype(np.float64)
 
     def get_action(self, pos, piece_size, agent_index):  # board.py:50-60: the first legal of the size's two pieces
         for piece in (2 * int(piece_size) - 2, 2 * int(piece_size) - 1):
@@ -270,6 +268,18 @@ class Board:
 
     def observation(self, agent_index):
         return self._evaluate()["obs%d" % self._agent(agent_index)].reshape(3, 3, 13).copy()
+
+    def print_pieces(self):  # board.py:223-239 (DEBUG helper, called by render() when args.debug is set)
+        """Five lines describing the position, in the reference's wording and list formats.  One quirk is kept:
+        "squares with uncovered pieces" tests ``check_covered()[pos]`` with the square number 0..8 as the index,
+        i.e. it looks at the small-piece level only, whichever level the piece is on."""
+        sq, covered = np.asarray(self.squares), self.check_covered()
+        occupied = [c % 9 for c in range(27) if sq[c] != 0]
+        print("open_indices: ", [c for c in range(27) if sq[c] == 0])
+        print("open_squares: ", [np.where(self.get_flatboard() == 0)[0]])
+        print("squares with pieces: ", occupied)
+        print("squares with uncovered pieces: ", [q % 9 for q in occupied if covered[q] == 0])
+        print("squares with covered pieces: ", [c % 9 for c in np.where(covered == 1)[0]])
 
     def print(self):  # board.py:155-156
         print(self.get_flatboard().reshape(3, 3).transpose())
@@ -301,15 +311,18 @@ class raw_env(_AECBase):  # noqa: N801  (reference spelling, gobblet.py:123)
     metadata = {
         "render_modes": ["text", "text_full"],  # pygame modes ("human", "rgb_array") are out of scope
         "name": "gobblet_v1",
-        "is_parallelizable": True,
+        # the reference says True (gobblet.py:127) but parallel_env is the AEC->parallel conversion of a strictly
+        # turn-based game: upstream skips its own test of it (tests/test_gobblet_env.py:37-43), and it is not
+        # offered here (use BatchedGobblet for lockstep stepping), so the metadata does not claim it
+        "is_parallelizable": False,
         "render_fps": 60,
         "has_manual_policy": False,
     }
 
-    def __init__(self, render_mode=None, args=None, device="cuda:0", board_backend=None):
+    def __init__(self, render_mode=None, args=None, device="cuda:0"):
         super().__init__()
-        self._device, self._board_backend = device, board_backend
-        self.board = Board(device=device, backend=board_backend)
+        self._device = device
+        self.board = Board(device=device)
         self.board_size = 3
         self.agents = ["player_1", "player_2"]          # gobblet.py:137
         self.possible_agents = self.agents[:]
@@ -371,7 +384,7 @@ class raw_env(_AECBase):  # noqa: N801  (reference spelling, gobblet.py:123)
             self.render()
 
     def reset(self, seed=None, return_info=False, options=None):  # gobblet.py:275-290 (seed is ignored)
-        self.board = Board(device=self._device, backend=self._board_backend)
+        self.board = Board(device=self._device)
         self.agents = self.possible_agents[:]
         self.rewards = {i: 0 for i in self.agents}
         self._cumulative_rewards = {i: 0 for i in self.agents}
@@ -390,7 +403,15 @@ class raw_env(_AECBase):  # noqa: N801  (reference spelling, gobblet.py:123)
             warnings.warn("You are calling render method without specifying any render mode.")
             return
         from .render import render_text
-        out = render_text(self, full=self.render_mode == "text_full")
+        if self.debug:  # gobblet.py:315-316
+            self.board.print_pieces()
+        if self.render_mode == "text" or self.debug:  # gobblet.py:317
+            full = False
+        elif self.render_mode == "text_full":         # gobblet.py:342
+            full = True
+        else:
+            raise NotImplementedError("pygame render modes ('human', 'rgb_array') are out of scope (SURVEY.md 8)")
+        out = render_text(self, full=full)
         print(out)  # (the reference ends with an empty print(); `out` ends with that newline's line)
         return out
 
@@ -478,8 +499,8 @@ class _EnvWrappers:
         self.env.close()
 
 
-def env(render_mode=None, args=None, device="cuda:0", board_backend=None):  # gobblet.py:110-117
-    e = raw_env(render_mode=render_mode, args=args, device=device, board_backend=board_backend)
+def env(render_mode=None, args=None, device="cuda:0"):  # gobblet.py:110-117
+    e = raw_env(render_mode=render_mode, args=args, device=device)
     if _HAVE_PZ:  # pragma: no cover
         e = _pz_wrappers.TerminateIllegalWrapper(e, illegal_reward=-1)
         e = _pz_wrappers.AssertOutOfBoundsWrapper(e)

@@ -8,7 +8,8 @@ rebuilt from the observation exactly as greedy_policy.py:43-71 does (``gbl_decod
 is ``gbl_greedy``.  Per-agent history of own actions (``prev_actions``, greedy_policy.py:19,211-219) is
 kept per board on the device.  Where the reference falls back to ``np.random.choice(actions_depth1)``
 (:211-217, numpy's global RNG) this class draws uniformly from the same candidate set with the
-library's counter-based sampler (``gbl_sample``), keyed by (seed, board, call index).
+library's counter-based sampler (the ``gbl_sample`` rule on a generator stream of its own), keyed by
+(seed, global board id, call index).
 ``depth=3`` is accepted and decides like ``depth=2``: the reference's depth-3 block (:160-208) only ever
 re-assigns ``chosen_action = action``, which :157 has just done (checked against the reference itself,
 tests/golden/greedy_depth3.npz).
@@ -24,11 +25,16 @@ from . import _native as nat
 
 
 class GreedyGobbletPolicy:
-    def __init__(self, depth: Optional[int] = 2, seed: Optional[int] = 0, device="cuda:0", **kwargs: Any) -> None:
+    def __init__(self, depth: Optional[int] = 2, seed: Optional[int] = 0, device="cuda:0", env_base: int = 0,
+                 **kwargs: Any) -> None:
+        """env_base: global index of board 0 of the batches this policy is handed (a shard of a larger batch passes
+        its first global board, like ``BatchedGobblet``): the fallback draw is keyed by the global board id, so
+        trajectories do not depend on how the boards are sharded."""
         if depth not in (1, 2, 3):
             raise ValueError("depth must be 1, 2 or 3")
         self.depth = depth
         self.seed = int(seed or 0)
+        self.env_base = int(env_base)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise nat.GobbletHipError("GreedyGobbletPolicy needs a GPU device (there is no CPU fallback)")
@@ -86,7 +92,8 @@ class GreedyGobbletPolicy:
         # one launch: the search, the :211-217 fallback draw (uniform over actions_depth1, keyed by seed / board /
         # call index) and the :219 history append for the acting agent
         nat.check(self._lib.gbl_greedy_act_at(state.data_ptr(), to_move.data_ptr(), nat.ptr(mask),
-                                              self.prev_actions.data_ptr(), self.depth, self.seed, 0, self._calls,
+                                              self.prev_actions.data_ptr(), self.depth, self.seed, self.env_base,
+                                              self._calls,
                                               nat.ptr(self._calls_dev), out.data_ptr(), act.data_ptr(),
                                               cand.data_ptr(), fb.data_ptr(), n, self._stream()), "gbl_greedy_act")
         self.last_chosen, self.last_candidates, self.last_fallback = act, cand, fb

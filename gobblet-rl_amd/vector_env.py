@@ -155,14 +155,25 @@ class BatchedGobblet:
 
     # -- checkpoint / resume: the whole environment is a handful of tensors ------------------------------
     def state_dict(self) -> dict:
-        return {"squares": self.squares.clone(), "to_move": self.to_move.clone(), "done": self.done.clone(),
-                "winner": self.winner.clone(), "rewards": self.rewards.clone(), "counters": self._counters.clone(),
-                "ply": self.ply, "seed": self.seed, "env_base": self.env_base}
+        sd = {"squares": self.squares.clone(), "to_move": self.to_move.clone(), "done": self.done.clone(),
+              "winner": self.winner.clone(), "rewards": self.rewards.clone(), "counters": self._counters.clone(),
+              "ply": self.ply, "seed": self.seed, "env_base": self.env_base}
+        if self.turn is not None:
+            sd["turn"] = self.turn.clone()
+        return sd
 
     def load_state_dict(self, sd: dict) -> None:
-        self.board.squares = sd["squares"]
+        """Copies INTO this environment's tensors: their addresses do not change (a hipGraph captured before the
+        load stays valid) and the dict is not aliased (it can be loaded again, e.g. to rewind)."""
+        n = self.num_envs
+        self.squares.copy_(torch.as_tensor(sd["squares"], device=self.device).to(torch.int8).reshape(n, nat.CELLS))
         self.to_move.copy_(sd["to_move"]); self.done.copy_(sd["done"]); self.winner.copy_(sd["winner"])
         self.rewards.copy_(sd["rewards"]); self._counters.copy_(sd["counters"])
+        if self.turn is not None:
+            if "turn" in sd:
+                self.turn.copy_(sd["turn"])
+            else:
+                self.turn.zero_()
         self.ply, self.seed, self.env_base = int(sd["ply"]), int(sd["seed"]), int(sd["env_base"])
         self.refresh()
 
@@ -205,6 +216,9 @@ class BatchedGobblet:
         the last ply.  ``count=True`` also accumulates ``counters`` (device atomics, a few
         microseconds per launch).  ``rollout(1)`` is one ply of the benchmark pipeline with every
         output materialised."""
+        if not self.auto_reset:
+            raise ValueError("rollout() plays with auto-reset (finished boards start a new game); this environment was "
+                             "created with auto_reset=False -- use sample_actions() + step() to keep finished boards frozen")
         n = self.num_envs
         nat.check(self._lib.gbl_rollout_at(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
                                            self.actions.data_ptr(), self.winner.data_ptr(), self.rewards.data_ptr(),

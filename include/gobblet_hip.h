@@ -120,13 +120,39 @@ int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *action
              int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int64_t n, int illegal_mode,
              int auto_reset, void *stream);
 
+/* Everything the reference derives from a position, for n boards, in ONE launch (the single-environment
+ * facade gobblet_v1.env() asks all of it once per ply): optionally Board.play_turn(agent_index[b], actions[b])
+ * first (board.py:118-132; illegal or out-of-range: silent no-op; `state` is updated in place), then one
+ * GBL_REC_BYTES-byte record per board of the resulting position:
+ *   +GBL_REC_SQUARES int8[27]  Board.squares                     board.py:33
+ *   +GBL_REC_WINNER  int8      check_for_winner()                board.py:183-194
+ *   +GBL_REC_FLAT    int8[9]   get_flatboard()                   board.py:159-177
+ *   +GBL_REC_COVERED int8[27]  check_covered()                   board.py:203-220
+ *   +GBL_REC_MASK0 / +GBL_REC_MASK1  int8[54]  is_legal(a, agent 0 / 1), a = 0..53   board.py:82-115
+ *   +GBL_REC_OBS0  / +GBL_REC_OBS1   int8[117] raw_env.observe planes of agent 0 / 1   gobblet.py:179-208
+ * (every field 4-byte aligned, padding bytes zero).  actions == NULL: no move (agent_index is then unused and
+ * may be NULL).  record_out: int8[n][GBL_REC_BYTES], 16-byte aligned. */
+#define GBL_REC_BYTES 432
+#define GBL_REC_SQUARES 0
+#define GBL_REC_WINNER 28
+#define GBL_REC_FLAT 32
+#define GBL_REC_COVERED 44
+#define GBL_REC_MASK0 72
+#define GBL_REC_MASK1 128
+#define GBL_REC_OBS0 184
+#define GBL_REC_OBS1 304
+int gbl_board_eval(int8_t *state, const int8_t *agent_index, const int32_t *actions, int8_t *record_out, int64_t n,
+                   void *stream);
+
 /* Masked-uniform action sampling -- the rule behind "masked-random actions"
  * (examples/example_basic.py:58-61, random_admissible_policy_rllib.py:23-30:
  * uniform over legal actions) -- with a counter-based RNG so CPU and GPU draw
  * the same action: r = word (ply & 3) of Philox4x32-10(ctr = (env_lo, env_hi,
- * ply >> 2, 0), key = (seed_lo, seed_hi)) -- one generator block serves four
+ * ply >> 2, stream), key = (seed_lo, seed_hi)) -- one generator block serves four
  * consecutive plies of a board; k = (r * nlegal) >> 32; the k-th legal action
- * in ascending order (-1 if the mask is empty).  env id = env_base + b. */
+ * in ascending order (-1 if the mask is empty).  env id = env_base + b.
+ * Counter word 3 separates the consumers of one (seed, board) pair: stream 0 here
+ * and in gbl_rollout, stream 1 for the fallback draw of gbl_greedy_act. */
 int gbl_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply,
                void *stream);
 
@@ -166,7 +192,8 @@ int gbl_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask, c
 
 /* One whole policy step of GreedyGobbletPolicy.compute_action, greedy_policy.py:38-221, in one launch:
  * gbl_greedy, then where it reports the fallback (:211-217) the gbl_sample rule over the candidate set
- * with (seed, env_base + b, call) in place of numpy's global RNG, then the history append of :219
+ * with (seed, env_base + b, call) on generator stream 1 in place of numpy's global RNG (so a random opponent
+ * sampling with the same seed never consumes the same word), then the history append of :219
  * (hist[b][agent to move] shifts left by one and takes the returned action).
  *   hist      : int8[n][2][3], read AND updated (required)
  *   action_out  int32[n] : the action the policy returns (-1 only if the candidate set is empty)

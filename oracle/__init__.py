@@ -282,12 +282,25 @@ def batch_rollout(state, to_move, done, seed, env_base, ply0, plies, illegal_mod
     return {"actions": actions, "winner": winner, "reward": reward, "mask": mask, "obs": obs, "counters": counters}
 
 
-def batch_greedy(state, to_move, mask=None, hist=None, depth=2):
-    """Returns (action int32[n] (-1 where fallback), cand_mask int8[n,54], fallback int8[n])."""
+def batch_greedy(state, to_move, mask=None, hist=None, depth=2, threads=1):
+    """Returns (action int32[n] (-1 where fallback), cand_mask int8[n,54], fallback int8[n]).  threads > 1: the
+    boards are cut into contiguous chunks evaluated by a thread pool (ctypes releases the GIL; boards are
+    independent; the greedy_work() tallies are then approximate)."""
     n = state.shape[0]
     act = np.zeros(n, np.int32); cm = np.zeros((n, ACTIONS), np.int8); fb = np.zeros(n, np.int8)
-    lib().gbo_batch_greedy(_p(state), _p(to_move), _p(mask), _p(hist), int(depth), _p(act, C.c_int32), _p(cm),
-                           _p(fb), n)
+    L = lib()
+
+    def part(lo, hi):
+        L.gbo_batch_greedy(_p(state[lo:hi]), _p(to_move[lo:hi]), _p(mask[lo:hi]) if mask is not None else None,
+                           _p(hist[lo:hi]) if hist is not None else None, int(depth), _p(act[lo:hi], C.c_int32),
+                           _p(cm[lo:hi]), _p(fb[lo:hi]), hi - lo)
+    if threads <= 1 or n < 2 * threads:
+        part(0, n)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        cuts = [n * i // threads for i in range(threads + 1)]
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda i: part(cuts[i], cuts[i + 1]), range(threads)))
     return act, cm, fb
 
 

@@ -261,16 +261,20 @@ void gbo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 /* The masked-uniform sampling rule ("masked-random actions" in the configs;
  * reference sites examples/example_basic.py:58-61,
  * random_admissible_policy_rllib.py:23-30: uniform over legal actions).
- * Draw r = philox(ctr=(env_lo, env_hi, ply >> 2, 0), key=(seed_lo, seed_hi))[ply & 3]
+ * Draw r = philox(ctr=(env_lo, env_hi, ply >> 2, stream), key=(seed_lo, seed_hi))[ply & 3]
  * (one generator block serves four consecutive plies of a board),
  * k = (r * nlegal) >> 32, return the k-th legal action in ascending order.
- * Returns -1 when the mask is empty. */
-int gbo_sample_action(const int8_t *mask, uint64_t seed, uint64_t env_id, uint32_t ply)
+ * Returns -1 when the mask is empty.
+ * stream separates the consumers of one (seed, board) pair: 0 = the masked-random
+ * actions of the environment / random policy, 1 = the greedy policy's fallback
+ * draw -- so a greedy agent and a random opponent with the same seed never
+ * consume the same generator word. */
+int gbo_sample_action_stream(const int8_t *mask, uint64_t seed, uint64_t env_id, uint32_t ply, uint32_t stream)
 {
     int n = 0;
     for (int a = 0; a < GBO_ACTIONS; ++a) n += (mask[a] != 0);
     if (n == 0) return -1;
-    uint32_t ctr[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), ply >> 2, 0u};
+    uint32_t ctr[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), ply >> 2, stream};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t out[4];
     gbo_philox4x32_10(ctr, key, out);
@@ -278,6 +282,11 @@ int gbo_sample_action(const int8_t *mask, uint64_t seed, uint64_t env_id, uint32
     for (int a = 0; a < GBO_ACTIONS; ++a)
         if (mask[a] != 0 && k-- == 0) return a;
     return -1;
+}
+
+int gbo_sample_action(const int8_t *mask, uint64_t seed, uint64_t env_id, uint32_t ply)
+{
+    return gbo_sample_action_stream(mask, seed, env_id, ply, 0u);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -745,7 +754,7 @@ void gbo_batch_greedy_act(const int8_t *state, const int8_t *to_move, const int8
         int8_t cm[GBO_ACTIONS], fb;
         gbo_batch_greedy(state + b * GBO_CELLS, to_move + b, mask_in ? mask_in + b * GBO_ACTIONS : NULL,
                          hist + b * 6, depth, &chosen, cm, &fb, 1);
-        int fin = fb ? gbo_sample_action(cm, seed, env_base + (uint64_t)b, call) : chosen;
+        int fin = fb ? gbo_sample_action_stream(cm, seed, env_base + (uint64_t)b, call, 1u) : chosen;
         action_out[b] = fin;
         if (chosen_out) chosen_out[b] = chosen;
         if (cand_mask_out) memcpy(cand_mask_out + b * GBO_ACTIONS, cm, GBO_ACTIONS);

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Build a differently configured library of the same ABI for A/B runs (GOBBLET_HIP_LIB=build/lib_NAME.so):
+#   scripts/build_variant.sh NAME [-DGBL_... ...]
+set -e
+name=$1; shift
+mkdir -p build
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mcode-object-version=5 \
+  -mllvm -amdgpu-kernarg-preload-count=16 "$@" -o build/lib_$name.so gobblet-rl_amd/csrc/gobblet_hip.hip 2>&1 | grep -v "argument unused" || true
+ls -la build/lib_$name.so

@@ -459,7 +459,7 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
                 if (action_out) action_out[b] = g.fallback ? -1 : g.chosen;
                 if (fallback_out) fallback_out[b] = g.fallback ? 1 : 0;
                 if (hist_rw) {
-                    int fin = g.fallback ? pick54(g.cands, draw32(seed, env_base + (uint64_t)b, call)) : g.chosen;
+                    int fin = g.fallback ? pick54(g.cands, draw32(seed, env_base + (uint64_t)b, call, kStreamGreedy)) : g.chosen;
                     final_out[b] = fin;
                     int8_t *hp = hist_rw + (b * 2 + ME[l]) * 3;
                     hp[0] = (int8_t)(PREV[l] >> 8);

@@ -367,6 +367,38 @@ def render_text():
     print("render_text.json:", len(out), "frames")
 
 
+def print_pieces_text(n_boards=48):
+    """stdout of the reference's debug printers on fixture boards: Board.print_pieces (board.py:223-239),
+    Board.print (:155-156) and str(Board) (:241-242); plus render() frames of a raw_env created with
+    args.debug = True (gobblet.py:315-316: print_pieces, then the "text" frame) along one golden game."""
+    import contextlib
+    import io
+    bf = np.load(os.path.join(OUT, "board_functions.npz"))
+    out = {"boards": [], "debug_frames": []}
+    for i in range(n_boards):
+        b = Board()
+        b.squares = bf["squares"][i].astype(np.float64)
+        rec = {"index": i, "squares": bf["squares"][i].astype(int).tolist()}
+        for key, fn in (("print_pieces", b.print_pieces), ("print", b.print), ("str", lambda: print(str(b)))):
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                fn()
+            rec[key] = buf.getvalue()
+        out["boards"].append(rec)
+    g = np.load(os.path.join(OUT, "random_games.npz"))
+    env = raw_env(render_mode="text", args=types.SimpleNamespace(debug=True))
+    for i in np.flatnonzero(g["game"] < 1):
+        if g["ply"][i] == 0:
+            env.reset()
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            env.step(int(g["action"][i]))
+        out["debug_frames"].append({"index": int(i), "text": buf.getvalue()})
+    with open(os.path.join(OUT, "print_pieces.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("print_pieces.json:", len(out["boards"]), "boards,", len(out["debug_frames"]), "debug frames")
+
+
 def c1_thousand_games(n_games=1000):
     """the AEC loop of examples/example_basic.py:50-67 over the reference
     raw_env, masked-uniform actions drawn from numpy.random.default_rng(0); whole trajectories."""
@@ -471,6 +503,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "render":
         render_text()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "print_pieces":
+        print_pieces_text()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "c1":
         c1_thousand_games()
         return
@@ -489,6 +524,7 @@ def main():
         print(f"  {k}: winner {bf['winner'][i]} flat {bf['flatboard'][i].tolist()}")
     greedy_vectors(games)
     render_text()
+    print_pieces_text()
     c1_thousand_games()
     greedy_restricted_masks()
     greedy_depth3()

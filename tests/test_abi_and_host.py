@@ -1,7 +1,7 @@
 """CPU-side checks of the product's host code: the C-ABI library builds, loads and exports every
 symbol include/gobblet_hip.h declares (no compute call is made without a GPU); argument checks
 that do not need a device; the single-env AEC facade's turn logic against the golden trajectories
-(with a test-only oracle backend standing in for the GPU board)."""
+(the CPU tests monkeypatch the facade's private engine factory with a test-only oracle board)."""
 import ctypes as C
 import json
 import os
@@ -63,8 +63,15 @@ def test_product_does_not_import_oracle():
 
 # ---- the AEC facade's host logic (gobblet.py:123-290), oracle backend -----------------------------------
 
+@pytest.fixture(autouse=True)
+def oracle_engine(monkeypatch):
+    """No GPU here: the facade's private engine factory is patched to a CPU stand-in for these host-logic
+    tests (the product has no such switch; tests/test_gpu_parity.py runs the same checks on the HIP engine)."""
+    monkeypatch.setattr(G.gobblet_v1, "_new_backend", lambda device: OracleBoardBackend(1))
+
+
 def make_raw():
-    return G.gobblet_v1.raw_env(board_backend=OracleBoardBackend(1))
+    return G.gobblet_v1.raw_env()
 
 
 def test_reset_starting():  # reference tests/test_gobblet_env.py:23-28
@@ -115,7 +122,7 @@ def test_raw_env_replays_golden_games(golden_dir):
 def test_aec_loop_like_example_basic():
     """The loop of examples/example_basic.py:50-67 over env(): masked-random play to termination."""
     rng = np.random.default_rng(0)
-    e = G.gobblet_v1.env(board_backend=OracleBoardBackend(1))
+    e = G.gobblet_v1.env()
     with pytest.raises(AttributeError):
         e.step(0)  # OrderEnforcing: step before reset
     for game in range(5):
@@ -135,7 +142,7 @@ def test_aec_loop_like_example_basic():
 
 
 def test_env_illegal_move_terminates_with_minus_one():
-    e = G.gobblet_v1.env(board_backend=OracleBoardBackend(1))
+    e = G.gobblet_v1.env()
     e.reset()
     for a in (18, 36):
         e.last()
@@ -148,7 +155,7 @@ def test_env_illegal_move_terminates_with_minus_one():
     assert e.terminations == {"player_1": True, "player_2": True} == e.truncations
     assert e.rewards == {"player_1": -1.0, "player_2": 0}
     with pytest.raises(AssertionError):
-        G.gobblet_v1.env(board_backend=OracleBoardBackend(1)).reset() or e.step(54)
+        G.gobblet_v1.env().reset() or e.step(54)
 
 
 def test_text_render_matches_reference(capsys, golden_dir):
@@ -156,7 +163,7 @@ def test_text_render_matches_reference(capsys, golden_dir):
     frames = json.load(open(os.path.join(golden_dir, "render_text.json")))
     g = np.load(os.path.join(golden_dir, "random_games.npz"))
     for mode in ("text", "text_full"):
-        e = G.gobblet_v1.raw_env(render_mode=mode, board_backend=OracleBoardBackend(1))
+        e = G.gobblet_v1.raw_env(render_mode=mode)
         for fr in [f for f in frames if f["mode"] == mode]:
             i = fr["index"]
             if g["ply"][i] == 0:
@@ -171,7 +178,7 @@ def test_seed_determinism_like_pettingzoo_seed_test():
     driven by the same seeded action stream produce identical observations, rewards and terminations."""
     def play(seed):
         rng = np.random.default_rng(seed)
-        e = G.gobblet_v1.env(board_backend=OracleBoardBackend(1))
+        e = G.gobblet_v1.env()
         e.reset(seed=seed)
         trace = []
         for agent in e.agent_iter(max_iter=60):
@@ -191,7 +198,7 @@ def test_api_contract_like_pettingzoo_api_test():
     """The parts of pettingzoo.test.api_test (reference tests/test_gobblet_env.py:32-34) that concern this
     environment: observations / masks lie in their spaces with the declared dtype and shape, rewards and
     termination dicts cover exactly the live agents, actions are Discrete(54), dead agents step with None."""
-    e = G.gobblet_v1.env(board_backend=OracleBoardBackend(1))
+    e = G.gobblet_v1.env()
     e.reset()
     assert e.possible_agents == ["player_1", "player_2"] and e.agents == e.possible_agents
     assert e.action_space("player_1").n == 54
@@ -209,3 +216,39 @@ def test_api_contract_like_pettingzoo_api_test():
         else:
             e.step(int(rng.choice(np.flatnonzero(obs["action_mask"]))))
     assert e.agents == []
+
+
+def _norm_np_repr(text):
+    """numpy >= 2 prints scalars inside lists as np.int64(4); numpy 1.x (the reference's pin) as 4"""
+    return re.sub(r"np\.int64\((-?\d+)\)", r"\1", text)
+
+
+def test_print_pieces_and_debug_render_match_reference(capsys, golden_dir):
+    """Board.print_pieces / print / __str__ (board.py:155-156, 223-242) and render() with args.debug
+    (gobblet.py:315-317) against stdout captured from the reference."""
+    import types
+    ref = json.load(open(os.path.join(golden_dir, "print_pieces.json")))
+    for rec in ref["boards"]:
+        b = G.gobblet_v1.Board(squares=rec["squares"])
+        for key, fn in (("print_pieces", b.print_pieces), ("print", b.print), ("str", lambda: print(str(b)))):
+            capsys.readouterr()
+            fn()
+            assert _norm_np_repr(capsys.readouterr().out) == _norm_np_repr(rec[key]), (rec["index"], key)
+    g = np.load(os.path.join(golden_dir, "random_games.npz"))
+    e = G.gobblet_v1.raw_env(render_mode="text", args=types.SimpleNamespace(debug=True))
+    for fr in ref["debug_frames"]:
+        i = fr["index"]
+        if g["ply"][i] == 0:
+            e.reset()
+        capsys.readouterr()
+        e.step(int(g["action"][i]))
+        assert _norm_np_repr(capsys.readouterr().out) == _norm_np_repr(fr["text"]), i
+
+
+def test_facade_has_no_public_backend_switch():
+    import inspect
+    for fn in (G.gobblet_v1.env, G.gobblet_v1.raw_env.__init__, G.gobblet_v1.Board.__init__):
+        assert not [p for p in inspect.signature(fn).parameters if "backend" in p]
+    assert G.gobblet_v1.raw_env.metadata["is_parallelizable"] is False
+    with pytest.raises(NotImplementedError):
+        G.gobblet_v1.parallel_env()

@@ -168,6 +168,37 @@ def test_board_api_vs_oracle(G):
     assert np.array_equal(npy(b.squares), exp_s)
 
 
+@pytest.mark.parametrize("n", [1, 63, 65, 4099])
+def test_board_eval_vs_oracle(G, n):
+    """gbl_board_eval: optional play_turn + everything the reference derives from the position, one launch."""
+    from gobblet_rl_amd import _native as nat
+    rng = np.random.default_rng(n)
+    state, tm, dn = selfplay(n, 30, seed=3 + n)
+
+    def check(rec, st):
+        assert np.array_equal(npy(rec["squares"]), st)
+        assert np.array_equal(npy(rec["winner"]), oracle.batch_winner(st))
+        assert np.array_equal(npy(rec["flat"]), oracle.batch_flatboard(st))
+        assert np.array_equal(npy(rec["covered"]), oracle.batch_covered(st))
+        for ag in (0, 1):
+            who = np.full(n, ag, np.int8)
+            assert np.array_equal(npy(rec["mask%d" % ag]), oracle.batch_legal_mask(st, who))
+            assert np.array_equal(npy(rec["obs%d" % ag]), oracle.batch_observe(st, who, ag))
+        raw = npy(rec["record"])
+        used = np.zeros(nat.REC_BYTES, bool)
+        for o, size in nat.REC_FIELDS.values():
+            used[o:o + size] = True
+        assert (raw[:, ~used] == 0).all()  # padding bytes are zero
+    b = G.BatchedBoard(n, DEV, squares=t(state))
+    check(b.evaluate(), state)
+    a = rng.integers(-2, 56, n).astype(np.int32)
+    legal = oracle.batch_sample(oracle.batch_legal_mask(state, tm), 5, 0, 0)
+    a[::2] = legal[::2]  # half of the boards play a legal move of the agent to move
+    exp_s = np.stack([oracle.play_turn(state[i], tm[i], a[i]) if 0 <= a[i] < 54 else state[i] for i in range(n)])
+    check(b.evaluate(t(tm), t(a)), exp_s)
+    assert np.array_equal(npy(b.squares), exp_s)  # the state is updated in place
+
+
 def test_sampler_and_rollout_vs_oracle(G):
     n, plies, seed, base = 4096 + 17, 48, 9, 123456789012
     env = G.BatchedGobblet(n, DEV, auto_reset=True, seed=seed, env_base=base)
@@ -584,7 +615,7 @@ def test_out_of_bounds_canaries(G, n):
     state, tm, dn = selfplay(n, 12, seed=n)
     a = oracle.batch_sample(oracle.batch_legal_mask(state, tm), 1, 0, 0)
     sizes = {"state": 27 * n, "tm": n, "dn": n, "act": 4 * n, "win": n, "rew": 2 * n, "mask": 54 * n, "obs": 117 * n,
-             "flat": 9 * n, "cov": 27 * n, "turn": 4 * n}
+             "flat": 9 * n, "cov": 27 * n, "turn": 4 * n, "rec": 432 * n}
     bufs = {k: guarded(v) for k, v in sizes.items()}
     p = {k: bufs[k][1] for k in bufs}
     p["state"].copy_(t(state).view(torch.uint8).reshape(-1)); p["tm"].copy_(t(tm).view(torch.uint8))
@@ -607,6 +638,8 @@ def test_out_of_bounds_canaries(G, n):
     nat.check(L.gbl_validate(ptr["state"], ptr["win"], n, None))
     nat.check(L.gbl_decode_obs(ptr["obs"], ptr["cov"], ptr["win"], n, None))
     nat.check(L.gbl_greedy(ptr["state"], ptr["tm"], None, None, 2, ptr["act"], ptr["mask"], ptr["win"], n, None))
+    nat.check(L.gbl_board_eval(ptr["state"], ptr["tm"], ptr["act"], ptr["rec"], n, None))
+    nat.check(L.gbl_board_eval(ptr["state"], None, None, ptr["rec"], n, None))
     torch.cuda.synchronize()
     for k, (buf, _) in bufs.items():
         assert intact(buf, sizes[k]), k
@@ -695,3 +728,142 @@ def test_graph_replay_draws_fresh_plies(G):
         og = oracle.batch_greedy_act(npy(st), npy(who), hist, 3, 0, call, depth=2)
         assert np.array_equal(outs[call], og[0]), call
     assert np.array_equal(npy(pol.prev_actions), hist)
+
+
+# ---- at-size checks (BASELINE configs at their stated sizes) -------------------------------------------
+def test_greedy_config5_full_size(G):
+    """BASELINE config 5 as stated: 65 536 boards of the stationary masked-random mix (both movers) x depth-2
+    greedy, one launch = 1 024 tiles x 4 wavefronts with pooled LDS candidate lists; every decision, candidate
+    set and fallback flag against the oracle -- with empty histories and with random ones."""
+    from gobblet_rl_amd import _native as nat
+    n = 65536
+    env = G.BatchedGobblet(n, DEV, auto_reset=True, seed=11)
+    env.rollout(64)
+    torch.cuda.synchronize()
+    state, tm = npy(env.squares), npy(env.to_move)
+    assert (oracle.batch_winner(state) == 0).all() and 0.3 < tm.mean() < 0.7
+    rng = np.random.default_rng(5)
+    hist = rng.integers(-1, 54, (n, 2, 3)).astype(np.int8)
+    L = nat.lib()
+    act = torch.empty(n, dtype=torch.int32, device=DEV); cm = torch.empty((n, 54), dtype=torch.int8, device=DEV)
+    fb = torch.empty(n, dtype=torch.int8, device=DEV)
+    for h in (None, hist):
+        hd = None if h is None else t(h)
+        nat.check(L.gbl_greedy(env.squares.data_ptr(), env.to_move.data_ptr(), None, nat.ptr(hd), 2, act.data_ptr(),
+                               cm.data_ptr(), fb.data_ptr(), n, nat.current_stream(torch.device(DEV))), "gbl_greedy")
+        torch.cuda.synchronize()
+        o = oracle.batch_greedy(state, tm, hist=h, depth=2, threads=16)
+        assert np.array_equal(npy(act), o[0]) and np.array_equal(npy(cm), o[1]) and np.array_equal(npy(fb), o[2])
+        assert h is None or 0 < int(o[2].sum()) < n  # with histories both outcomes of the fallback test occur
+
+
+def test_winner_exhaustive_on_gpu(G):
+    """gbl_winner over every pattern of tops (3^9, at each level) and 100 000 random stacks (the packed line
+    arithmetic of winner_of against the oracle's walk over the 8 lines), and the same boards through the fused
+    step's winner output (an illegal action 54 leaves the board as it is, raw_env semantics)."""
+    import itertools
+    cfg = np.array(list(itertools.product((0, 1, -1), repeat=9)), np.int8)
+    parts = []
+    for lvl in range(3):
+        st = np.zeros((len(cfg), 27), np.int8)
+        st[:, 9 * lvl:9 * lvl + 9] = cfg * (2 * lvl + 1)
+        parts.append(st)
+    rng = np.random.default_rng(1)
+    st = np.zeros((100000, 27), np.int8)
+    for lvl, vals in enumerate(((1, 2), (3, 4), (5, 6))):
+        occ = rng.random((len(st), 9)) < 0.45
+        v = rng.choice(vals, size=(len(st), 9)) * rng.choice((1, -1), size=(len(st), 9))
+        st[:, 9 * lvl:9 * lvl + 9] = np.where(occ, v, 0)
+    parts.append(st)
+    boards = np.ascontiguousarray(np.concatenate(parts))
+    w = oracle.batch_winner(boards)
+    assert len(np.unique(w)) == 3
+    b = G.BatchedBoard(len(boards), DEV, squares=t(boards))
+    assert np.array_equal(npy(b.check_for_winner()), w)
+    env = vec_env(G, len(boards), boards, np.zeros(len(boards), np.int8), np.zeros(len(boards), np.int8))
+    env.step(torch.full((len(boards),), 54, dtype=torch.int32, device=DEV))
+    assert np.array_equal(npy(env.winner), w) and np.array_equal(npy(env.squares), boards)
+
+
+def _norm_np_repr(text):
+    import re
+    return re.sub(r"np\.int64\((-?\d+)\)", r"\1", text)
+
+
+def test_text_render_and_debug_printers_on_gpu(G, golden_dir, capsys):
+    """SURVEY 8 f3 on the HIP engine: every frame of render_mode "text" / "text_full" (gobblet.py:299-429) along
+    the golden games, Board.print_pieces / print / __str__ (board.py:155-156, 223-242) and the args.debug frames
+    (gobblet.py:315-317), character for character against stdout captured from the reference."""
+    import types
+    frames = json.load(open(os.path.join(golden_dir, "render_text.json")))
+    g = np.load(os.path.join(golden_dir, "random_games.npz"))
+    for mode in ("text", "text_full"):
+        e = G.gobblet_v1.raw_env(render_mode=mode, device=DEV)
+        for fr in [f for f in frames if f["mode"] == mode]:
+            i = fr["index"]
+            if g["ply"][i] == 0:
+                e.reset()
+            capsys.readouterr()
+            e.step(int(g["action"][i]))
+            assert capsys.readouterr().out == fr["text"], (mode, i)
+    ref = json.load(open(os.path.join(golden_dir, "print_pieces.json")))
+    for rec in ref["boards"]:
+        b = G.gobblet_v1.Board(squares=rec["squares"], device=DEV)
+        for key, fn in (("print_pieces", b.print_pieces), ("print", b.print), ("str", lambda: print(str(b)))):
+            capsys.readouterr()
+            fn()
+            assert _norm_np_repr(capsys.readouterr().out) == _norm_np_repr(rec[key]), (rec["index"], key)
+    e = G.gobblet_v1.raw_env(render_mode="text", args=types.SimpleNamespace(debug=True), device=DEV)
+    for fr in ref["debug_frames"]:
+        i = fr["index"]
+        if g["ply"][i] == 0:
+            e.reset()
+        capsys.readouterr()
+        e.step(int(g["action"][i]))
+        assert _norm_np_repr(capsys.readouterr().out) == _norm_np_repr(fr["text"]), i
+
+
+def test_load_state_dict_twice_and_graph_after_load(G):
+    """load_state_dict copies into the environment's own tensors: the checkpoint is not aliased (loading it again
+    rewinds to the same state), tensor addresses survive (a hipGraph captured before the load keeps working), and
+    `turn` travels with it."""
+    n = 3000
+    env = G.BatchedGobblet(n, DEV, auto_reset=True, seed=4, track_turn=True)
+    env.rollout(17)
+    sd = env.state_dict()
+    keep = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in sd.items()}
+    ptrs = (env.squares.data_ptr(), env.to_move.data_ptr(), env.action_mask.data_ptr())
+    env.rollout(9)
+    after9 = (env.squares.clone(), env.turn.clone(), env.action_mask.clone())
+    for _ in range(2):  # rewind twice from the SAME dict
+        env.load_state_dict(sd)
+        assert ptrs == (env.squares.data_ptr(), env.to_move.data_ptr(), env.action_mask.data_ptr())
+        assert all(torch.equal(sd[k], keep[k]) for k in sd if torch.is_tensor(sd[k]))  # the checkpoint is untouched
+        assert torch.equal(env.turn, keep["turn"]) and env.ply == keep["ply"]
+        env.rollout(9)
+        assert all(torch.equal(a, b) for a, b in zip(after9, (env.squares, env.turn, env.action_mask)))
+    # a graph captured before a load plays on the restored state
+    env.load_state_dict(sd)
+    env.device_ply()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        env.rollout(1); env.advance_ply()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            for _ in range(4):
+                env.rollout(1)
+            env.advance_ply()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    env.load_state_dict(sd)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        g.replay(); g.replay()
+    torch.cuda.synchronize()
+    ref = G.BatchedGobblet(n, DEV, auto_reset=True, seed=4, track_turn=True)
+    ref.load_state_dict(sd)
+    ref.rollout(8)
+    assert torch.equal(env.squares, ref.squares) and torch.equal(env.turn, ref.turn) and env.ply == ref.ply
+    with pytest.raises(ValueError):
+        G.BatchedGobblet(8, DEV, auto_reset=False).rollout(1)
