@@ -2,12 +2,16 @@
 """bench.py -- env-steps/s of the batched Gobblet hot path on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--boards B | --boards-per-gpu B]
-                    [--mode fused|step] [--graph 0|1] [--no-obs] [--no-configs] [--no-cpu-baseline]
+                    [--mode collect|fused|step] [--traj T] [--graph 0|1] [--no-obs] [--no-configs] [--no-cpu-baseline]
 
-One "step" = one lockstep ply of the benchmark pipeline over this rank's shard of boards:
-    mode fused (default): gbl_rollout(plies=1) -- masked-uniform sampling + raw_env.step + observe
-                 fused into ONE launch per ply; state, action, mask, obs, winner, reward, done of
-                 every ply are materialised in HBM (a consumer can read them after each launch).
+One "step" = one lockstep ply of the benchmark pipeline over this rank's shard of boards -- masked-uniform
+sampling + raw_env.step + observe of the next mover, with EVERY ply's action, mask, obs, winner, reward, done and
+next mover materialised in HBM where a consumer can read them:
+    mode collect (default): gbl_collect -- T plies (--traj, default 32) per launch, ply t writing slot t of
+                 trajectory arrays [T][boards][...] (what a rollout collector hands a trainer); the boards stay in
+                 LDS / registers between the plies of a launch, so the state crosses HBM once per T plies.
+    mode fused : gbl_rollout(plies=1) -- ONE launch per ply, the ply's outputs overwrite the environment's
+                 tensors (round 1's pipeline; 234 algorithmic bytes per env-step).
     mode step  : gbl_sample (action from the mask buffer) + gbl_step (externally supplied
                  actions: the drop-in form of raw_env.step + observe) -- two launches per ply.
 Workload (BASELINE.json metric / BASELINE.md C4): 2^20 boards IN TOTAL, sharded by contiguous global index
@@ -21,8 +25,10 @@ device-resident counter (gbl_rollout_at + gbl_counter_add), so the graph is repl
 first launch carries one-off costs) and the timed replay still plays K fresh plies; --graph 0 launches eagerly.
 
 Prints ONE JSON line on rank 0 (see the task's bench contract) including
-    roofline     -- dominant kernel (k_rollout / k_step): algorithmic 234 B per env-step x boards
-                    per launch / mean launch duration from HIP events on the launch stream, vs 8 TB/s HBM peak
+    roofline     -- dominant kernel: algorithmic bytes per launch / mean launch duration from HIP events on the
+                    launch stream, vs 8 TB/s HBM peak.  Bytes per env-step: 234 for k_rollout / k_step (SURVEY.md
+                    8d: reads 33 + writes 201); for k_collect the same per-ply outputs (mask 54 + obs 117 + action 4 +
+                    winner 1 + done 1 + to_move 1 = 178) and the state only once per launch (57 B per board)
     cpu_baseline -- the CPU oracle (a C port of the reference algorithm; kind "port") doing the same pipeline
                     on the host cores, on a bounded sample (rank 0, N=1 only)
     configs      -- (N=1 only) the other sizes BASELINE.json names, each a short run with its own roofline:
@@ -42,6 +48,9 @@ if ROOT not in sys.path:
 
 ALGO_BYTES_FULL = 234      # reads 33 + writes 201 per env-step
 ALGO_BYTES_MASK_ONLY = 117  # same without the 117-byte observation
+# gbl_collect: per ply and board it writes mask 54 + obs 117 + action 4 + winner 1 + done 1 + to_move 1 (the same
+# outputs SURVEY.md 8(d) counts); the state is read (27 + to_move 1) and written (27 + to_move 1 + done 1) once per launch
+ALGO_BYTES_COLLECT_PLY, ALGO_BYTES_COLLECT_PLY_MASK_ONLY, ALGO_BYTES_COLLECT_LAUNCH = 178, 61, 57
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; max shader clock (MI355X_MICROARCH.md)
 TOTAL_BOARDS = 1 << 20
@@ -55,7 +64,10 @@ def parse():
     ap.add_argument("--boards", "--total-boards", dest="boards", type=int, default=TOTAL_BOARDS,
                     help="TOTAL boards, split over the GPUs (strong scaling: BASELINE.md C4)")
     ap.add_argument("--boards-per-gpu", type=int, default=0, help="fixed per-GPU shard instead (weak scaling)")
-    ap.add_argument("--mode", choices=["step", "fused"], default="fused")
+    ap.add_argument("--mode", choices=["collect", "fused", "step"], default="collect")
+    ap.add_argument("--traj", type=int, default=0,
+                    help="plies per launch in mode collect; 0 = by shard size (8 from 2^19 boards per GPU, 16 from 2^18, "
+                         "else 32: small shards amortise the launch over more plies), never more than half of --steps")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the K timed plies as one hipGraph; 0: eager launches")
     ap.add_argument("--no-obs", action="store_true",
                     help="MASK_ONLY variant (BASELINE.md: 117 algorithmic bytes per env-step): no observation tensor")
@@ -115,6 +127,12 @@ def cpu_baseline(boards, warmup, target_s):
             "value_1core": n1 * 4 / d1}
 
 
+def auto_traj(boards, steps, requested=0):
+    """Plies per gbl_collect launch: the requested value, or by shard size; at least two launches per timed run."""
+    t = requested if requested > 0 else (8 if boards >= (1 << 19) else 16 if boards >= (1 << 18) else 32)
+    return max(1, min(t, max(1, steps // 2)))
+
+
 def kernel_source_hash():
     """Identifies the kernel sources a committed profile was taken from (profiles/pmc_traffic.json records it)."""
     h = hashlib.sha256()
@@ -140,34 +158,61 @@ def committed_counter(key, field):
 
 
 class Pipeline:
-    """One shard of boards and its per-ply launch sequence, with the ply index in device memory."""
+    """One shard of boards and its launch sequence, with the ply index in device memory."""
 
-    def __init__(self, G, torch, boards, env_base, dev, no_obs=False, mode="fused"):
+    def __init__(self, G, torch, boards, env_base, dev, no_obs=False, mode="collect", traj=32):
         self.G, self.torch, self.nat, self.lib = G, torch, G._native, G._native.lib()
-        self.boards, self.dev, self.mode, self.no_obs = boards, dev, mode, no_obs
+        self.boards, self.dev, self.mode, self.no_obs, self.T = boards, dev, mode, no_obs, max(1, int(traj))
         env = self.env = G.BatchedGobblet(boards, dev, illegal_mode="noop", auto_reset=True, seed=0, env_base=env_base,
                                           with_observation=not no_obs)
         self.P = dict(sq=env.squares.data_ptr(), tm=env.to_move.data_ptr(), dn=env.done.data_ptr(),
                       ac=env.actions.data_ptr(), wi=env.winner.data_ptr(), rw=env.rewards.data_ptr(),
                       mk=env.action_mask.data_ptr(), ob=None if no_obs else env.observation.data_ptr())
         self.ctr = torch.zeros(1, dtype=torch.int32, device=dev)  # plies played so far (keys the sampler)
-        self.algo_bytes = ALGO_BYTES_MASK_ONLY if no_obs else ALGO_BYTES_FULL
+        self.traj = None
+        if mode == "collect":
+            self.traj = env.trajectory_buffers(self.T)
+            f = self.traj["_full"]
+            self.TP = dict(ac=f["actions"].data_ptr(), wi=f["winner"].data_ptr(), rw=f["rewards"].data_ptr(),
+                           dn=f["done"].data_ptr(), tm=f["to_move"].data_ptr(), mk=f["action_mask"].data_ptr(),
+                           ob=None if no_obs else f["observation"].data_ptr())
 
-    def enqueue(self, k, stream, ev=None):
-        """Ply number (counter + k) on `stream`; ev = (start, stop) events bracketing the dominant kernel."""
+    def plan(self, k):
+        """The launches that play k plies: [(ply offset, plies of the launch)]."""
+        if self.mode != "collect":
+            return [(i, 1) for i in range(k)]
+        return [(i, min(self.T, k - i)) for i in range(0, k, self.T)]
+
+    def launch_bytes(self, plies):
+        """Algorithmic bytes of one launch of the dominant kernel (see the module docstring)."""
+        if self.mode == "collect":
+            per = ALGO_BYTES_COLLECT_PLY_MASK_ONLY if self.no_obs else ALGO_BYTES_COLLECT_PLY
+            return (per * plies + ALGO_BYTES_COLLECT_LAUNCH) * self.boards
+        return (ALGO_BYTES_MASK_ONLY if self.no_obs else ALGO_BYTES_FULL) * self.boards
+
+    def enqueue(self, off, plies, stream, ev=None):
+        """Plies (counter + off) .. (counter + off + plies - 1) on `stream`; ev = (start, stop) events bracketing
+        the dominant kernel."""
         P, lib, env, n = self.P, self.lib, self.env, self.boards
         if self.mode == "step":
-            rc = lib.gbl_sample_at(P["mk"], P["ac"], n, env.seed, env.env_base, k, self.ctr.data_ptr(), stream)
+            rc = lib.gbl_sample_at(P["mk"], P["ac"], n, env.seed, env.env_base, off, self.ctr.data_ptr(), stream)
             self.nat.check(rc, "gbl_sample_at")
             if ev:
                 ev[0].record()
             rc = lib.gbl_step(P["sq"], P["tm"], P["dn"], P["ac"], P["wi"], P["rw"], P["mk"], P["ob"], None, n, 0, 1, stream)
-        else:
+        elif self.mode == "fused":
             if ev:
                 ev[0].record()
             rc = lib.gbl_rollout_at(P["sq"], P["tm"], P["dn"], P["ac"], P["wi"], P["rw"], P["mk"], P["ob"], n, env.seed,
-                                    env.env_base, k, self.ctr.data_ptr(), 1, 0, None, None, stream)
-        self.nat.check(rc, "ply launch")
+                                    env.env_base, off, self.ctr.data_ptr(), 1, 0, None, None, stream)
+        else:
+            if ev:
+                ev[0].record()
+            T = self.TP
+            rc = lib.gbl_collect(P["sq"], P["tm"], P["dn"], T["ac"], T["wi"], T["rw"], T["dn"], T["tm"], T["mk"], T["ob"],
+                                 n, self.traj["_slot_boards"], env.seed, env.env_base, off, self.ctr.data_ptr(), plies, 0,
+                                 None, None, stream)
+        self.nat.check(rc, "launch")
         if ev:
             ev[1].record()
 
@@ -176,8 +221,8 @@ class Pipeline:
 
     def eager(self, k, events=None):
         s = self.nat.current_stream(self.dev)
-        for i in range(k):
-            self.enqueue(i, s, events[i] if events else None)
+        for i, (off, plies) in enumerate(self.plan(k)):
+            self.enqueue(off, plies, s, events[i] if events else None)
         self.advance(k, s)
 
     def capture(self, k):
@@ -187,8 +232,8 @@ class Pipeline:
         # events in the multi-GPU runs) must not invalidate the capture
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             cs = self.nat.current_stream(self.dev)
-            for i in range(k):
-                self.enqueue(i, cs)
+            for off, plies in self.plan(k):
+                self.enqueue(off, plies, cs)
             self.advance(k, cs)
         return g
 
@@ -196,19 +241,23 @@ class Pipeline:
         E = self.torch.cuda.Event
         return [(E(enable_timing=True), E(enable_timing=True)) for _ in range(k)]
 
-    def kernel_roofline(self, mean_kernel_s, launches, timing):
-        achieved = self.algo_bytes * self.boards / mean_kernel_s / 1e9
+    def kernel_roofline(self, kernel_s, plies_timed, launches, timing):
+        """kernel_s: summed duration of the dominant kernel over `launches` launches that played `plies_timed` plies."""
+        total_bytes = sum(self.launch_bytes(pl) for _, pl in self.plan(plies_timed))
+        achieved = total_bytes / kernel_s / 1e9
+        name = {"step": "k_step", "fused": "k_rollout (plies=1)", "collect": f"k_collect ({self.T} plies per launch)"}[self.mode]
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": ("k_step" if self.mode == "step" else "k_rollout (plies=1)")
-                          + ("<mask>" if self.no_obs else "<mask,obs>"),
-                "algorithmic_bytes_per_env_step": self.algo_bytes, "env_steps_per_launch": self.boards,
-                "mean_launch_us": mean_kernel_s * 1e6, "launches_timed": launches, "timing": timing}
+                "kernel": name + ("<mask>" if self.no_obs else "<mask,obs>"),
+                "algorithmic_bytes_per_env_step": total_bytes / (self.boards * plies_timed),
+                "algorithmic_bytes_per_launch": total_bytes / launches,
+                "env_steps_per_launch": self.boards * plies_timed / launches,
+                "mean_launch_us": kernel_s / launches * 1e6, "launches_timed": launches, "timing": timing}
 
 
-def short_run(G, torch, dev, boards, K, W, no_obs=False):
+def short_run(G, torch, dev, boards, K, W, no_obs=False, mode="collect", traj=32):
     """A sub-record: W warm-up plies, K plies as a hipGraph replayed once untimed, then timed between HIP events."""
-    p = Pipeline(G, torch, boards, 0, dev, no_obs=no_obs)
+    p = Pipeline(G, torch, boards, 0, dev, no_obs=no_obs, mode=mode, traj=traj)
     p.eager(W)
     g = p.capture(K)
     g.replay()
@@ -219,10 +268,13 @@ def short_run(G, torch, dev, boards, K, W, no_obs=False):
     b.record()
     torch.cuda.synchronize(dev)
     s = a.elapsed_time(b) / 1e3
+    launches = len(p.plan(K))
     rec = {"workload": f"{boards} boards x 1 GPU, masked-random actions, auto-reset, "
-                       f"{'MASK_ONLY' if no_obs else 'FULL'} outputs every ply, {K} plies as one hipGraph",
+                       f"{'MASK_ONLY' if no_obs else 'FULL'} outputs every ply, mode {mode}, {K} plies "
+                       f"({launches} launches) as one hipGraph",
            "value": boards * K / s, "unit": "env-steps/s", "us_per_step": s / K * 1e6,
-           "roofline": p.kernel_roofline(s / K, K, "HIP events around the graph replay / K (includes kernel boundaries)")}
+           "roofline": p.kernel_roofline(s, K, launches,
+                                         "HIP events around the graph replay (includes kernel boundaries)")}
     del g, p
     return rec
 
@@ -299,7 +351,9 @@ def main():
         env_base, boards = G.shard_bounds(args.boards, world, rank)
         total = args.boards
     K, W = args.steps, args.warmup
-    p = Pipeline(G, torch, boards, env_base, dev, no_obs=args.no_obs, mode=args.mode)
+    args.traj = auto_traj(boards, K, args.traj)
+    p = Pipeline(G, torch, boards, env_base, dev, no_obs=args.no_obs, mode=args.mode, traj=args.traj)
+    nlaunch = len(p.plan(K))
     p.eager(W)  # warm-up plies (untimed): decorrelate game phases, warm caches / code objects
     torch.cuda.synchronize(dev)
 
@@ -310,7 +364,7 @@ def main():
         torch.cuda.synchronize(dev)
         ev = p.events(1)
     else:
-        ev = p.events(K)
+        ev = p.events(nlaunch)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -328,20 +382,22 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # dominant-kernel time for the roofline: HIP events on the launch stream
+    plies_timed = K
     if graph is None:
-        mean_kernel_s = sum(a.elapsed_time(b) for a, b in ev) / K / 1e3
-        launches, timing = K, "HIP event pair around every launch of the dominant kernel"
-    elif args.mode == "fused":
-        mean_kernel_s = ev[0][0].elapsed_time(ev[0][1]) / K / 1e3
-        launches, timing = K, "HIP events around the graph replay / K (includes kernel boundaries)"
+        kernel_s = sum(a.elapsed_time(b) for a, b in ev) / 1e3
+        launches, timing = nlaunch, "HIP event pair around every launch of the dominant kernel"
+    elif args.mode != "step":
+        kernel_s = ev[0][0].elapsed_time(ev[0][1]) / 1e3
+        launches, timing = nlaunch, "HIP events around the graph replay of all launches (includes kernel boundaries)"
     else:
         # two kernels per ply in the graph: time gbl_step on its own with event pairs, eagerly, after the timed region
-        k2 = min(K, 64)
-        ev2 = p.events(k2)
-        p.eager(k2, ev2)
+        plies_timed = launches = min(K, 64)
+        ev2 = p.events(launches)
+        p.eager(launches, ev2)
         torch.cuda.synchronize(dev)
-        mean_kernel_s = sum(a.elapsed_time(b) for a, b in ev2) / k2 / 1e3
-        launches, timing = k2, "HIP event pair around each of %d eager gbl_step launches after the timed replay" % k2
+        kernel_s = sum(a.elapsed_time(b) for a, b in ev2) / 1e3
+        timing = "HIP event pair around each of %d eager gbl_step launches after the timed replay" % launches
+    mean_kernel_s = kernel_s / launches
     per_rank_us = [mean_kernel_s * 1e6]
     if dist is not None:
         cpu = args.dist_backend != "nccl"
@@ -354,9 +410,9 @@ def main():
         per_rank_us = [float(x.item()) for x in allk]
 
     if rank == 0:
-        roof = p.kernel_roofline(mean_kernel_s, launches, timing)
-        roof["traffic"], roof["traffic_source"] = committed_counter(
-            f"{args.mode}{'-noobs' if args.no_obs else ''}:{boards}", "hbm_bytes_per_launch")
+        roof = p.kernel_roofline(kernel_s, plies_timed, launches, timing)
+        tkey = f"{args.mode}{'-noobs' if args.no_obs else ''}:{boards}" + (f":T{min(args.traj, K)}" if args.mode == "collect" else "")
+        roof["traffic"], roof["traffic_source"] = committed_counter(tkey, "hbm_bytes_per_launch")
         variant = "MASK_ONLY" if args.no_obs else "FULL"
         out = {
             "metric": "env-steps/sec at 2^20 parallel boards, 1/2/4/8 MI355X; bit-exact mask/winner",
@@ -375,19 +431,26 @@ def main():
                                    f"actions, auto-reset, {variant} outputs (state+mask{'' if args.no_obs else '+obs'}"
                                    f"+winner+reward+done) every ply",
                        "boards_per_gpu": boards, "total_boards": total, "mode": args.mode,
-                       "launches_per_step": 2 if args.mode == "step" else 1,
+                       "plies_per_launch": args.traj if args.mode == "collect" else 1,
+                       "launches_timed": nlaunch * (2 if args.mode == "step" else 1),
                        "sharding": f"contiguous board ranges, {world} shard(s), no collective on the step path",
-                       "launch": ("hipGraph replay of K plies (device-resident ply index; one untimed warm replay of "
-                                  "the same graph = K more untimed plies before the timed one)") if graph is not None else "eager",
+                       "launch": ("hipGraph replay of the K plies' launches (device-resident ply index; one untimed warm "
+                                  "replay of the same graph = K more untimed plies before the timed one)") if graph is not None else "eager",
                        "kernel_us_per_rank": per_rank_us, "kernel_us_max": max(per_rank_us)},
             "roofline": roof,
         }
         if world == 1 and not args.no_configs:
             cfg = {}
-            for name, n, k, noobs in (("c2_4096", 4096, 200, False), ("c3_262144", 262144, 200, False),
-                                      ("c4_shard_131072", 131072, 200, False), ("large_4194304", 1 << 22, 40, False),
-                                      ("maskonly_1048576", 1 << 20, 100, True)):
-                cfg[name] = short_run(G, torch, dev, n, k, W, no_obs=noobs)
+            for name, n, k, noobs, mode in (
+                    ("c2_4096", 4096, 256, False, "collect"), ("c3_262144", 262144, 128, False, "collect"),
+                    ("c4_shard_131072", 131072, 256, False, "collect"), ("large_4194304", 1 << 22, 32, False, "collect"),
+                    ("maskonly_1048576", 1 << 20, 64, True, "collect"),
+                    # round 1's pipeline, one launch per ply (gbl_rollout, 234 algorithmic bytes per env-step)
+                    ("single_ply_1048576", 1 << 20, 200, False, "fused"), ("single_ply_262144", 262144, 200, False, "fused"),
+                    ("single_ply_131072", 131072, 200, False, "fused"), ("single_ply_4096", 4096, 200, False, "fused"),
+                    ("single_ply_maskonly_1048576", 1 << 20, 200, True, "fused"),
+                    ("single_ply_large_4194304", 1 << 22, 40, False, "fused")):
+                cfg[name] = short_run(G, torch, dev, n, k, W, no_obs=noobs, mode=mode, traj=auto_traj(n, k))
             cfg["c5_greedy_65536"] = greedy_run(G, torch, dev)
             out["configs"] = cfg
         if world == 1 and not args.no_cpu_baseline:

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # GOBBLET_HIP_LIB: load a differently built library of the same ABI (kernel A/B experiments)
 LIB_PATH = os.environ.get("GOBBLET_HIP_LIB") or os.path.join(CSRC, "libgobblet_hip.so")
-SOURCES = [os.path.join(CSRC, "gobblet_hip.hip"), os.path.join(CSRC, "gobblet_device.h"),
+SOURCES = [os.path.join(CSRC, "gobblet_hip.hip"), os.path.join(CSRC, "gobblet_device.h"), os.path.join(CSRC, "gobblet_diag.h"),
            os.path.join(_HERE, "..", "include", "gobblet_hip.h")]
 # -amdgpu-kernarg-preload-count: the first 16 dwords of a kernel's arguments arrive in SGPRs with the wave
 # launch (the kernels order their arguments for that), so a wavefront's first loads do not wait for a
@@ -52,6 +52,8 @@ SIGNATURES = {
     "gbl_validate": (_int, [_vp, _vp, _i64, _vp]),
     "gbl_observe": (_int, [_vp, _vp, _int, _vp, _i64, _vp]),
     "gbl_board_eval": (_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "gbl_pinned_alloc": (_int, [_i64, C.POINTER(_vp), C.POINTER(_vp)]),
+    "gbl_pinned_free": (_int, [_vp]),
     "gbl_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
     "gbl_sample": (_int, [_vp, _vp, _i64, _u64, _u64, _u32, _vp]),
     "gbl_rollout": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u64, _u64, _u32, _u32, _int, _vp, _vp, _vp]),
@@ -62,6 +64,8 @@ SIGNATURES = {
     "gbl_rollout_at": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u64, _u64, _u32, _vp, _u32, _int, _vp, _vp, _vp]),
     "gbl_greedy_act_at": (_int, [_vp, _vp, _vp, _vp, _int, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gbl_counter_add": (_int, [_vp, _u32, _vp]),
+    "gbl_collect": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _u64, _u64, _u32, _vp, _u32, _int,
+                           _vp, _vp, _vp]),
 }
 
 

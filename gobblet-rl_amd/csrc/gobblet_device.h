@@ -355,12 +355,12 @@ struct RegRow {
 // re-staging 7 dwords).  Rows are 27 bytes apart: the clear relies on unaligned LDS stores (gfx950).
 struct ImageRow {
     uint8_t *row;
-    __device__ __forceinline__ void apply(const MoveCells &m)
+    __device__ __forceinline__ void apply(const MoveCells &m) const
     {
         if (m.had) row[m.cold] = 0;
         row[m.cnew] = (uint8_t)m.val;
     }
-    __device__ __forceinline__ void reset() { __builtin_memset(row, 0, kCells); }
+    __device__ __forceinline__ void reset() const { __builtin_memset(row, 0, kCells); }
 };
 
 __device__ __forceinline__ void apply_move(Planes &p, uint32_t (&r)[7], int mover, uint32_t a)
@@ -954,6 +954,71 @@ __device__ __forceinline__ void greedy_replay_sets(GreedyHead &h, uint64_t threa
     for (uint64_t it = threat & todo; it; it &= it - 1) {
         const int a = __builtin_ctzll(it);
         greedy_threat(h, a, reply_of(a), (before_calm >> a) & 1ull);
+    }
+    if (calm) h.chosen = 63 - __builtin_clzll(calm);
+}
+
+// position of the k-th (0-based) set bit of a 54-bit set; k < popcount(m)
+__device__ __forceinline__ uint32_t kth_bit64(uint64_t m, uint32_t k)
+{
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32), nlo = __popc(lo);
+    const bool low = k < nlo;
+    return kth_bit32(low ? lo : hi, low ? k : k - nlo) + (low ? 0u : 32u);
+}
+
+// The depth-2 loop (:103-157) in CLOSED FORM -- no per-candidate iteration.  What the loop does with a candidate
+// that has a winning reply (greedy_threat) depends on the candidate only through three bits of its summary and on
+// how many such candidates came before it:
+//   * each of them takes itself off actions_depth1 while more than one action is left (:129-134), so the j-th of
+//     them (j = 0, 1, ...) is handled iff j < n0 - 1 (n0 = len(actions_depth1) on entry), and those removed are the
+//     first min(count, n0 - 1) of the set;
+//   * the reply loop breaks at the SECOND opponent win only when the removal left a single action (:135-143), i.e.
+//     for j = n0 - 2 only; every earlier one looks at all opponent wins and proposes the first that we could play
+//     ourselves (summary bit 8), the one at j = n0 - 2 with a second winning reply (bit 7) proposes the FIRST winning
+//     reply if that is a legal move of ours;
+//   * a proposal is taken only while chosen_action is None (:142): before the first candidate without a winning
+//     reply, and only the first proposal counts.
+// So the loop's effect is a handful of set operations on per-board candidate sets, which the evaluating lanes
+// accumulate: threat (summary bit 0), allwin (bit 15), second (bit 7), block (bit 8), flegal (first winning reply is
+// a legal move of ours) -- plus ONE summary lookup, for the candidate whose proposal is taken.
+struct ReplySets {
+    uint64_t threat, allwin, second, block, flegal;
+};
+
+template <typename ReplyOf>
+__device__ __forceinline__ void greedy_replay_closed(GreedyHead &h, ReplySets r, ReplyOf reply_of)
+{
+    uint64_t todo = h.todo;
+    // twin placements share their partner's summary (reply_of must serve them too)
+    r.threat |= (r.threat << 9) & h.dup;
+    r.allwin |= (r.allwin << 9) & h.dup;
+    r.second |= (r.second << 9) & h.dup;
+    r.block |= (r.block << 9) & h.dup;
+    r.flegal |= (r.flegal << 9) & h.dup;
+    r.allwin &= todo;
+    if (r.allwin) todo &= below_eq(__builtin_ctzll(r.allwin));  // :151: nothing after the break is looked at
+    const uint64_t calm = todo & ~r.threat;
+    const uint64_t before_calm = calm ? (1ull << __builtin_ctzll(calm)) - 1ull : ~0ull;
+    const uint64_t th = r.threat & todo & h.cands;  // (every candidate of todo is still in actions_depth1)
+    const int m = __popcll(th), n0 = h.ncands;
+    if (m > 0 && n0 > 1) {
+        // A: the first n0 - 2 of th (they never break early); e: the one after them, if any
+        uint64_t A = th, e = 0;
+        if (n0 - 2 < m) {
+            e = 1ull << kth_bit64(th, (uint32_t)(n0 - 2));
+            A = th & (e - 1ull);
+        }
+        const uint64_t e_prop = (e & r.second) ? (e & r.flegal) : (e & r.block);
+        const uint64_t prop = before_calm & ((A & r.block) | e_prop);
+        if (h.chosen < 0 && prop) {
+            const int a = __builtin_ctzll(prop);
+            const uint32_t s = reply_of(a);
+            const bool early = ((e >> a) & 1ull) && ((r.second >> a) & 1ull);  // broke at the second opponent win
+            h.chosen = early ? (int)((s >> 1) & 63u) : (int)((s >> 9) & 63u);
+        }
+        const uint64_t removed = A | e;
+        h.cands &= ~removed;
+        h.ncands = n0 - __popcll(removed);
     }
     if (calm) h.chosen = 63 - __builtin_clzll(calm);
 }

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "../../include/gobblet_hip.h"
+#include "gobblet_diag.h"
 
 using namespace gbl;
 
@@ -52,16 +53,16 @@ inline Geometry geometry(int64_t n, int waves = 1)
 constexpr int kStepWaves = GBL_WG_WAVES;
 
 // Non-temporal store policy of the step kernels (see store_rows): stream the observation always, the
-// mask too once one ply's footprint exceeds the 256 MiB Infinity Cache.  GBL_NT_POLICY (environment,
-// read once) overrides it for A/B runs.
+// mask too once one ply's footprint exceeds the 256 MiB Infinity Cache.  A pure function of the batch size: the
+// library reads no environment and keeps no state; A/B builds pin a policy with -DGBL_FORCE_NT=1|3
+// (scripts/build_variant.sh).
 inline int nt_policy(int64_t n)
 {
-    static const int forced = [] {
-        const char *e = getenv("GBL_NT_POLICY");
-        return e ? atoi(e) : -1;
-    }();
-    if (forced >= 0) return forced & 7;
+#ifdef GBL_FORCE_NT
+    return (GBL_FORCE_NT) == 3 ? 3 : 1;
+#else
     return n * 234 > ((int64_t)256 << 20) ? 3 : 1;
+#endif
 }
 
 // LDS words for a tile image of ROWB-byte rows (+ slack for row_load's look-ahead dword)
@@ -76,11 +77,11 @@ struct Lane {
     bool valid;
 };
 
-template <int W = 1>
+template <int W = 1, bool XCD_REMAP = true>
 __device__ __forceinline__ bool lane_setup(Lane &L, int64_t n, int64_t ntiles)
 {
     if (W == 1) {
-        L.tile = xcd_tile(blockIdx.x, ntiles);
+        L.tile = XCD_REMAP ? xcd_tile(blockIdx.x, ntiles) : (int64_t)blockIdx.x;
         L.lane = threadIdx.x;
     } else {  // W consecutive tiles per workgroup, one per wavefront
         L.tile = xcd_tile(blockIdx.x, (ntiles + W - 1) / W) * W + (threadIdx.x >> 6);
@@ -101,11 +102,17 @@ __device__ __forceinline__ void load_state(const int8_t *state, uint32_t *img, c
     tile_in<kCells>(state + L.tile * (kTile * kCells), img, L.lane, L.rows, between);
     wave_lds_fence();
     row_load<kCells>(img, L.lane, r);
-    r[6] &= 0x00FFFFFFu;
-    if (!L.valid) {
-#pragma unroll
-        for (int j = 0; j < 7; ++j) r[j] = 0;
-    }
+    r[6] &= 0x00FFFFFFu;  // (lanes past the end of a ragged last tile hold whatever the image held: see planes_of)
+}
+
+// The board's bit planes; lanes past the end of a ragged last tile get an EMPTY board (one select on the occupancy
+// plane -- the other two are only read where it is set -- instead of seven on the row's dwords).  Nothing such a
+// lane computes is ever stored: ragged tiles are written back byte-granular, valid rows only.
+__device__ __forceinline__ Planes planes_of(const Lane &L, const uint32_t (&r)[7])
+{
+    Planes p = make_planes(r);
+    p.nz = L.valid ? p.nz : 0u;
+    return p;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(64) void k_legal_mask(const int8_t *__restrict__ st
     if (!lane_setup(L, n, ntiles)) return;
     uint32_t r[7];
     load_state(state, s_state, L, r);
-    Planes p = make_planes(r);
+    Planes p = planes_of(L, r);
     int mover = L.valid ? to_move[L.b] : 0;
     uint32_t d[14];
     mask_row(legal54(p, mover != 0), d);
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(64) void k_is_legal(const int8_t *__restrict__ stat
     uint32_t r[7];
     load_state(state, s_state, L, r);
     if (!L.valid) return;
-    Planes p = make_planes(r);
+    Planes p = planes_of(L, r);
     int a = actions[L.b];
     uint64_t m = legal54(p, agent[L.b] != 0);
     bool ok = (uint32_t)a < (uint32_t)kActions && ((m >> (a & 63)) & 1ull);
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(64) void k_play_turn(int8_t *__restrict__ state, co
     if (!lane_setup(L, n, ntiles)) return;
     uint32_t r[7];
     load_state(state, s_state, L, r);
-    Planes p = make_planes(r);
+    Planes p = planes_of(L, r);
     int a = L.valid ? actions[L.b] : 0;
     int mover = L.valid ? (agent[L.b] != 0) : 0;
     uint64_t m = legal54(p, mover);
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(64) void k_winner(const int8_t *__restrict__ state,
     uint32_t r[7];
     load_state(state, s_state, L, r);
     if (!L.valid) return;
-    winner[L.b] = (int8_t)winner_of(make_planes(r));
+    winner[L.b] = (int8_t)winner_of(planes_of(L, r));
 }
 
 __global__ __launch_bounds__(64) void k_flatboard(const int8_t *__restrict__ state, int8_t *__restrict__ flat, int64_t n,
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(64) void k_flatboard(const int8_t *__restrict__ sta
     uint32_t r[7];
     load_state(state, s_state, L, r);
     uint32_t d[3];
-    flat_row(make_planes(r), r, d);
+    flat_row(planes_of(L, r), r, d);
     row_stage<9>(s_flat, L.lane, d);
     wave_lds_fence();
     tile_out<9>(flat + L.tile * (kTile * 9), s_flat, L.lane, L.rows);
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(64) void k_covered(const int8_t *__restrict__ state
     uint32_t r[7];
     load_state(state, s_state, L, r);
     uint32_t d[7];
-    covered_row(make_planes(r), d);
+    covered_row(planes_of(L, r), d);
     wave_lds_fence();  // every lane has read its row before the image is reused
     row_stage<kCells>(s_state, L.lane, d);
     wave_lds_fence();
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(64) void k_observe(const int8_t *__restrict__ state
     int who = agent_sel >= 0 ? agent_sel : (L.valid ? to_move[L.b] : 0);
     obs_image_zero(s_obs, L.lane);
     wave_lds_fence();
-    obs_scatter(s_obs, L.lane, make_planes(r), who != 0);
+    obs_scatter(s_obs, L.lane, planes_of(L, r), who != 0);
     wave_lds_fence();
     tile_out<kObs, true>(obs + L.tile * (kTile * kObs), s_obs, L.lane, L.rows);
 }
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(64) void k_board_eval(int8_t *__restrict__ state, c
     if (!lane_setup(L, n, ntiles)) return;
     uint32_t r[7];
     load_state(state, s_state, L, r);
-    Planes p = make_planes(r);
+    Planes p = planes_of(L, r);
     if (actions) {  // board.py:118-132
         const int a = L.valid ? actions[L.b] : -1;
         const int mover = L.valid ? (agent[L.b] != 0) : 0;
@@ -321,6 +328,31 @@ static_assert(image_words<kObs>() % 4 == 0 && image_words<kActions>() % 4 == 0 &
 // stream gains once a ply's footprint (234 B per board) no longer fits the 256 MiB Infinity Cache
 // (2^22 boards: 169 -> 141 us) and loses ~2 % below that; the state rows are re-read next ply and stay
 // cached.  The host picks the variant from the batch size (nt_policy()).
+// the tile's observation rows (raw_env.observe of `observer`) through the image `img`; obs_out: row 0 of the array
+template <bool NT>
+__device__ __forceinline__ void store_obs(uint32_t *img, const Lane &L, const Planes &p, int observer,
+                                          int8_t *__restrict__ obs_out)
+{
+    obs_image_zero(img, L.lane);
+    wave_lds_fence();
+    obs_scatter(img, L.lane, p, observer);
+    wave_lds_fence();
+    tile_out<kObs, NT>(obs_out + L.tile * (kTile * kObs), img, L.lane, L.rows);
+    wave_lds_fence();
+}
+
+// the tile's mask rows from 54-bit sets
+template <bool NT>
+__device__ __forceinline__ void store_mask(uint32_t *img, const Lane &L, uint64_t legal, int8_t *__restrict__ mask_out)
+{
+    uint32_t d[14];
+    mask_row(legal, d);
+    row_stage<kActions>(img, L.lane, d);
+    wave_lds_fence();
+    tile_out<kActions, NT>(mask_out + L.tile * (kTile * kActions), img, L.lane, L.rows);
+    wave_lds_fence();
+}
+
 template <bool WITH_MASK, bool WITH_OBS, int NT>
 __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, bool mask_zero, const Planes &p, int observer,
                                            int8_t *__restrict__ state, int8_t *__restrict__ mask_out,
@@ -329,53 +361,13 @@ __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, bool ma
     wave_lds_fence();  // every lane's byte patches are in the image
     tile_out<kCells, (NT & 4) != 0>(state + L.tile * (kTile * kCells), img, L.lane, L.rows);
     wave_lds_fence();
-    if (WITH_OBS) {
-        obs_image_zero(img, L.lane);
-        wave_lds_fence();
-        obs_scatter(img, L.lane, p, observer);
-        wave_lds_fence();
-        tile_out<kObs, (NT & 1) != 0>(obs_out + L.tile * (kTile * kObs), img, L.lane, L.rows);
-        wave_lds_fence();
-    }
-    if (WITH_MASK) {
-        // the next mover's legal mask is computed only now, behind the state and observation stores: the
-        // sooner a wave's first stores are in flight, the shorter the launch's ramp-up
-        uint32_t d[14];
-        mask_row(mask_zero ? 0ull : legal54(p, observer), d);
-        row_stage<kActions>(img, L.lane, d);
-        wave_lds_fence();
-        tile_out<kActions, (NT & 2) != 0>(mask_out + L.tile * (kTile * kActions), img, L.lane, L.rows);
-    }
+    if (WITH_OBS) store_obs<(NT & 1) != 0>(img, L, p, observer, obs_out);
+    // the next mover's legal mask is computed only now, behind the state and observation stores: the
+    // sooner a wave's first stores are in flight, the shorter the launch's ramp-up
+    if (WITH_MASK) store_mask<(NT & 2) != 0>(img, L, mask_zero ? 0ull : legal54(p, observer), mask_out);
 }
 
-// Diagnostic build only (-DGBL_STAMPS): per-wavefront s_memtime stamps of the fused kernel's phases,
-// written to a side buffer that nothing else reads (scripts/microbench/phase_stamps.py).  In the real
-// build the macros expand to nothing.
-#ifdef GBL_STAMPS
-__device__ unsigned long long g_stamps[1 << 17][12];
-#define GBL_STAMP(i) unsigned long long st_##i = __builtin_amdgcn_s_memtime()
-#define GBL_STAMP_REAL(i) unsigned long long rt_##i = __builtin_amdgcn_s_memrealtime()
-#define GBL_STAMP_DEP(i, v)                                  \
-    asm volatile("" ::"v"(v));                               \
-    unsigned long long st_##i = __builtin_amdgcn_s_memtime()
-#define GBL_STAMP_DRAIN(i)                                   \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         \
-    unsigned long long st_##i = __builtin_amdgcn_s_memtime()
-#define GBL_STAMP_FLUSH(tile)                                                                              \
-    if (threadIdx.x == 0 && (tile) < (1 << 17)) {                                                          \
-        unsigned long long *o_ = g_stamps[tile];                                                           \
-        o_[0] = st_0; o_[1] = st_1; o_[2] = st_2; o_[3] = st_3; o_[4] = st_4; o_[5] = st_5;               \
-        o_[6] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); /* HW_REG_HW_ID */                   \
-        o_[7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); /* HW_REG_XCC_ID */                 \
-        o_[8] = rt_0; o_[9] = __builtin_amdgcn_s_memrealtime(); /* 100 MHz, chip-wide */                  \
-    }
-#else
-#define GBL_STAMP(i)
-#define GBL_STAMP_REAL(i)
-#define GBL_STAMP_DEP(i, v)
-#define GBL_STAMP_DRAIN(i)
-#define GBL_STAMP_FLUSH(tile)
-#endif
+// (GBL_STAMP* : per-wavefront phase stamps of the diagnostic build, gobblet_diag.h; they expand to nothing here)
 
 // gbl_step: fused raw_env.step + observe(next mover) over a tile of boards.
 // (argument order: what a wavefront needs first comes first -- the first 16 dwords are preloaded into SGPRs at
@@ -403,7 +395,7 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_step(int8_t *__restrict__ s
     mover = L.valid && mover != 0;
     was_done = L.valid && !auto_reset && was_done != 0;
     action = L.valid ? action : 0;
-    Planes p = make_planes(r);
+    Planes p = planes_of(L, r);
     Ply y;
     int dn;
     step_lane(ImageRow{reinterpret_cast<uint8_t *>(s_img) + L.lane * kCells}, p, mover, was_done, action, illegal_mode,
@@ -451,7 +443,7 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_rollout(int8_t *__restrict_
     load_state(state, s_img, L, r, [&] { block = draw_block(seed, env_base + (uint64_t)L.b, ply0); });
     mover = L.valid && mover != 0;
     GBL_STAMP_DEP(1, r[0] + (uint32_t)mover);
-    Planes p = make_planes(r);
+    Planes p = planes_of(L, r);
     const ImageRow row{reinterpret_cast<uint8_t *>(s_img) + L.lane * kCells};  // the board's row, patched in place
     uint32_t games = 0, w1 = 0, w2 = 0;  // wave-uniform tallies (ballot + popcount)
     Ply y{0, 0, 0, false, false};
@@ -495,6 +487,101 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_rollout(int8_t *__restrict_
     GBL_STAMP(4);
     GBL_STAMP_DRAIN(5);
     GBL_STAMP_FLUSH(L.tile);
+}
+
+// gbl_collect: `plies` masked-random plies per launch with EVERY ply's outputs materialised -- ply t writes its
+// action, winner, reward, done, next mover, legal mask and observation into slot t of trajectory arrays
+// ([plies][slot_boards][...]), exactly what `plies` launches of gbl_rollout(plies = 1) with advancing output
+// pointers leave behind.  The tile's state is loaded once, lives in its LDS image (patched per move) and in the
+// lane's bit planes for all plies, and is stored once; a wavefront's stores of ply t drain while it computes
+// ply t + 1, there is no kernel boundary, no launch ramp and no state traffic between plies, and the legal mask
+// stored for the next mover is the one the next ply samples from (computed once).
+#ifndef GBL_X_COLLECT_WAVES
+#define GBL_X_COLLECT_WAVES 1
+#endif
+template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY>
+__global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n,
+                                                int64_t ntiles, uint64_t seed, uint64_t env_base,
+                                                const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies,
+                                                int8_t *__restrict__ done, int64_t slot_boards,
+                                                int32_t *__restrict__ actions_t, int8_t *__restrict__ winner_t,
+                                                int8_t *__restrict__ reward_t, int8_t *__restrict__ done_t,
+                                                int8_t *__restrict__ to_move_t, int8_t *__restrict__ mask_t,
+                                                int8_t *__restrict__ obs_t, int illegal_mode,
+                                                int64_t *__restrict__ counters, int32_t *__restrict__ turn)
+{
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    __shared__ uint32_t s_out[out_image_words<true, WITH_OBS>()];
+    if (DEV_PLY) ply0 += *ply_dev;
+    Lane L;
+#ifdef GBL_X_COLLECT_REMAP
+    if (!lane_setup(L, n, ntiles)) return;
+#else
+    // identity block -> tile map: the trajectory is written once and streams to HBM, where ONE write front per
+    // array beats eight (one per XCD) -- unlike the single-ply kernels, whose outputs are rewritten every launch
+    if (!lane_setup<1, false>(L, n, ntiles)) return;
+#endif
+    int mover = to_move[L.valid ? L.b : n - 1];
+    uint32_t r[7];
+    Draw4 block{{0u, 0u, 0u, 0u}};
+    load_state(state, s_state, L, r, [&] { block = draw_block(seed, env_base + (uint64_t)L.b, ply0); });
+    mover = L.valid && mover != 0;
+    Planes p = planes_of(L, r);
+    const ImageRow row{reinterpret_cast<uint8_t *>(s_state) + L.lane * kCells};
+    uint32_t games = 0, w1 = 0, w2 = 0;
+    Ply y{0, 0, 0, false, false};
+    int dn = 0, tcount = 0;
+    bool treset = false;
+    uint64_t legal = legal54(p, mover);
+    for (uint32_t t = 0; t < plies; ++t) {
+        const uint32_t ply = ply0 + t;
+        const int action = pick54(legal, draw_word(block, ply));
+        if (t + 1 < plies && ((ply + 1) & 3u) == 0) block = draw_block(seed, env_base + (uint64_t)L.b, ply + 1);
+        {  // step_lane with the mover's mask at hand
+            y = play_ply(p, row, mover, legal, action, illegal_mode);
+            dn = y.terminal ? 1 : 0;
+            if (y.terminal) {  // raw_env.reset, gobblet.py:275-290
+                p = Planes{0u, 0u, 0u};
+                mover = 0;
+                row.reset();
+            }
+        }
+        tcount = next_turn(tcount, y, 1);
+        treset = treset || y.terminal;
+        if (counters) {
+            games += __popcll(__ballot(L.valid && y.terminal));
+            w1 += __popcll(__ballot(L.valid && y.winner == 1));
+            w2 += __popcll(__ballot(L.valid && y.winner == -1));
+        }
+        // slot t
+        const int64_t slot = (int64_t)t * slot_boards;
+        if (L.valid) {
+            const int64_t at = slot + L.b;
+            if (actions_t) actions_t[at] = action;
+            if (winner_t) winner_t[at] = (int8_t)y.winner;
+            if (reward_t) reinterpret_cast<uint16_t *>(reward_t)[at] = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
+            if (done_t) done_t[at] = (int8_t)dn;
+            if (to_move_t) to_move_t[at] = (int8_t)mover;
+        }
+        if (WITH_OBS) store_obs<true>(s_out, L, p, mover, obs_t + slot * kObs);
+        legal = legal54(p, mover);  // the next mover's: stored now, sampled from next ply
+        if (WITH_MASK) store_mask<true>(s_out, L, legal, mask_t + slot * kActions);
+    }
+    wave_lds_fence();  // every lane's byte patches are in the state image
+    tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
+    if (L.valid) {
+        to_move[L.b] = (int8_t)mover;
+        done[L.b] = (int8_t)dn;
+        if (turn) turn[L.b] = treset ? tcount : turn[L.b] + tcount;
+    }
+    if (counters && L.lane == 0) {
+        unsigned long long *c = reinterpret_cast<unsigned long long *>(counters) +
+                                (size_t)(L.tile % GBL_COUNTER_STRIPES) * GBL_COUNTER_STRIDE;
+        atomicAdd(c + 0, (unsigned long long)L.rows * plies);
+        if (games) atomicAdd(c + 1, (unsigned long long)games);
+        if (w1) atomicAdd(c + 2, (unsigned long long)w1);
+        if (w2) atomicAdd(c + 3, (unsigned long long)w2);
+    }
 }
 
 // gbl_counter_add: the device-resident ply / call counter of the *_at entry points
@@ -589,12 +676,23 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
     __shared__ uint32_t s_mask[image_words<kActions>()];
     __shared__ uint32_t s_board[kTile][4];          // planes nz, neg, odd and the agent to move
     __shared__ uint64_t s_legal[kTile];             // its legal moves on the root position
-    __shared__ uint16_t s_pair[kTile * kActions];   // (owner lane << 8) | candidate, lists back to back
+    // (board << 8) | candidate of every depth-2 evaluation, in kSegs segments: segment g lists candidates
+    // [g * kSeg, (g + 1) * kSeg) of all 64 boards and is built by wavefront g mod W
+    constexpr int kSegs = W >= 2 ? W : 2, kSeg = (kActions + kSegs - 1) / kSegs, kSegCap = kTile * kSeg;
+    static_assert(kSeg <= 32, "a segment's candidates fit one 32-bit word");
+    __shared__ uint16_t s_pair[kSegs * kSegCap];
+    __shared__ unsigned long long s_work[kTile];    // the candidates of a board that get an evaluation of their own
+    __shared__ int s_count[kSegs];
     __shared__ uint16_t s_reply[kTile][kActions];   // greedy_reply() of (board, candidate), where bit 0 is set
-    __shared__ unsigned long long s_threat[kTile];  // candidates whose summary has bit 0 / bit 15
-    __shared__ unsigned long long s_allwin[kTile];
-    __shared__ int s_total, s_deferred;
+    __shared__ unsigned long long s_threat[kTile];  // candidates whose summary has bit 0 / bit 15 / bit 7 / bit 8,
+    __shared__ unsigned long long s_allwin[kTile];  // and those whose first winning reply is a legal move of ours
+    __shared__ unsigned long long s_second[kTile];  // (the sets greedy_replay_closed works on)
+    __shared__ unsigned long long s_block[kTile];
+    __shared__ unsigned long long s_flegal[kTile];
+    __shared__ int s_deferred;
     __shared__ uint16_t s_again[kTile * kActions];  // pairs that need the exact evaluation (greedy_reply<true>)
+    GBL_STAMP(0);
+    GBL_STAMP_REAL(0);
     Lane L;
     if (!lane_setup(L, n, ntiles)) return;  // the same for every thread of the workgroup
     const int slot = L.lane;                // 0 .. 64 W - 1
@@ -608,10 +706,19 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
     uint32_t prev3 = 0x00FFFFFFu;
     int total = 0, me = 0;
     if (owner) {
+        // per-board scalars first, branch-free from a clamped index: in flight together with the tile (see k_step);
+        // the history of BOTH agents (6 bytes, 2-byte aligned), the mover picks its three below
+        const int64_t bs = L.valid ? L.b : n - 1;
+        const int tm = to_move[bs];
+        uint32_t h0 = 0xFFFFu, h1 = 0xFFFFu, h2 = 0xFFFFu;
+        if (hist) {
+            const uint16_t *hp = reinterpret_cast<const uint16_t *>(hist + bs * 6);
+            h0 = hp[0]; h1 = hp[1]; h2 = hp[2];
+        }
         uint32_t r[7];
         load_state(state, s_state, L, r);
-        Planes p = make_planes(r);
-        me = L.valid ? (to_move[L.b] != 0) : 0;
+        Planes p = planes_of(L, r);
+        me = L.valid ? (tm != 0) : 0;
         uint64_t mask;
         if (mask_in) {
             tile_in<kActions>(mask_in + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
@@ -624,10 +731,8 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
             mask = legal54(p, me);
         }
         if (!L.valid) mask = 0;
-        if (hist && L.valid) {
-            const int8_t *hp = hist + (L.b * 2 + me) * 3;
-            prev3 = (uint32_t)(uint8_t)hp[0] | ((uint32_t)(uint8_t)hp[1] << 8) | ((uint32_t)(uint8_t)hp[2] << 16);
-        }
+        if (hist && L.valid)  // bytes 0-2: player_1's last three actions, bytes 3-5: player_2's
+            prev3 = me ? ((h1 >> 8) | (h2 << 8)) & 0x00FFFFFFu : (h0 | (h1 << 16)) & 0x00FFFFFFu;
         h = greedy_head(p, me, mask, depth);  // invalid lanes: empty mask, nothing to do
         if (depth > 1) {
             s_board[L.lane][0] = p.nz;
@@ -637,37 +742,61 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
             s_legal[L.lane] = h.legal_me;
             s_threat[L.lane] = 0ull;
             s_allwin[L.lane] = 0ull;
-            const uint64_t work = h.todo & ~h.dup;  // twin placements are not evaluated a second time
-            const int mine = __popcll(work);
-            int upto = mine;  // inclusive prefix sum of the list lengths over the wavefront
-#pragma unroll
-            for (int d = 1; d < kTile; d <<= 1) {
-                int v = __shfl_up(upto, d);
-                upto += L.lane >= d ? v : 0;
-            }
-            total = __shfl(upto, kTile - 1);
-            if (L.lane == kTile - 1) {
-                s_total = total;
-                s_deferred = 0;
-            }
-            int k = upto - mine;
-            for (uint64_t it = work; it; it &= it - 1)
-                s_pair[k++] = (uint16_t)((L.lane << 8) | __builtin_ctzll(it));
+            s_second[L.lane] = 0ull;
+            s_block[L.lane] = 0ull;
+            s_flegal[L.lane] = 0ull;
+            s_work[L.lane] = h.todo & ~h.dup;  // twin placements are not evaluated a second time
+            if (L.lane == 0) s_deferred = 0;
         }
     }
+    GBL_STAMP(1);
+    GBL_STAMP_DECL(2);
     if (depth > 1) {
         pool_fence<W>();
-        if (W > 1) total = s_total;
+        // The pair lists, by all W wavefronts: lane = board.  One ballot per candidate compacts the boards that have
+        // it (no per-lane loop, no divergence); the order of a list is irrelevant, results land in per-board sets.
+        for (int sg = slot >> 6; sg < kSegs; sg += W) {
+            const uint32_t wk = (uint32_t)(s_work[L.lane] >> (sg * kSeg)) & (uint32_t)((1ull << kSeg) - 1ull);
+            const uint32_t tag = ((uint32_t)L.lane << 8) + (uint32_t)(sg * kSeg);
+            uint16_t *seg = s_pair + sg * kSegCap;
+            uint32_t cnt = 0;  // wave-uniform
+#pragma unroll
+            for (int j = 0; j < kSeg; ++j) {
+                const bool has = (wk >> j) & 1u;
+                const unsigned long long m = __ballot(has);
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, cnt));
+                if (has) seg[at] = (uint16_t)(tag + j);
+                cnt += (uint32_t)__popcll(m);
+            }
+            if (L.lane == 0) s_count[sg] = (int)cnt;
+        }
+        pool_fence<W>();
+        int seg_end[kSegs];  // cumulative list lengths
+        total = 0;
+#pragma unroll
+        for (int w = 0; w < kSegs; ++w) seg_end[w] = (total += s_count[w]);
+        auto pair_at = [&](int g) -> uint32_t {
+            int w = 0, start = 0;
+#pragma unroll
+            for (int k = 0; k + 1 < kSegs; ++k) {
+                w += g >= seg_end[k] ? 1 : 0;
+                start = g >= seg_end[k] ? seg_end[k] : start;
+            }
+            return s_pair[w * kSegCap + (g - start)];
+        };
         auto record = [&](uint32_t o, uint32_t a, uint32_t sum) {
             if (sum & 1u) {
                 s_reply[o][a] = (uint16_t)sum;
                 atomicOr(&s_threat[o], 1ull << a);
+                if (sum & (1u << 7)) atomicOr(&s_second[o], 1ull << a);
+                if (sum & (1u << 8)) atomicOr(&s_block[o], 1ull << a);
+                if ((s_legal[o] >> ((sum >> 1) & 63u)) & 1ull) atomicOr(&s_flegal[o], 1ull << a);
             }
             if (sum >> 15) atomicOr(&s_allwin[o], 1ull << a);
         };
         // first round: the cheap evaluation; the few pairs where a lift could hand us a line are set aside
         for (int g = slot; g < total; g += kTile * W) {
-            const uint32_t pair = s_pair[g], o = pair >> 8, a = pair & 0xFFu;
+            const uint32_t pair = pair_at(g), o = pair >> 8, a = pair & 0xFFu;
             const Planes q{s_board[o][0], s_board[o][1], s_board[o][2]};
             const uint32_t sum = greedy_reply<false>(q, (int)s_board[o][3], s_legal[o], a);
             if (sum == kGreedyDefer)
@@ -676,6 +805,7 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
                 record(o, a, sum);
         }
         pool_fence<W>();
+        GBL_STAMP_SET(2);
         const int again = s_deferred;
         for (int g = slot; g < again; g += kTile * W) {
             const uint32_t pair = s_again[g], o = pair >> 8, a = pair & 0xFFu;
@@ -684,11 +814,12 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
         }
         pool_fence<W>();
     }
+    GBL_STAMP(3);
     if (!owner) return;
-    if (depth > 1)  // :103-157 in order, on the owner's lane
-        greedy_replay_sets(h, s_threat[L.lane], s_allwin[L.lane], [&](int a) {
-            return (uint32_t)s_reply[L.lane][((h.dup >> a) & 1ull) ? a - 9 : a];
-        });
+    if (depth > 1)  // :103-157 on the owner's lane, in closed form over the candidate sets
+        greedy_replay_closed(h, ReplySets{s_threat[L.lane], s_allwin[L.lane], s_second[L.lane], s_block[L.lane],
+                                          s_flegal[L.lane]},
+                             [&](int a) { return (uint32_t)s_reply[L.lane][((h.dup >> a) & 1ull) ? a - 9 : a]; });
     GreedyResult g = greedy_finish(h, prev3);
     if (cand_out) {
         uint32_t d[14];
@@ -710,6 +841,9 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
             hp[2] = (int8_t)fin;
         }
     }
+    GBL_STAMP(4);
+    GBL_STAMP_DRAIN(5);
+    GBL_STAMP_FLUSH(L.tile);
 }
 
 }  // namespace
@@ -739,12 +873,6 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
 
 extern "C" {
 
-#ifdef GBL_STAMPS
-int gbl_debug_stamps(unsigned long long *host_out, int64_t ntiles)
-{
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), (size_t)ntiles * 12 * sizeof(unsigned long long));
-}
-#endif
 
 const char *gbl_last_error(void) { return g_err; }
 
@@ -844,6 +972,31 @@ int gbl_observe(const int8_t *state, const int8_t *to_move, int agent_sel, int8_
     GBL_LAUNCHED("gbl_observe");
 }
 
+int gbl_pinned_alloc(int64_t bytes, void **host_ptr, void **dev_ptr)
+{
+    if (bytes <= 0 || !host_ptr || !dev_ptr) return fail(GBL_ERR_ARG, "gbl_pinned_alloc: bytes > 0, host_ptr and dev_ptr required");
+    void *h = nullptr, *d = nullptr;
+    hipError_t e = hipHostMalloc(&h, (size_t)bytes, hipHostMallocMapped | hipHostMallocPortable);
+    if (e != hipSuccess) return hip_fail(e, "gbl_pinned_alloc");
+    e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) {
+        (void)hipHostFree(h);
+        return hip_fail(e, "gbl_pinned_alloc (device pointer)");
+    }
+    memset(h, 0, (size_t)bytes);
+    *host_ptr = h;
+    *dev_ptr = d;
+    return GBL_OK;
+}
+
+int gbl_pinned_free(void *host_ptr)
+{
+    if (!host_ptr) return GBL_OK;
+    hipError_t e = hipHostFree(host_ptr);
+    if (e != hipSuccess) return hip_fail(e, "gbl_pinned_free");
+    return GBL_OK;
+}
+
 int gbl_board_eval(int8_t *state, const int8_t *agent_index, const int32_t *actions, int8_t *record_out, int64_t n,
                    void *stream)
 {
@@ -870,6 +1023,7 @@ int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *action
     if (reward_out && (reinterpret_cast<uintptr_t>(reward_out) & 1u))
         return fail(GBL_ERR_ALIGN, "reward_out must be 2-byte aligned");
     if (turn && (reinterpret_cast<uintptr_t>(turn) & 3u)) return fail(GBL_ERR_ALIGN, "turn must be 4-byte aligned");
+    if (reinterpret_cast<uintptr_t>(actions) & 3u) return fail(GBL_ERR_ALIGN, "actions must be 4-byte aligned");
     Geometry g = geometry(n, kStepWaves);
     hipStream_t s = (hipStream_t)stream;
     auto_reset = auto_reset != 0;
@@ -878,12 +1032,8 @@ int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *action
     hipLaunchKernelGGL((k_step<M, O, NT>), dim3(g.grid), dim3(64 * kStepWaves), 0, s, state, to_move, done, actions, \
                        n, g.ntiles, illegal_mode, auto_reset, winner_out, reward_out, mask_out, obs_out, turn)
 #define GBL_STEP(M, O)                                          \
-    switch (nt) {                                               \
-    case 0: GBL_STEP_NT(M, O, 0); break;                        \
-    case 1: GBL_STEP_NT(M, O, 1); break;                        \
-    case 7: GBL_STEP_NT(M, O, 7); break;                        \
-    default: GBL_STEP_NT(M, O, 3); break;                       \
-    }
+    if (nt == 3) GBL_STEP_NT(M, O, 3);                          \
+    else GBL_STEP_NT(M, O, 1);
     if (mask_out && obs_out) GBL_STEP(true, true)
     else if (mask_out) GBL_STEP(true, false)
     else if (obs_out) GBL_STEP(false, true)
@@ -941,6 +1091,9 @@ int gbl_rollout_at(int8_t *state, int8_t *to_move, int8_t *done, int32_t *action
         return fail(GBL_ERR_ALIGN, "reward_out must be 2-byte aligned");
     if (counters && (reinterpret_cast<uintptr_t>(counters) & 127u))
         return fail(GBL_ERR_ALIGN, "counters must be 128-byte aligned");
+    if (turn && (reinterpret_cast<uintptr_t>(turn) & 3u)) return fail(GBL_ERR_ALIGN, "turn must be 4-byte aligned");
+    if (actions_out && (reinterpret_cast<uintptr_t>(actions_out) & 3u))
+        return fail(GBL_ERR_ALIGN, "actions_out must be 4-byte aligned");
     Geometry g = geometry(n, kStepWaves);
     hipStream_t s = (hipStream_t)stream;
     const int nt = nt_policy(n);
@@ -952,12 +1105,8 @@ int gbl_rollout_at(int8_t *state, int8_t *to_move, int8_t *done, int32_t *action
     if (ply_dev) GBL_ROLL_K(M, O, NT, true);                    \
     else GBL_ROLL_K(M, O, NT, false)
 #define GBL_ROLL(M, O)                                          \
-    switch (nt) {                                               \
-    case 0: GBL_ROLL_NT(M, O, 0); break;                        \
-    case 1: GBL_ROLL_NT(M, O, 1); break;                        \
-    case 7: GBL_ROLL_NT(M, O, 7); break;                        \
-    default: GBL_ROLL_NT(M, O, 3); break;                       \
-    }
+    if (nt == 3) { GBL_ROLL_NT(M, O, 3); }                      \
+    else { GBL_ROLL_NT(M, O, 1); }
     if (mask_out && obs_out) GBL_ROLL(true, true)
     else if (mask_out) GBL_ROLL(true, false)
     else if (obs_out) GBL_ROLL(false, true)
@@ -966,6 +1115,43 @@ int gbl_rollout_at(int8_t *state, int8_t *to_move, int8_t *done, int32_t *action
 #undef GBL_ROLL_NT
 #undef GBL_ROLL_K
     GBL_LAUNCHED("gbl_rollout");  // (also gbl_rollout_at)
+}
+
+int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_traj, int8_t *winner_traj,
+                int8_t *reward_traj, int8_t *done_traj, int8_t *to_move_traj, int8_t *mask_traj, int8_t *obs_traj,
+                int64_t n, int64_t slot_boards, uint64_t seed, uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev,
+                uint32_t plies, int illegal_mode, int64_t *counters, int32_t *turn, void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done");
+    if (illegal_mode != GBL_ILLEGAL_NOOP && illegal_mode != GBL_ILLEGAL_TERMINATE)
+        return fail(GBL_ERR_ARG, "illegal_mode must be GBL_ILLEGAL_NOOP or GBL_ILLEGAL_TERMINATE");
+    if (plies == 0) return GBL_OK;
+    if (slot_boards < n || (slot_boards & 15)) return fail(GBL_ERR_ARG, "slot_boards must be >= n and a multiple of 16");
+    GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask_traj, "mask_traj"); GBL_ALIGNED(obs_traj, "obs_traj");
+    if (reward_traj && (reinterpret_cast<uintptr_t>(reward_traj) & 1u))
+        return fail(GBL_ERR_ALIGN, "reward_traj must be 2-byte aligned");
+    if (actions_traj && (reinterpret_cast<uintptr_t>(actions_traj) & 3u))
+        return fail(GBL_ERR_ALIGN, "actions_traj must be 4-byte aligned");
+    if (turn && (reinterpret_cast<uintptr_t>(turn) & 3u)) return fail(GBL_ERR_ALIGN, "turn must be 4-byte aligned");
+    if (counters && (reinterpret_cast<uintptr_t>(counters) & 127u))
+        return fail(GBL_ERR_ALIGN, "counters must be 128-byte aligned");
+    Geometry g = geometry(n);
+    hipStream_t s = (hipStream_t)stream;
+#define GBL_COLLECT_K(M, O, D)                                                                                        \
+    hipLaunchKernelGGL((k_collect<M, O, D>), dim3(g.grid), dim3(64), 0, s, state, to_move, n, g.ntiles, seed, env_base, \
+                       ply_dev, ply0, plies, done, slot_boards, actions_traj, winner_traj, reward_traj, done_traj,     \
+                       to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn)
+#define GBL_COLLECT(M, O)                                       \
+    if (ply_dev) GBL_COLLECT_K(M, O, true);                     \
+    else GBL_COLLECT_K(M, O, false)
+    if (mask_traj && obs_traj) { GBL_COLLECT(true, true); }
+    else if (mask_traj) { GBL_COLLECT(true, false); }
+    else if (obs_traj) { GBL_COLLECT(false, true); }
+    else { GBL_COLLECT(false, false); }
+#undef GBL_COLLECT
+#undef GBL_COLLECT_K
+    GBL_LAUNCHED("gbl_collect");
 }
 
 int gbl_decode_obs(const int8_t *obs, int8_t *state, int8_t *to_move, int64_t n, void *stream)
@@ -993,11 +1179,11 @@ namespace {
 // 1: 49 / 155 / 518 us, 2: 43 / 139 / 487, 4: 41 / 121 / 451, 8: 40 / 136 / 520, 16: 50 / 176 / 679.
 int greedy_waves(int depth)
 {
-    static const int forced = [] {
-        const char *e = getenv("GBL_GREEDY_WAVES");  // 1, 2 or 4: A/B runs
-        return e ? atoi(e) : 0;
-    }();
-    return forced ? forced : depth == 1 ? 1 : 4;
+#ifdef GBL_FORCE_GREEDY_WAVES  // 1, 2 or 4: A/B builds (scripts/build_variant.sh)
+    return GBL_FORCE_GREEDY_WAVES;
+#else
+    return depth == 1 ? 1 : 4;
+#endif
 }
 
 void launch_greedy(int waves, const Geometry &g, hipStream_t stream, const int8_t *state, const int8_t *to_move,
@@ -1023,6 +1209,7 @@ int gbl_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask, c
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(action_out, "action_out");
     if (depth < 1 || depth > 3) return fail(GBL_ERR_ARG, "depth must be 1, 2 or 3");
     GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask, "mask"); GBL_ALIGNED(cand_mask_out, "cand_mask_out");
+    if (hist && (reinterpret_cast<uintptr_t>(hist) & 1u)) return fail(GBL_ERR_ALIGN, "hist must be 2-byte aligned");
     launch_greedy(greedy_waves(depth), geometry(n), (hipStream_t)stream, state, to_move, mask, hist, depth, action_out,
                   cand_mask_out, fallback_out, n, nullptr, nullptr, 0, 0, 0);
     GBL_LAUNCHED("gbl_greedy");
@@ -1044,6 +1231,7 @@ int gbl_greedy_act_at(const int8_t *state, const int8_t *to_move, const int8_t *
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(hist, "hist"); GBL_NEED(action_out, "action_out");
     if (depth < 1 || depth > 3) return fail(GBL_ERR_ARG, "depth must be 1, 2 or 3");
     GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask, "mask"); GBL_ALIGNED(cand_mask_out, "cand_mask_out");
+    if (hist && (reinterpret_cast<uintptr_t>(hist) & 1u)) return fail(GBL_ERR_ALIGN, "hist must be 2-byte aligned");
     launch_greedy(greedy_waves(depth), geometry(n), (hipStream_t)stream, state, to_move, mask, nullptr, depth, chosen_out,
                   cand_mask_out, fallback_out, n, hist, action_out, seed, env_base, call, call_dev);
     GBL_LAUNCHED("gbl_greedy_act");

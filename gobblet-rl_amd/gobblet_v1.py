@@ -9,6 +9,8 @@ with the same attributes are used (they are third-party to the reference too).
 """
 from __future__ import annotations
 
+import ctypes
+
 import numpy as np
 import torch
 
@@ -130,10 +132,67 @@ except Exception:  # noqa: BLE001
         Discrete, Box, Dict = _Discrete, _Box, _Dict
 
 
+class _HipBoardEngine:
+    """The 1-board engine behind ``Board``: ONE ``gbl_board_eval`` launch per query.  The board (27 B), the move
+    (agent, action) and the 432-byte record live in one pinned host block mapped into the device's address space
+    (``gbl_pinned_alloc``): the kernel reads and writes it directly, so a ply is one launch and one stream
+    synchronisation -- no separate copies.  Stateless between calls (the caller passes the position every time),
+    so one engine per device serves every ``Board``."""
+
+    _STATE, _ACTION, _AGENT, _BYTES = 448, 432, 436, 512  # offsets in the block; the record is at 0
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise nat.GobbletHipError("gobblet_v1 needs a GPU device (there is no CPU fallback)")
+        self._lib = nat.lib()
+        host, dev = ctypes.c_void_p(), ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.gbl_pinned_alloc(self._BYTES, ctypes.byref(host), ctypes.byref(dev)), "gbl_pinned_alloc")
+        self._host, self._dev = host.value, dev.value
+        block = np.ctypeslib.as_array((ctypes.c_int8 * self._BYTES).from_address(self._host))
+        self._record = block[:nat.REC_BYTES]
+        self._state = block[self._STATE:self._STATE + 27]
+        self._action = block[self._ACTION:self._ACTION + 4].view(np.int32)
+        self._agent = block[self._AGENT:self._AGENT + 1]
+        self._fields = {k: self._record[o:o + size] for k, (o, size) in nat.REC_FIELDS.items()}
+        self._stream = torch.cuda.current_stream(self.device)
+
+    def __del__(self):
+        try:
+            self._lib.gbl_pinned_free(self._host)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def evaluate(self, squares, agent_index=None, action=None) -> dict:
+        """Everything the reference derives from ``squares`` (int8[27]) -- after Board.play_turn(agent_index,
+        action) when a move is given -- as numpy arrays (copies)."""
+        self._state[:] = squares
+        base = self._dev
+        if action is None:
+            rc = self._lib.gbl_board_eval(base + self._STATE, None, None, base, 1, self._stream.cuda_stream)
+        else:
+            self._action[0], self._agent[0] = action, agent_index
+            rc = self._lib.gbl_board_eval(base + self._STATE, base + self._AGENT, base + self._ACTION, base, 1,
+                                          self._stream.cuda_stream)
+        nat.check(rc, "gbl_board_eval")
+        self._stream.synchronize()
+        return {k: v.copy() for k, v in self._fields.items()}
+
+
+_ENGINES: dict = {}
+
+
 def _new_backend(device):
-    """The 1-board engine behind ``Board``: always the HIP library.  (Module-level so that the CPU-only
+    """The engine of a ``Board``: always the HIP library, one per device.  (Module-level so that the CPU-only
     host-logic tests can monkeypatch it; nothing in the package does.)"""
-    return BatchedBoard(1, device)
+    key = str(torch.device(device))
+    if key not in _ENGINES:
+        _ENGINES[key] = _HipBoardEngine(device)
+    return _ENGINES[key]
+
+
+_LINES = [(0, 1, 2), (3, 4, 5), (6, 7, 8), (0, 3, 6), (1, 4, 7), (2, 5, 8), (0, 4, 8), (2, 4, 6)]  # board.py:135-153
 
 
 class Board:
@@ -141,37 +200,31 @@ class Board:
 
     ``squares`` is a host numpy float64[27] exactly like the reference's (callers read it, assign whole
     arrays and single cells: greedy_policy.py:71, manual_policy.py:60,194-196).  Whenever a query finds
-    that its content changed, the position is uploaded to the 1-board ``BatchedBoard`` backend and
-    EVERYTHING the reference derives from a position -- winner, flat board, covered cells, both agents'
-    legal masks and observations -- is computed in ONE launch (``gbl_board_eval``) and fetched with one
-    device-to-host copy; later queries on the same position are answered from that.  ``play_turn`` is fused
-    in front of the same launch and primes the cache for the new position, so one ply of the AEC loop costs one
-    launch and one round trip.  The engine is always the HIP library (``_new_backend``); there is no fallback and no
+    that its content changed, EVERYTHING the reference derives from the position -- winner, flat board,
+    covered cells, both agents' legal masks and observations -- is computed in ONE launch
+    (``gbl_board_eval``) and later queries on the same position are answered from that.  ``play_turn`` is
+    fused in front of the same launch and primes the cache for the new position, so one ply of the AEC loop
+    costs one launch.  The engine is always the HIP library (``_new_backend``); there is no fallback and no
     public way to swap it.
     """
-
-    _PARTS = tuple((k, size) for k, (_, size) in nat.REC_FIELDS.items())
 
     def __init__(self, squares=None, device="cuda:0"):
         self.squares = np.zeros(27)           # board.py:33
         self.squares_preview = np.zeros(27)   # board.py:34
         if squares is not None:
             self.squares = np.array(squares, dtype=np.float64).reshape(27)
-        self._backend = _new_backend(device)
-        dev = getattr(self._backend, "device", "cpu")
-        self._agents = (torch.zeros(1, dtype=torch.int8, device=dev), torch.ones(1, dtype=torch.int8, device=dev))
+        self._engine = _new_backend(device)
         self._key, self._cache = None, None
-        self._record = None
-        if isinstance(self._backend, BatchedBoard):
-            # the engine's one-launch evaluation (gbl_board_eval) writes a 432-byte record per board; the host gets
-            # it with one asynchronous copy into pinned memory
-            self._record = torch.zeros((1, nat.REC_BYTES), dtype=torch.int8, device=dev)
-            self._host = torch.zeros((1, nat.REC_BYTES), dtype=torch.int8).pin_memory()
-            self._action = torch.zeros(1, dtype=torch.int32, device=dev)
-            self._upload = torch.zeros(27, dtype=torch.int8).pin_memory()
-        self.winning_combinations = self._backend.winning_combinations  # board.py:135-153
-        self.calculate_winners = self._backend.calculate_winners
-        self.setup = self._backend.setup
+        self.calculate_winners()
+
+    def calculate_winners(self):  # board.py:135-153
+        self.winning_combinations = list(_LINES)
+
+    def setup(self):  # board.py:36-37
+        self.calculate_winners()
+
+    def _key_of(self):
+        return np.ascontiguousarray(self.squares, dtype=np.float64).tobytes()
 
     def _position(self):
         sq = np.asarray(self.squares)
@@ -179,47 +232,12 @@ class Board:
             raise ValueError("Board.squares must be 27 integers in [-6, 6]")
         return sq.astype(np.int8)
 
-    def _pull(self, agent_index=None, action=None):
-        """All derived quantities of the backend's position (after an optional play_turn): ONE launch, one copy."""
-        b = self._backend
-        if self._record is not None:
-            if action is None:
-                b.evaluate(out=self._record)
-            else:
-                b.evaluate(self._agents[int(agent_index)], action, out=self._record)
-            self._host.copy_(self._record, non_blocking=True)
-            torch.cuda.current_stream(b.device).synchronize()
-            host = self._host.numpy()[0]
-            out = {name: host[o:o + size].copy() for name, (o, size) in nat.REC_FIELDS.items()}
-            self._key, self._cache = out["squares"].tobytes(), out
-            return out
-        if action is not None:
-            b.play_turn(self._agents[int(agent_index)], action)
-        parts = [b.squares, b.check_for_winner(), b.get_flatboard(), b.check_covered(), b.legal_mask(self._agents[0]),
-                 b.legal_mask(self._agents[1]), b.observation(self._agents[0]), b.observation(self._agents[1])]
-        host = torch.cat([x.reshape(-1).to(torch.int8) for x in parts]).cpu().numpy()
-        out, at = {}, 0
-        for name, size in self._PARTS:
-            out[name] = host[at:at + size]
-            at += size
-        self._key, self._cache = out["squares"].tobytes(), out
-        return out
-
     def _evaluate(self):
-        sq = self._position()
-        if self._cache is None or sq.tobytes() != self._key:
-            if self._record is not None:
-                self._upload.numpy()[:] = sq
-                self._backend.squares[0].copy_(self._upload, non_blocking=True)
-            else:
-                self._backend.squares = torch.from_numpy(sq)[None]
-            self._pull()
+        key = self._key_of()
+        if key != self._key:
+            self._cache = self._engine.evaluate(self._position())
+            self._key = key
         return self._cache
-
-    def _sync(self):
-        """The backend holding this position (for callers that want the batched API itself)."""
-        self._evaluate()
-        return self._backend
 
     # decoders, board.py:42-79
     get_action_from_pos_piece = staticmethod(BatchedBoard.get_action_from_pos_piece)
@@ -239,10 +257,11 @@ class Board:
     def play_turn(self, agent_index, action):  # board.py:118-132
         if agent_index not in (0, 1):
             raise ValueError("agent_index must be 0 or 1")
-        self._evaluate()  # the device holds this position
         action = int(action) if 0 <= int(action) < 54 else -1  # out of range = illegal = no-op
         # the move and the new position's record in one launch
-        self.squares = self._pull(agent_index, action)["squares"].astype(np.float64)
+        self._cache = self._engine.evaluate(self._position(), int(agent_index), action)
+        self.squares = self._cache["squares"].astype(np.float64)
+        self._key = self.squares.tobytes()
 
     def get_action(self, pos, piece_size, agent_index):  # board.py:50-60: the first legal of the size's two pieces
         for piece in (2 * int(piece_size) - 2, 2 * int(piece_size) - 1):
@@ -265,6 +284,10 @@ class Board:
 
     def legal_moves(self, agent_index):
         return np.flatnonzero(self._evaluate()["mask%d" % self._agent(agent_index)]).tolist()
+
+    def legal_mask(self, agent_index):
+        """int8[54]: [is_legal(a, agent_index) for a in range(54)] (gobblet.py:223-228, 211-213), a copy"""
+        return self._evaluate()["mask%d" % self._agent(agent_index)].astype(np.int8)
 
     def observation(self, agent_index):
         return self._evaluate()["obs%d" % self._agent(agent_index)].reshape(3, 3, 13).copy()
@@ -346,10 +369,11 @@ class raw_env(_AECBase):  # noqa: N801  (reference spelling, gobblet.py:123)
     def observe(self, agent):  # gobblet.py:179-215
         idx = self.possible_agents.index(agent)
         observation = self.board.observation(idx)
-        legal_moves = self._legal_moves() if agent == self.agent_selection else []
-        action_mask = np.zeros(54, "int8")
-        for i in legal_moves:
-            action_mask[i] = 1
+        # gobblet.py:209-213: the legal moves of the agent to move as a 0/1 vector; all zeros for the other agent
+        if agent == self.agent_selection:
+            action_mask = self.board.legal_mask(idx)
+        else:
+            action_mask = np.zeros(54, "int8")
         return {"observation": observation, "action_mask": action_mask}
 
     def observation_space(self, agent):

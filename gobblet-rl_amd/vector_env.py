@@ -24,6 +24,8 @@ from .board import BatchedBoard, _as_i32
 
 
 class BatchedGobblet:
+    SLOT_PAD_BOARDS = 0  # see trajectory_buffers
+
     metadata = {"name": "gobblet_v1_batched", "num_actions": nat.ACTIONS, "observation_shape": (3, 3, 13)}
 
     def __init__(self, num_envs: int, device="cuda:0", illegal_mode: str | int = "noop", auto_reset: bool = False,
@@ -199,6 +201,60 @@ class BatchedGobblet:
                                      self.illegal_mode, int(self.auto_reset), self._stream()), "gbl_step")
         self._ply += 1
         return self.observe(), self.rewards, self.done, self.winner
+
+    # -- trajectory collection: T plies per launch, every ply materialised -------------------------------------
+    def trajectory_buffers(self, plies: int, pad_boards: int | None = None) -> dict:
+        """Device tensors for ``collect``: every entry has shape (plies, N, ...) and is a view of a
+        (plies, slot_boards, ...) allocation; slot_boards = N rounded up to 128 boards (+ ``pad_boards``), so that
+        every slot of every array starts on a 128-byte line (the C-ABI itself asks for a multiple of 16 only)."""
+        n, dev, T = self.num_envs, self.device, int(plies)
+        slot = -(-n // 128) * 128 + (self.SLOT_PAD_BOARDS if pad_boards is None else int(pad_boards))
+        full = {"actions": torch.zeros((T, slot), dtype=torch.int32, device=dev),
+                "winner": torch.zeros((T, slot), dtype=torch.int8, device=dev),
+                "rewards": torch.zeros((T, slot, 2), dtype=torch.int8, device=dev),
+                "done": torch.zeros((T, slot), dtype=torch.int8, device=dev),
+                "to_move": torch.zeros((T, slot), dtype=torch.int8, device=dev),
+                "action_mask": torch.zeros((T, slot, nat.ACTIONS), dtype=torch.int8, device=dev)}
+        if self.observation is not None:
+            full["observation"] = torch.zeros((T, slot, 3, 3, 13), dtype=torch.int8, device=dev)
+        out = {k: v[:, :n] for k, v in full.items()}
+        out["_full"], out["_slot_boards"], out["_plies"] = full, slot, T
+        return out
+
+    def collect(self, plies: int, out: dict | None = None, count: bool = False, refresh: bool = True) -> dict:
+        """``plies`` masked-random plies with auto-reset in ONE launch (``gbl_collect``), EVERY ply materialised:
+        entry t of the returned tensors -- "actions", "winner", "rewards", "done", "to_move", "action_mask",
+        "observation", each (plies, N, ...) -- is what ``rollout(1)`` called ``plies`` times would have left in the
+        attribute tensors after call t: the action played, its result, and the mask / observation of the agent to
+        move next.  The environment's own tensors (squares, to_move, done, turn, counters) hold the position after
+        the last ply; with ``refresh`` the ``action_mask`` / ``observation`` / ``actions`` / ``winner`` / ``rewards``
+        attributes are copied from the last slot (device copies of ~180 B per board: a pure collector that only
+        reads the trajectory passes ``refresh=False`` and calls ``refresh()`` before it next steps by hand).
+        ``out``: a dict from ``trajectory_buffers(plies)`` to reuse (a replay buffer's staging area)."""
+        if not self.auto_reset:
+            raise ValueError("collect() plays with auto-reset; this environment was created with auto_reset=False")
+        T = int(plies)
+        if out is None:
+            out = self.trajectory_buffers(T)
+        if out["_plies"] != T:
+            raise ValueError("trajectory buffers were made for %d plies" % out["_plies"])
+        f, n = out["_full"], self.num_envs
+        nat.check(self._lib.gbl_collect(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
+                                        f["actions"].data_ptr(), f["winner"].data_ptr(), f["rewards"].data_ptr(),
+                                        f["done"].data_ptr(), f["to_move"].data_ptr(), f["action_mask"].data_ptr(),
+                                        f["observation"].data_ptr() if "observation" in f else None, n,
+                                        out["_slot_boards"], self.seed, self.env_base, self._ply, nat.ptr(self._ply_dev),
+                                        T, self.illegal_mode, self._counters.data_ptr() if count else None,
+                                        nat.ptr(self.turn), self._stream()), "gbl_collect")
+        self._ply += T
+        if not refresh:
+            return out
+        # keep the attribute tensors consistent with the position after the last ply
+        self.action_mask.copy_(out["action_mask"][T - 1]); self.actions.copy_(out["actions"][T - 1])
+        self.winner.copy_(out["winner"][T - 1]); self.rewards.copy_(out["rewards"][T - 1])
+        if self.observation is not None:
+            self.observation.copy_(out["observation"][T - 1])
+        return out
 
     # -- masked-uniform sampling (examples/example_basic.py:58-61) ----------------------------------------
     def sample_actions(self, out: torch.Tensor | None = None) -> torch.Tensor:

@@ -120,6 +120,14 @@ int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *action
              int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int64_t n, int illegal_mode,
              int auto_reset, void *stream);
 
+/* Host memory that the kernels read and write directly (pinned and mapped into the device's address space), for
+ * callers that want a result on the host without a separate copy -- the single-environment facade keeps its
+ * board, action and 432-byte record there, so a ply crosses PCIe inside its one launch.  *host_ptr is the CPU's
+ * view, *dev_ptr the pointer to hand to the gbl_* entry points (same memory).  The caller owns the block and
+ * frees it with gbl_pinned_free(host_ptr); the library keeps no reference. */
+int gbl_pinned_alloc(int64_t bytes, void **host_ptr, void **dev_ptr);
+int gbl_pinned_free(void *host_ptr);
+
 /* Everything the reference derives from a position, for n boards, in ONE launch (the single-environment
  * facade gobblet_v1.env() asks all of it once per ply): optionally Board.play_turn(agent_index[b], actions[b])
  * first (board.py:118-132; illegal or out-of-range: silent no-op; `state` is updated in place), then one
@@ -216,6 +224,24 @@ int gbl_rollout_at(int8_t *state, int8_t *to_move, int8_t *done, int32_t *action
 int gbl_greedy_act_at(const int8_t *state, const int8_t *to_move, const int8_t *mask, int8_t *hist, int depth,
                       uint64_t seed, uint64_t env_base, uint32_t call, const uint32_t *call_dev, int32_t *action_out,
                       int32_t *chosen_out, int8_t *cand_mask_out, int8_t *fallback_out, int64_t n, void *stream);
+
+/* Trajectory collection (K plies per launch with EVERY ply materialised).  `plies` masked-random
+ * plies with auto-reset in ONE launch; ply t (t = 0 .. plies-1) leaves in slot t of the trajectory arrays exactly
+ * what gbl_rollout(plies = 1) with ply index ply0 + t leaves in its output arrays:
+ *   actions_traj int32[plies][slot_boards]      the action played at ply t
+ *   winner_traj  int8 [plies][slot_boards]      check_for_winner() after it        reward_traj int8[plies][slot_boards][2]
+ *   done_traj    int8 [plies][slot_boards]      1 where the episode ended on ply t (the board was then reset)
+ *   to_move_traj int8 [plies][slot_boards]      the agent to move next -- the one mask / obs of the slot belong to
+ *   mask_traj    int8 [plies][slot_boards][54]  obs_traj int8[plies][slot_boards][117]
+ * (any of them may be NULL; board b of slot t is element t * slot_boards + b; slot_boards >= n, a multiple of 16,
+ * so every slot starts 16-byte aligned).  state / to_move / done / turn / counters are read at entry and hold
+ * the position after the last ply on return, as with gbl_rollout.  A consumer (replay buffer, trainer) reads
+ * the whole trajectory after the launch; between plies nothing but the per-ply outputs touches HBM.
+ * ply_dev: NULL, or the device-resident base of the ply index as in gbl_rollout_at. */
+int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_traj, int8_t *winner_traj,
+                int8_t *reward_traj, int8_t *done_traj, int8_t *to_move_traj, int8_t *mask_traj, int8_t *obs_traj,
+                int64_t n, int64_t slot_boards, uint64_t seed, uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev,
+                uint32_t plies, int illegal_mode, int64_t *counters, int32_t *turn, void *stream);
 /* *counter += by, enqueued on the stream (device uint32). */
 int gbl_counter_add(uint32_t *counter, uint32_t by, void *stream);
 

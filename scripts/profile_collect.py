@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Turn what scripts/profile_round.sh left under gpurun_out/final/ into the tracked files under
-profiles/<round>/ and profiles/pmc_traffic.json (read by bench.py for roofline.traffic).
+profiles/<round>/ and profiles/pmc_traffic.json (read by bench.py for roofline.traffic and the greedy
+VALU-instruction count; every record carries the hash of the kernel sources it was measured on).
 
-    python scripts/profile_collect.py r01
+    python scripts/profile_collect.py r02
 """
 import contextlib
+import hashlib
 import io
 import json
 import os
@@ -26,65 +28,74 @@ def capture(fn, *a):
     return buf.getvalue()
 
 
-def counter_mean(db, kernel, counter):
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in ("gobblet_hip.hip", "gobblet_device.h"):
+        h.update(open(os.path.join(ROOT, "gobblet-rl_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def counter_mean(db, kernel, counter, skip=1):
     q = ("select dispatch_id, sum(value) from counters_collection where kernel_name like ? and counter_name = ? "
-         "group by dispatch_id")
+         "group by dispatch_id order by dispatch_id")
     v = [r[1] for r in sqlite3.connect(db).execute(q, (f"%{kernel}%", counter))]
+    v = v[skip:] if len(v) > skip else v  # (the first dispatch of a process includes one-off effects)
     return sum(v) / len(v), len(v)
-
-
-def greedy(dst):
-    src = os.path.join(ROOT, "gpurun_out", "c5")
-    for a, b in (("d2", "c5_greedy_depth2_65536"), ("d1", "c5_greedy_depth1_65536"), ("d2_1m", "c5_greedy_depth2_1048576"),
-                 ("policy", "c5_greedy_policy_step_65536")):
-        shutil.copy(os.path.join(src, a + ".json"), os.path.join(dst, b + ".json"))
-    open(os.path.join(dst, "c5_greedy_kernel_stats.csv"), "w").write(
-        capture(rocpd_summary.stats, os.path.join(src, "stats", "p_results.db")))
-    sq = ("# k_greedy<4> depth 2 (pairs pooled over a tile, 4 wavefronts per tile, cheap + exact reply evaluation, twin "
-          "placements evaluated once), 65536 boards = 1024 tiles; rocprofv3 --pmc, summed over instances per dispatch\n")
-    sq += capture(rocpd_summary.counters, "k_greedy", [os.path.join(src, "pmc1", "p_results.db"),
-                                                       os.path.join(src, "pmc2", "p_results.db")])
-    open(os.path.join(dst, "c5_greedy_sq_counters.csv"), "w").write(sq)
-    print(sq)
-    print(open(os.path.join(dst, "c5_greedy_kernel_stats.csv")).read()[:400])
 
 
 def main():
     rnd = sys.argv[1]
     dst = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(dst, exist_ok=True)
-    if len(sys.argv) > 2 and sys.argv[2] == "greedy":
-        return greedy(dst)
-    for name in ("bench_default", "bench_maskonly", "bench_stepmode", "bench_4194304_boards", "bench_2097152_boards"):
-        shutil.copy(os.path.join(SRC, name + ".json"), os.path.join(dst, "final_" + name + ".json"))
-    for name in ("bench_c3_262144_boards", "bench_c2_4096_boards", "playouts"):
+    khash = kernel_source_hash()
+    for name in ("bench_default", "bench_driver_cmd", "bench_single_ply", "bench_stepmode", "bench_maskonly",
+                 "bench_c4_shard_131072", "greedy_65536", "greedy_1048576", "greedy_policy", "playouts"):
         shutil.copy(os.path.join(SRC, name + ".json"), os.path.join(dst, name + ".json"))
-    for mode, kernel in (("fused", "k_rollout<true, true, 1, false>"), ("step", "k_step<true, true, 1>")):
-        out = "final_%s_kernel_stats.csv" % ("fused" if mode == "fused" else "stepmode")
-        open(os.path.join(dst, out), "w").write(capture(rocpd_summary.stats, os.path.join(SRC, mode + "_stats", "p_results.db")))
+    for name in ("facade.txt", "valu_rates.txt", "winner_lanes.txt"):
+        shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
+    for run in ("collect", "single", "step", "greedy"):
+        open(os.path.join(dst, f"{run}_kernel_stats.csv"), "w").write(
+            capture(rocpd_summary.stats, os.path.join(SRC, f"{run}_stats", "p_results.db")))
+    open(os.path.join(dst, "kernel_durations_by_size.csv"), "w").write(
+        "# scripts/sweep_sizes.py under rocprofv3 --kernel-trace: k_rollout = one ply per launch, k_collect = 32 plies per launch\n"
+        + capture(rocpd_summary.bygrid, "k_rollout", os.path.join(SRC, "sweep_trace", "p_results.db"), 64)
+        + capture(rocpd_summary.bygrid, "k_collect", os.path.join(SRC, "sweep_trace", "p_results.db"), 1))
+    # ---- HBM traffic per launch ---------------------------------------------------------------------------------
     traffic = {}
     rows = ["kernel,counter,dispatches,mean_value_KB"]
-    for mode, kernel in (("fused", "k_rollout<true, true, 1, false>"), ("step", "k_step<true, true, 1>")):
+    for key, run, kernel in (("collect:1048576:T8", "collect", "k_collect<true, true"),
+                             ("fused:1048576", "single", "k_rollout<true, true")):
         kb = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            kb[c], n = counter_mean(os.path.join(SRC, f"{mode}_pmc_{c}", "p_results.db"), kernel, c)
+            kb[c], n = counter_mean(os.path.join(SRC, f"{run}_pmc_{c}", "p_results.db"), kernel, c)
             rows.append(f"{kernel.replace(',', ';')},{c},{n},{kb[c]:.3f}")
-        traffic[f"{mode}:1048576"] = {
+        traffic[key] = {
             # gfx950 reports half of wide coalesced reads (MI355X_MICROARCH.md): FETCH_SIZE is doubled
             "hbm_bytes_per_launch": (2 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024,
-            "FETCH_SIZE_KB": kb["FETCH_SIZE"], "WRITE_SIZE_KB": kb["WRITE_SIZE"],
-            "note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, {kernel}, 2^20 boards; FETCH_SIZE "
-                    f"doubled per MI355X_MICROARCH.md; source profiles/{rnd}/final_pmc_summary.csv "
-                    f"(scripts/profile_round.sh + scripts/profile_collect.py)"}
-    open(os.path.join(dst, "final_pmc_summary.csv"), "w").write("\n".join(rows) + "\n")
+            "FETCH_SIZE_KB": kb["FETCH_SIZE"], "WRITE_SIZE_KB": kb["WRITE_SIZE"], "kernel_source_hash": khash,
+            "source": f"profiles/{rnd}/pmc_summary.csv",
+            "note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, eager launches of {kernel}...>, 2^20 "
+                    f"boards; FETCH_SIZE doubled per MI355X_MICROARCH.md (scripts/profile_round.sh + profile_collect.py)"}
+    open(os.path.join(dst, "pmc_summary.csv"), "w").write("\n".join(rows) + "\n")
+    # ---- SQ counters ------------------------------------------------------------------------------------------------
+    for m, kernel, what in (("traj", "k_collect<true, true", "gbl_collect FULL, 8 plies per launch, 2^20 boards"),
+                            ("trajmask", "k_collect<true, false", "gbl_collect MASK_ONLY, 8 plies per launch, 2^20 boards"),
+                            ("full", "k_rollout<true, true", "gbl_rollout FULL, one ply per launch, 2^20 boards"),
+                            ("mask", "k_rollout<true, false", "gbl_rollout MASK_ONLY, one ply per launch, 2^20 boards"),
+                            ("greedy", "k_greedy", "gbl_greedy depth 2, 65536 boards")):
+        sq = f"# {what}; rocprofv3 --pmc (two passes), summed over instances, mean per dispatch\n"
+        sq += capture(rocpd_summary.counters, kernel, [os.path.join(SRC, f"{m}_sq1", "p_results.db"),
+                                                       os.path.join(SRC, f"{m}_sq2", "p_results.db")])
+        open(os.path.join(dst, f"sq_counters_{m}.csv"), "w").write(sq)
+        if m == "greedy":
+            insts, _ = counter_mean(os.path.join(SRC, "greedy_sq1", "p_results.db"), "k_greedy", "SQ_INSTS_VALU")
+            traffic["greedy:65536"] = {"SQ_INSTS_VALU": insts, "kernel_source_hash": khash,
+                                       "source": f"profiles/{rnd}/sq_counters_greedy.csv"}
+        print(sq)
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
-    sq = "# k_rollout<true, true, 1>, 2^20 boards, one ply per launch; rocprofv3 --pmc (two passes), per dispatch\n"
-    sq += capture(rocpd_summary.counters, "k_rollout<true, true, 1, false>", [os.path.join(SRC, "fused_sq1", "p_results.db"),
-                                                                     os.path.join(SRC, "fused_sq2", "p_results.db")])
-    open(os.path.join(dst, "final_fused_sq_counters.csv"), "w").write(sq)
-    print(open(os.path.join(dst, "final_pmc_summary.csv")).read())
-    print(sq)
-    print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in traffic.items()}))
+    print(open(os.path.join(dst, "pmc_summary.csv")).read())
+    print(open(os.path.join(dst, "kernel_durations_by_size.csv")).read())
+    print(json.dumps({k: v.get("hbm_bytes_per_launch", v.get("SQ_INSTS_VALU")) for k, v in traffic.items()}))
 
 
 if __name__ == "__main__":

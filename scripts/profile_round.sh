@@ -1,28 +1,47 @@
 #!/bin/bash
 # Everything the numbers in README.md / DESIGN.md / profiles/ come from, in one GPU call:
-#   gpurun -- 'scripts/profile_round.sh'      then      python scripts/profile_collect.py r01
+#   gpurun -- 'scripts/profile_round.sh'      then      python scripts/profile_collect.py r02
 # Writes bench lines and rocprofv3 databases under gpurun_out/final/.
 set -e -o pipefail
 export TMPDIR=/tmp
 O=gpurun_out/final
 rm -rf $O && mkdir -p $O
+python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1   # (no compiler may run under the profiler's preload)
+# ---- bench lines --------------------------------------------------------------------------------------------
 python bench.py > $O/bench_default.json
-python bench.py --no-obs --no-cpu-baseline > $O/bench_maskonly.json
-python bench.py --mode step --no-cpu-baseline > $O/bench_stepmode.json
-python bench.py --boards 4194304 --steps 300 --no-cpu-baseline > $O/bench_4194304_boards.json
-python bench.py --boards 2097152 --steps 500 --no-cpu-baseline > $O/bench_2097152_boards.json
-python bench.py --boards 262144 --no-cpu-baseline > $O/bench_c3_262144_boards.json
-python bench.py --boards 4096 --no-cpu-baseline > $O/bench_c2_4096_boards.json
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-configs --no-cpu-baseline > $O/bench_driver_cmd.json
+python bench.py --mode fused --no-configs --no-cpu-baseline > $O/bench_single_ply.json
+python bench.py --mode step --no-configs --no-cpu-baseline > $O/bench_stepmode.json
+python bench.py --no-obs --no-configs --no-cpu-baseline > $O/bench_maskonly.json
+python bench.py --boards 131072 --no-configs --no-cpu-baseline > $O/bench_c4_shard_131072.json
+python scripts/bench_greedy.py > $O/greedy_65536.json
+python scripts/bench_greedy.py --boards 1048576 > $O/greedy_1048576.json
+python scripts/bench_greedy_policy.py > $O/greedy_policy.json 2> /dev/null
 python scripts/bench_playouts.py > $O/playouts.json 2> /dev/null
+python scripts/bench_facade.py > $O/facade.txt
+scripts/microbench/valu_rates > $O/valu_rates.txt
+scripts/microbench/winner_lanes > $O/winner_lanes.txt
 echo "bench lines done"
-rocprofv3 --kernel-trace --stats -d $O/fused_stats -o p -- python3 bench.py --steps 300 --no-cpu-baseline > $O/fused_stats.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/step_stats -o p -- python3 bench.py --mode step --steps 300 --no-cpu-baseline > $O/step_stats.log 2>&1
+# ---- kernel traces (durations) ------------------------------------------------------------------------------
+rocprofv3 --kernel-trace --stats -d $O/collect_stats -o p -- python3 bench.py --steps 320 --no-configs --no-cpu-baseline > $O/collect_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/single_stats -o p -- python3 bench.py --mode fused --steps 300 --no-configs --no-cpu-baseline > $O/single_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/step_stats -o p -- python3 bench.py --mode step --steps 300 --no-configs --no-cpu-baseline > $O/step_stats.log 2>&1
+rocprofv3 --kernel-trace -d $O/sweep_trace -o p -- python3 scripts/sweep_sizes.py --sizes 4096,131072,262144,1048576 --modes full,mask,traj,trajmask --plies 128 --reps 2 > $O/sweep_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/greedy_stats -o p -- python3 scripts/run_eager.py greedy 65536 20 > $O/greedy_stats.log 2>&1
 echo "kernel traces done"
+# ---- HBM traffic (separate --pmc passes; eager launches so that counters are attributed per dispatch) ----------
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $O/fused_pmc_$c -o p -- python3 bench.py --steps 20 --warmup 8 --graph 0 --no-cpu-baseline > $O/fused_pmc_$c.log 2>&1
-  rocprofv3 --pmc $c -d $O/step_pmc_$c -o p -- python3 bench.py --mode step --steps 20 --warmup 8 --graph 0 --no-cpu-baseline > $O/step_pmc_$c.log 2>&1
+  rocprofv3 --pmc $c -d $O/collect_pmc_$c -o p -- python3 scripts/run_eager.py traj 1048576 6 8 > $O/collect_pmc_$c.log 2>&1
+  rocprofv3 --pmc $c -d $O/single_pmc_$c -o p -- python3 scripts/run_eager.py full 1048576 20 > $O/single_pmc_$c.log 2>&1
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES -d $O/fused_sq1 -o p -- python3 bench.py --steps 20 --warmup 8 --graph 0 --no-cpu-baseline > $O/fused_sq1.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE -d $O/fused_sq2 -o p -- python3 bench.py --steps 20 --warmup 8 --graph 0 --no-cpu-baseline > $O/fused_sq2.log 2>&1
+# ---- SQ counters ------------------------------------------------------------------------------------------------
+SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES"
+SQ2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
+for m in traj trajmask full mask; do
+  rocprofv3 --pmc $SQ1 -d $O/${m}_sq1 -o p -- python3 scripts/run_eager.py $m 1048576 6 8 > $O/${m}_sq1.log 2>&1
+  rocprofv3 --pmc $SQ2 -d $O/${m}_sq2 -o p -- python3 scripts/run_eager.py $m 1048576 6 8 > $O/${m}_sq2.log 2>&1
+done
+rocprofv3 --pmc $SQ1 -d $O/greedy_sq1 -o p -- python3 scripts/run_eager.py greedy 65536 20 > $O/greedy_sq1.log 2>&1
+rocprofv3 --pmc $SQ2 -d $O/greedy_sq2 -o p -- python3 scripts/run_eager.py greedy 65536 20 > $O/greedy_sq2.log 2>&1
 echo "counters done"
 ls $O

@@ -27,20 +27,35 @@ def main():
     ap.add_argument("--modes", default="full,mask")
     ap.add_argument("--plies", type=int, default=300)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--traj", type=int, default=32, help="plies per launch of the trajectory modes (traj, trajmask)")
     ap.add_argument("--tag", default=os.environ.get("GOBBLET_HIP_LIB", "default"))
     args = ap.parse_args()
     for mode in args.modes.split(","):
         for n in (int(s) for s in args.sizes.split(",")):
-            env = G.BatchedGobblet(n, "cuda:0", auto_reset=True, seed=0, with_observation=(mode == "full"))
+            traj = mode.startswith("traj")
+            env = G.BatchedGobblet(n, "cuda:0", auto_reset=True, seed=0, with_observation=mode in ("full", "traj"))
             for _ in range(64):
                 env.rollout(1)
             env.device_ply()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                for _ in range(args.plies):
-                    env.rollout(1)
-                env.advance_ply()
+            if traj:  # gbl_collect: args.traj plies per launch, every ply materialised in its trajectory slot
+                T = args.traj
+                launches = max(1, args.plies // T)  # (every launch reuses the same T slots)
+                buf = env.trajectory_buffers(T)
+                env.collect(T, out=buf, refresh=False)
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    for _ in range(launches):
+                        env.collect(T, out=buf, refresh=False)
+                    env.advance_ply()
+                plies = launches * T
+            else:
+                plies = args.plies
+                with torch.cuda.graph(g):
+                    for _ in range(plies):
+                        env.rollout(1)
+                    env.advance_ply()
             g.replay()  # untimed: first launch of the instantiated graph
             torch.cuda.synchronize()
             us = []
@@ -50,13 +65,17 @@ def main():
                 g.replay()
                 b.record()
                 torch.cuda.synchronize()
-                us.append(a.elapsed_time(b) * 1e3 / args.plies)
-            bytes_per = 234 if mode == "full" else 117
+                us.append(a.elapsed_time(b) * 1e3 / plies)
+            # algorithmic bytes per env-step: SURVEY.md 8d (234 FULL / 117 MASK_ONLY); a trajectory launch reads and
+            # writes the state once per T plies and writes the action: 178 + 55 / T (61 + 55 / T without observation)
+            bytes_per = {"full": 234, "mask": 117, "traj": 178 + 55 / args.traj, "trajmask": 61 + 55 / args.traj}[mode]
             med = statistics.median(us)
-            print(json.dumps({"tag": args.tag, "mode": mode, "boards": n, "us_per_ply": round(med, 3),
+            print(json.dumps({"tag": args.tag + (f":T{args.traj}" if traj else ""), "mode": mode, "boards": n, "us_per_ply": round(med, 3),
                               "best_us": round(min(us), 3), "frac_of_8TBps": round(bytes_per * n / med / 8e6, 4),
                               "env_steps_per_s": n / med * 1e6}), flush=True)
             del g, env
+            if traj:
+                del buf
 
 
 if __name__ == "__main__":

@@ -412,7 +412,7 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
             H[l] = greedy_head(p, me, mask, depth);
         }
         static uint16_t pair[64 * kActions], reply[64][kActions];
-        uint64_t threat[64] = {0}, allwin[64] = {0};
+        uint64_t threat[64] = {0}, allwin[64] = {0}, second[64] = {0}, block[64] = {0}, flegal[64] = {0};
         int total = 0;
         for (int l = 0; l < 64; ++l)
             for (uint64_t it = H[l].todo & ~H[l].dup; it; it &= it - 1)
@@ -423,6 +423,9 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
             if (sum & 1u) {
                 reply[o][a] = (uint16_t)sum;
                 threat[o] |= 1ull << a;
+                if (sum & (1u << 7)) second[o] |= 1ull << a;
+                if (sum & (1u << 8)) block[o] |= 1ull << a;
+                if ((H[o].legal_me >> ((sum >> 1) & 63u)) & 1ull) flegal[o] |= 1ull << a;
             }
             if (sum >> 15) allwin[o] |= 1ull << a;
         };
@@ -447,9 +450,11 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
             int64_t b = t.tile * 64 + l;
             GreedyResult g;
             if (pooled) {
-                greedy_replay_sets(H[l], threat[l], allwin[l], [&](int a) {
-                    return (uint32_t)reply[l][((H[l].dup >> a) & 1ull) ? a - 9 : a];
-                });
+                auto reply_of = [&](int a) { return (uint32_t)reply[l][((H[l].dup >> a) & 1ull) ? a - 9 : a]; };
+                GreedyHead seq = H[l];  // the loop form and the closed form must agree on everything they leave behind
+                greedy_replay_sets(seq, threat[l], allwin[l], reply_of);
+                greedy_replay_closed(H[l], ReplySets{threat[l], allwin[l], second[l], block[l], flegal[l]}, reply_of);
+                if (seq.chosen != H[l].chosen || seq.cands != H[l].cands || seq.ncands != H[l].ncands) g_fast_mismatch++;
                 g = greedy_finish(H[l], PREV[l]);
             } else {
                 g = greedy_decide(P[l], ME[l], MASK[l], depth, PREV[l]);

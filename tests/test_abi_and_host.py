@@ -12,7 +12,7 @@ import pytest
 
 import gobblet_rl_amd as G
 from gobblet_rl_amd import _native as nat
-from tests.oracle_backend import OracleBoardBackend
+from tests.oracle_backend import OracleBoardEngine
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -67,7 +67,7 @@ def test_product_does_not_import_oracle():
 def oracle_engine(monkeypatch):
     """No GPU here: the facade's private engine factory is patched to a CPU stand-in for these host-logic
     tests (the product has no such switch; tests/test_gpu_parity.py runs the same checks on the HIP engine)."""
-    monkeypatch.setattr(G.gobblet_v1, "_new_backend", lambda device: OracleBoardBackend(1))
+    monkeypatch.setattr(G.gobblet_v1, "_new_backend", lambda device: OracleBoardEngine())
 
 
 def make_raw():

@@ -166,7 +166,10 @@ def test_greedy_vs_oracle_selfplay(boards):
     o = oracle.batch_greedy(state, tm, mask=m, depth=2)
     for x, y in zip(e, o):
         assert np.array_equal(x, y)
-    # the per-board composition (greedy_decide) next to the kernel's pooled one (greedy_replay_sets)
+    # (inside the pooled flow the closed form of the depth-2 loop, greedy_replay_closed, is cross-checked against the
+    #  loop form, greedy_replay_sets, on every board, and the cheap reply evaluation against the exact one)
+    assert emu.greedy_stats()[2] == 0
+    # the per-board composition (greedy_decide) next to the kernel's pooled one
     for kw in ({"hist": hist}, {"mask": m}):
         for x, y in zip(emu.greedy(state, tm, depth=2, pooled=False, **kw), oracle.batch_greedy(state, tm, depth=2, **kw)):
             assert np.array_equal(x, y)

@@ -867,3 +867,64 @@ def test_load_state_dict_twice_and_graph_after_load(G):
     assert torch.equal(env.squares, ref.squares) and torch.equal(env.turn, ref.turn) and env.ply == ref.ply
     with pytest.raises(ValueError):
         G.BatchedGobblet(8, DEV, auto_reset=False).rollout(1)
+
+
+@pytest.mark.parametrize("n,with_obs,illegal", [(65, True, "noop"), (4099, True, "noop"), (4096, False, "terminate"),
+                                                 (1, True, "noop")])
+def test_collect_equals_ply_by_ply_rollout(G, n, with_obs, illegal):
+    """gbl_collect: T plies in one launch, every ply materialised in its trajectory slot == T launches of the
+    fused single ply (gbl_rollout, plies = 1), which is itself checked against the oracle; state, turn and tallies
+    after the launch included.  Ragged batch sizes exercise the slot stride (slot_boards = n rounded up to 16)."""
+    T, seed, base = 23, 6, 10_000_000_000
+    kw = dict(auto_reset=True, seed=seed, env_base=base, with_observation=with_obs, illegal_mode=illegal, track_turn=True)
+    a, b = G.BatchedGobblet(n, DEV, **kw), G.BatchedGobblet(n, DEV, **kw)
+    a.rollout(5, count=True); b.rollout(5, count=True)  # not from the empty board, not from ply 0
+    tr = a.collect(T, count=True)
+    assert tr["_slot_boards"] % 16 == 0 and tr["_slot_boards"] >= n
+    for t_ in range(T):
+        b.rollout(1, count=True)
+        assert torch.equal(tr["actions"][t_], b.actions), t_
+        assert torch.equal(tr["winner"][t_], b.winner) and torch.equal(tr["rewards"][t_], b.rewards), t_
+        assert torch.equal(tr["done"][t_], b.done) and torch.equal(tr["to_move"][t_], b.to_move), t_
+        assert torch.equal(tr["action_mask"][t_], b.action_mask), t_
+        if with_obs:
+            assert torch.equal(tr["observation"][t_], b.observation), t_
+    assert torch.equal(a.squares, b.squares) and torch.equal(a.to_move, b.to_move) and torch.equal(a.done, b.done)
+    assert torch.equal(a.turn, b.turn) and torch.equal(a.counters, b.counters) and a.ply == b.ply
+    assert torch.equal(a.action_mask, b.action_mask)
+    assert int(tr["done"].sum()) > 0 or n == 1  # games ended (and restarted) inside the trajectory
+    # the padding boards of a slot are never written
+    pad = tr["_full"]["action_mask"][:, n:]
+    assert pad.numel() == 0 or int(pad.abs().sum()) == 0
+
+
+def test_collect_vs_oracle_and_graph_replay(G):
+    """A trajectory against the oracle ply by ply, then the same launch replayed from a hipGraph with the ply
+    index on the device (fresh plies on every replay)."""
+    n, T, seed = 3000, 12, 21
+    env = G.BatchedGobblet(n, DEV, auto_reset=True, seed=seed)
+    s, tm, dn = oracle.batch_reset(n)
+    tr = env.collect(T)
+    torch.cuda.synchronize()
+    for t_ in range(T):
+        o = oracle.batch_rollout(s, tm, dn, seed, 0, t_, 1)
+        assert np.array_equal(npy(tr["actions"][t_]), o["actions"]) and np.array_equal(npy(tr["action_mask"][t_]), o["mask"])
+        assert np.array_equal(npy(tr["observation"][t_]), o["obs"]) and np.array_equal(npy(tr["to_move"][t_]), tm)
+    assert np.array_equal(npy(env.squares), s)
+    env.device_ply()
+    buf = env.trajectory_buffers(T)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        env.collect(T, out=buf); env.advance_ply()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            env.collect(T, out=buf)
+            env.advance_ply()
+        g.replay(); g.replay()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    oracle.batch_rollout(s, tm, dn, seed, 0, T, 2 * T)           # eager launch + first replay
+    last = [oracle.batch_rollout(s, tm, dn, seed, 0, 3 * T + t_, 1) for t_ in range(T)]  # second replay, ply by ply
+    assert env.ply == 4 * T and np.array_equal(npy(env.squares), s)
+    assert all(np.array_equal(npy(buf["observation"][t_]), last[t_]["obs"]) for t_ in range(T))
