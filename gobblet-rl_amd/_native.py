@@ -82,6 +82,15 @@ def needs_build() -> bool:
     return any(os.path.getmtime(s) > t for s in SOURCES)
 
 
+def _compiler_env() -> dict:
+    """The environment for a compiler child process WITHOUT a profiler's preload: under `rocprofv3 --pmc -- python3
+    ...` this process is GPU-initialised by the preloaded tool library, and a child that inherits the preload and
+    then execs clang is the exec-after-GPU-init pattern that takes a pool machine down."""
+    drop = ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE")
+    return {k: v for k, v in os.environ.items()
+            if k not in drop and not k.startswith(("ROCP", "ROCPROFILER", "ROCTRACER", "ROCTX"))}
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     if not force and not needs_build():
@@ -100,7 +109,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 if verbose:
                     print(" ".join(cmd[:-3] + ["-o", LIB_PATH, SOURCES[0]]))
                 try:
-                    subprocess.check_call(cmd, cwd=CSRC)
+                    subprocess.check_call(cmd, cwd=CSRC, env=_compiler_env())
                     os.replace(tmp, LIB_PATH)
                 finally:
                     if os.path.exists(tmp):

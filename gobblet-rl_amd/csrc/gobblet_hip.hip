@@ -417,7 +417,8 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_step(int8_t *__restrict__ s
 // "sample + step" ply of the benchmark pipeline.
 // DEV_PLY: the ply index is ply0 + *ply_dev (gbl_rollout_at, graph replay).  A template parameter because even
 // the never-taken runtime test costs the by-value kernel 0.3 us: it sits in front of the hoisted draw.
-template <bool WITH_MASK, bool WITH_OBS, int NT, bool DEV_PLY>
+// ONE_PLY: plies == 1 known at compile time (the fused ply of a ply-by-ply pipeline): no loop, no second draw.
+template <bool WITH_MASK, bool WITH_OBS, int NT, bool DEV_PLY, bool ONE_PLY>
 __global__ __launch_bounds__(64 * kStepWaves) void k_rollout(int8_t *__restrict__ state, int8_t *__restrict__ to_move,
                                                 int64_t n, int64_t ntiles, uint64_t seed, uint64_t env_base,
                                                 const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies,
@@ -449,10 +450,11 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_rollout(int8_t *__restrict_
     Ply y{0, 0, 0, false, false};
     int dn = 0, action = -1, tcount = 0;  // tcount: turn delta, or the absolute turn once a reset happened
     bool treset = false;
+    if (ONE_PLY) plies = 1;
     for (uint32_t t = 0; t < plies; ++t) {
         const uint32_t ply = ply0 + t;
         action = pick54(legal54(p, mover), draw_word(block, ply));
-        if (t + 1 < plies && ((ply + 1) & 3u) == 0) block = draw_block(seed, env_base + (uint64_t)L.b, ply + 1);
+        if (!ONE_PLY && t + 1 < plies && ((ply + 1) & 3u) == 0) block = draw_block(seed, env_base + (uint64_t)L.b, ply + 1);
         step_lane(row, p, mover, 0, action, illegal_mode, 1, dn, y);
         tcount = next_turn(tcount, y, 1);
         treset = treset || y.terminal;
@@ -1097,13 +1099,16 @@ int gbl_rollout_at(int8_t *state, int8_t *to_move, int8_t *done, int32_t *action
     Geometry g = geometry(n, kStepWaves);
     hipStream_t s = (hipStream_t)stream;
     const int nt = nt_policy(n);
-#define GBL_ROLL_K(M, O, NT, D)                                                                                     \
-    hipLaunchKernelGGL((k_rollout<M, O, NT, D>), dim3(g.grid), dim3(64 * kStepWaves), 0, s, state, to_move, n,      \
+#define GBL_ROLL_K(M, O, NT, D, ONE)                                                                                \
+    hipLaunchKernelGGL((k_rollout<M, O, NT, D, ONE>), dim3(g.grid), dim3(64 * kStepWaves), 0, s, state, to_move, n, \
                        g.ntiles, seed, env_base, ply_dev, ply0, plies, done, actions_out, winner_out, reward_out,   \
                        mask_out, obs_out, illegal_mode, counters, turn)
+#define GBL_ROLL_D(M, O, NT, D)                                 \
+    if (plies == 1) GBL_ROLL_K(M, O, NT, D, true);              \
+    else GBL_ROLL_K(M, O, NT, D, false)
 #define GBL_ROLL_NT(M, O, NT)                                   \
-    if (ply_dev) GBL_ROLL_K(M, O, NT, true);                    \
-    else GBL_ROLL_K(M, O, NT, false)
+    if (ply_dev) { GBL_ROLL_D(M, O, NT, true); }                \
+    else { GBL_ROLL_D(M, O, NT, false); }
 #define GBL_ROLL(M, O)                                          \
     if (nt == 3) { GBL_ROLL_NT(M, O, 3); }                      \
     else { GBL_ROLL_NT(M, O, 1); }
@@ -1113,6 +1118,7 @@ int gbl_rollout_at(int8_t *state, int8_t *to_move, int8_t *done, int32_t *action
     else GBL_ROLL(false, false)
 #undef GBL_ROLL
 #undef GBL_ROLL_NT
+#undef GBL_ROLL_D
 #undef GBL_ROLL_K
     GBL_LAUNCHED("gbl_rollout");  // (also gbl_rollout_at)
 }

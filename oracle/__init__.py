@@ -22,6 +22,12 @@ CELLS, ACTIONS, OBS = 27, 54, 117
 ILLEGAL_NOOP, ILLEGAL_TERMINATE = 0, 1
 
 
+def _clean_env():
+    """compiler children must not inherit a profiler's preload (see gobblet-rl_amd/_native.py:_compiler_env)"""
+    return {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "HSA_TOOLS_LIB")
+            and not k.startswith(("ROCP", "ROCPROFILER", "ROCTRACER", "ROCTX"))}
+
+
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (seconds). Returns the .so path."""
     src = os.path.join(_HERE, "gobblet_oracle.c")
@@ -29,7 +35,7 @@ def build(force: bool = False) -> str:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-                subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libgobblet_oracle.so"])
+                subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libgobblet_oracle.so"], env=_clean_env())
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB_PATH

@@ -42,3 +42,15 @@ st, en = (rt0 - base) * 10, (rt1 - base) * 10
 print(f"  starts (ns after the first): p10 {np.percentile(st, 10):.0f} p50 {np.percentile(st, 50):.0f} p90 {np.percentile(st, 90):.0f} last {st.max()}")
 print(f"  ends   (ns after the first start): first {en.min()} p10 {np.percentile(en, 10):.0f} p50 {np.percentile(en, 50):.0f} p90 {np.percentile(en, 90):.0f} last {en.max()}")
 print(f"  lifetime ns mean {(en - st).mean():.0f} -> shader clock {life.mean() / (en - st).mean():.2f} GHz")
+xcc = (buf[:, 7] & 0xF).astype(np.int64)
+for x in sorted(set(xcc.tolist())):
+    m = xcc == x
+    print(f"    xcc {x}: {int(m.sum()):5d} tiles  start {st[m].min():5d}..{st[m].max():5d} ns  eval phase mean {d[m, 1].mean():8.0f} cycles  "
+          f"lifetime mean {life[m].mean():8.0f}  last end {en[m].max():6d} ns")
+cu = ((buf[:, 6] >> 8) & 0xF).astype(np.int64) | (((buf[:, 6] >> 12) & 0xF).astype(np.int64) << 4) | (xcc << 8)
+ids, inv = np.unique(cu, return_inverse=True)
+per = np.bincount(inv)
+print(f"  CUs used {len(ids)}; tiles per CU min {per.min()} max {per.max()} (histogram {np.bincount(per).tolist()})")
+worst = np.array([life[inv == i].max() for i in range(len(ids))])
+print(f"  slowest tile per CU: p50 {np.median(worst):.0f} p95 {np.percentile(worst, 95):.0f} max {worst.max()} cycles; by tiles per CU: "
+      + ", ".join(f"{k}: {worst[per == k].mean():.0f}" for k in sorted(set(per.tolist()))))

@@ -18,7 +18,9 @@ def build():
         try:
             if not os.path.exists(_LIB) or any(os.path.getmtime(_LIB) < os.path.getmtime(s) for s in _SRCS):
                 subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unknown-pragmas", "-fPIC", "-shared",
-                                       "-o", _LIB, _SRCS[0]])
+                                       "-o", _LIB, _SRCS[0]],
+                                      env={k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "HSA_TOOLS_LIB")
+                                           and not k.startswith(("ROCP", "ROCPROFILER", "ROCTRACER", "ROCTX"))})
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB

@@ -928,3 +928,44 @@ def test_collect_vs_oracle_and_graph_replay(G):
     last = [oracle.batch_rollout(s, tm, dn, seed, 0, 3 * T + t_, 1) for t_ in range(T)]  # second replay, ply by ply
     assert env.ply == 4 * T and np.array_equal(npy(env.squares), s)
     assert all(np.array_equal(npy(buf["observation"][t_]), last[t_]["obs"]) for t_ in range(T))
+
+
+def test_bench_script_runs_and_reports(G):
+    """bench.py's contract line on a small shard, in each mode: one JSON line with the contract's keys, a roofline
+    whose achieved rate is consistent with the reported time, and the sub-records it promises."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in (["--mode", "collect"], ["--mode", "fused"], ["--mode", "step"], ["--mode", "collect", "--no-obs", "--graph", "0"]):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--boards", "16384", "--steps", "20", "--warmup", "5",
+                              "--no-configs", "--no-cpu-baseline", *extra], capture_output=True, text=True, timeout=300, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in d, k
+        assert d["steps"] == 20 and d["n_gpus"] == 1 and d["config"]["total_boards"] == 16384 and d["scaling"] == "strong"
+        r = d["roofline"]
+        assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
+        assert abs(d["value"] - 16384 * 20 / (d["ms_per_step"] * 20 / 1e3)) / d["value"] < 1e-6
+
+
+def test_bench_script_two_ranks_rehearsal(G):
+    """The N > 1 path of bench.py (one rank per GPU under torch.distributed.run: barriers around the timed region,
+    MAX-reduce of the elapsed time, all-gather of the per-rank kernel times, strong-scaling shards) rehearsed with two
+    ranks that share this box's one GPU over gloo."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--boards", "32768", "--dist-backend", "gloo", "--share-device"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_boards"] == 32768
+    assert d["config"]["boards_per_gpu"] == 16384 and len(d["config"]["kernel_us_per_rank"]) == 2
+    assert "configs" not in d and "cpu_baseline" not in d  # N = 1 only
