@@ -210,8 +210,8 @@ class Pipeline:
                 ev[0].record()
             T = self.TP
             rc = lib.gbl_collect(P["sq"], P["tm"], P["dn"], T["ac"], T["wi"], T["rw"], T["dn"], T["tm"], T["mk"], T["ob"],
-                                 n, self.traj["_slot_boards"], env.seed, env.env_base, off, self.ctr.data_ptr(), plies, 0,
-                                 None, None, stream)
+                                 n, self.traj["_ply_stride"], self.traj["_tile_stride"], env.seed, env.env_base, off,
+                                 self.ctr.data_ptr(), plies, 0, None, None, stream)
         self.nat.check(rc, "launch")
         if ev:
             ev[1].record()

@@ -64,8 +64,8 @@ SIGNATURES = {
     "gbl_rollout_at": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u64, _u64, _u32, _vp, _u32, _int, _vp, _vp, _vp]),
     "gbl_greedy_act_at": (_int, [_vp, _vp, _vp, _vp, _int, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gbl_counter_add": (_int, [_vp, _u32, _vp]),
-    "gbl_collect": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _u64, _u64, _u32, _vp, _u32, _int,
-                           _vp, _vp, _vp]),
+    "gbl_collect": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u64, _u64, _u32, _vp, _u32,
+                           _int, _vp, _vp, _vp]),
 }
 
 

@@ -328,28 +328,28 @@ static_assert(image_words<kObs>() % 4 == 0 && image_words<kActions>() % 4 == 0 &
 // stream gains once a ply's footprint (234 B per board) no longer fits the 256 MiB Infinity Cache
 // (2^22 boards: 169 -> 141 us) and loses ~2 % below that; the state rows are re-read next ply and stay
 // cached.  The host picks the variant from the batch size (nt_policy()).
-// the tile's observation rows (raw_env.observe of `observer`) through the image `img`; obs_out: row 0 of the array
+// the tile's observation rows (raw_env.observe of `observer`) through the image `img`; obs_tile: the tile's first row
 template <bool NT>
 __device__ __forceinline__ void store_obs(uint32_t *img, const Lane &L, const Planes &p, int observer,
-                                          int8_t *__restrict__ obs_out)
+                                          int8_t *__restrict__ obs_tile)
 {
     obs_image_zero(img, L.lane);
     wave_lds_fence();
     obs_scatter(img, L.lane, p, observer);
     wave_lds_fence();
-    tile_out<kObs, NT>(obs_out + L.tile * (kTile * kObs), img, L.lane, L.rows);
+    tile_out<kObs, NT>(obs_tile, img, L.lane, L.rows);
     wave_lds_fence();
 }
 
-// the tile's mask rows from 54-bit sets
+// the tile's mask rows from 54-bit sets; mask_tile: the tile's first row
 template <bool NT>
-__device__ __forceinline__ void store_mask(uint32_t *img, const Lane &L, uint64_t legal, int8_t *__restrict__ mask_out)
+__device__ __forceinline__ void store_mask(uint32_t *img, const Lane &L, uint64_t legal, int8_t *__restrict__ mask_tile)
 {
     uint32_t d[14];
     mask_row(legal, d);
     row_stage<kActions>(img, L.lane, d);
     wave_lds_fence();
-    tile_out<kActions, NT>(mask_out + L.tile * (kTile * kActions), img, L.lane, L.rows);
+    tile_out<kActions, NT>(mask_tile, img, L.lane, L.rows);
     wave_lds_fence();
 }
 
@@ -361,10 +361,11 @@ __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, bool ma
     wave_lds_fence();  // every lane's byte patches are in the image
     tile_out<kCells, (NT & 4) != 0>(state + L.tile * (kTile * kCells), img, L.lane, L.rows);
     wave_lds_fence();
-    if (WITH_OBS) store_obs<(NT & 1) != 0>(img, L, p, observer, obs_out);
+    if (WITH_OBS) store_obs<(NT & 1) != 0>(img, L, p, observer, obs_out + L.tile * (kTile * kObs));
     // the next mover's legal mask is computed only now, behind the state and observation stores: the
     // sooner a wave's first stores are in flight, the shorter the launch's ramp-up
-    if (WITH_MASK) store_mask<(NT & 2) != 0>(img, L, mask_zero ? 0ull : legal54(p, observer), mask_out);
+    if (WITH_MASK)
+        store_mask<(NT & 2) != 0>(img, L, mask_zero ? 0ull : legal54(p, observer), mask_out + L.tile * (kTile * kActions));
 }
 
 // (GBL_STAMP* : per-wavefront phase stamps of the diagnostic build, gobblet_diag.h; they expand to nothing here)
@@ -505,7 +506,7 @@ template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY>
 __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n,
                                                 int64_t ntiles, uint64_t seed, uint64_t env_base,
                                                 const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies,
-                                                int8_t *__restrict__ done, int64_t slot_boards,
+                                                int8_t *__restrict__ done, int64_t ply_stride, int64_t tile_stride,
                                                 int32_t *__restrict__ actions_t, int8_t *__restrict__ winner_t,
                                                 int8_t *__restrict__ reward_t, int8_t *__restrict__ done_t,
                                                 int8_t *__restrict__ to_move_t, int8_t *__restrict__ mask_t,
@@ -514,6 +515,8 @@ __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__r
 {
     __shared__ uint32_t s_state[image_words<kCells>()];
     __shared__ uint32_t s_out[out_image_words<true, WITH_OBS>()];
+    GBL_STAMP(0);
+    GBL_STAMP_REAL(0);
     if (DEV_PLY) ply0 += *ply_dev;
     Lane L;
 #ifdef GBL_X_COLLECT_REMAP
@@ -555,19 +558,19 @@ __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__r
             w1 += __popcll(__ballot(L.valid && y.winner == 1));
             w2 += __popcll(__ballot(L.valid && y.winner == -1));
         }
-        // slot t
-        const int64_t slot = (int64_t)t * slot_boards;
+        // ply t of this tile: boards [cell, cell + 64) of the trajectory arrays
+        const int64_t cell = (int64_t)t * ply_stride + L.tile * tile_stride;
         if (L.valid) {
-            const int64_t at = slot + L.b;
+            const int64_t at = cell + L.lane;
             if (actions_t) actions_t[at] = action;
             if (winner_t) winner_t[at] = (int8_t)y.winner;
             if (reward_t) reinterpret_cast<uint16_t *>(reward_t)[at] = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
             if (done_t) done_t[at] = (int8_t)dn;
             if (to_move_t) to_move_t[at] = (int8_t)mover;
         }
-        if (WITH_OBS) store_obs<true>(s_out, L, p, mover, obs_t + slot * kObs);
+        if (WITH_OBS) store_obs<true>(s_out, L, p, mover, obs_t + cell * kObs);
         legal = legal54(p, mover);  // the next mover's: stored now, sampled from next ply
-        if (WITH_MASK) store_mask<true>(s_out, L, legal, mask_t + slot * kActions);
+        if (WITH_MASK) store_mask<true>(s_out, L, legal, mask_t + cell * kActions);
     }
     wave_lds_fence();  // every lane's byte patches are in the state image
     tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
@@ -584,6 +587,9 @@ __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__r
         if (w1) atomicAdd(c + 2, (unsigned long long)w1);
         if (w2) atomicAdd(c + 3, (unsigned long long)w2);
     }
+    GBL_STAMP(1); GBL_STAMP(2); GBL_STAMP(3); GBL_STAMP(4);
+    GBL_STAMP_DRAIN(5);
+    GBL_STAMP_FLUSH(L.tile);
 }
 
 // gbl_counter_add: the device-resident ply / call counter of the *_at entry points
@@ -1125,15 +1131,22 @@ int gbl_rollout_at(int8_t *state, int8_t *to_move, int8_t *done, int32_t *action
 
 int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_traj, int8_t *winner_traj,
                 int8_t *reward_traj, int8_t *done_traj, int8_t *to_move_traj, int8_t *mask_traj, int8_t *obs_traj,
-                int64_t n, int64_t slot_boards, uint64_t seed, uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev,
-                uint32_t plies, int illegal_mode, int64_t *counters, int32_t *turn, void *stream)
+                int64_t n, int64_t ply_stride, int64_t tile_stride, uint64_t seed, uint64_t env_base, uint32_t ply0,
+                const uint32_t *ply_dev, uint32_t plies, int illegal_mode, int64_t *counters, int32_t *turn, void *stream)
 {
     GBL_CHECK_N(n);
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done");
     if (illegal_mode != GBL_ILLEGAL_NOOP && illegal_mode != GBL_ILLEGAL_TERMINATE)
         return fail(GBL_ERR_ARG, "illegal_mode must be GBL_ILLEGAL_NOOP or GBL_ILLEGAL_TERMINATE");
     if (plies == 0) return GBL_OK;
-    if (slot_boards < n || (slot_boards & 15)) return fail(GBL_ERR_ARG, "slot_boards must be >= n and a multiple of 16");
+    {   // the (ply, tile) cells of 64 boards must start 16-byte aligned and must not overlap
+        const int64_t tiles = (n + kTile - 1) / kTile;
+        const bool aligned = ply_stride > 0 && tile_stride > 0 && !(ply_stride & 15) && !(tile_stride & 15);
+        const bool time_major = tile_stride >= kTile && (plies == 1 || ply_stride >= (tiles - 1) * tile_stride + kTile);
+        const bool tile_major = ply_stride >= kTile && (tiles == 1 || tile_stride >= ((int64_t)plies - 1) * ply_stride + kTile);
+        if (!aligned || !(time_major || tile_major))
+            return fail(GBL_ERR_ARG, "ply_stride / tile_stride: multiples of 16 boards that keep the (ply, tile) cells apart");
+    }
     GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask_traj, "mask_traj"); GBL_ALIGNED(obs_traj, "obs_traj");
     if (reward_traj && (reinterpret_cast<uintptr_t>(reward_traj) & 1u))
         return fail(GBL_ERR_ALIGN, "reward_traj must be 2-byte aligned");
@@ -1146,7 +1159,8 @@ int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_t
     hipStream_t s = (hipStream_t)stream;
 #define GBL_COLLECT_K(M, O, D)                                                                                        \
     hipLaunchKernelGGL((k_collect<M, O, D>), dim3(g.grid), dim3(64), 0, s, state, to_move, n, g.ntiles, seed, env_base, \
-                       ply_dev, ply0, plies, done, slot_boards, actions_traj, winner_traj, reward_traj, done_traj,     \
+                       ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj, reward_traj,     \
+                       done_traj,                                                                                      \
                        to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn)
 #define GBL_COLLECT(M, O)                                       \
     if (ply_dev) GBL_COLLECT_K(M, O, true);                     \

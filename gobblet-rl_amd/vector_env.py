@@ -203,39 +203,62 @@ class BatchedGobblet:
         return self.observe(), self.rewards, self.done, self.winner
 
     # -- trajectory collection: T plies per launch, every ply materialised -------------------------------------
-    def trajectory_buffers(self, plies: int, pad_boards: int | None = None) -> dict:
-        """Device tensors for ``collect``: every entry has shape (plies, N, ...) and is a view of a
+    def trajectory_buffers(self, plies: int, layout: str = "time", pad_boards: int | None = None) -> dict:
+        """Device tensors for ``collect``.
+
+        layout "time" (default): every entry has shape (plies, N, ...) -- one slice per ply, a view of a
         (plies, slot_boards, ...) allocation; slot_boards = N rounded up to 128 boards (+ ``pad_boards``), so that
-        every slot of every array starts on a 128-byte line (the C-ABI itself asks for a multiple of 16 only)."""
+        every slot of every array starts on a 128-byte line (the C-ABI itself asks for multiples of 16 only).
+        layout "tile": every entry has shape (tiles, plies, 64, ...), tiles = ceil(N / 64) -- board b is
+        [b // 64, :, b % 64]; each tile keeps its whole trajectory contiguous, so every wavefront of the kernel writes
+        one sequential region per array (boards past N in the last tile are never written)."""
         n, dev, T = self.num_envs, self.device, int(plies)
-        slot = -(-n // 128) * 128 + (self.SLOT_PAD_BOARDS if pad_boards is None else int(pad_boards))
-        full = {"actions": torch.zeros((T, slot), dtype=torch.int32, device=dev),
-                "winner": torch.zeros((T, slot), dtype=torch.int8, device=dev),
-                "rewards": torch.zeros((T, slot, 2), dtype=torch.int8, device=dev),
-                "done": torch.zeros((T, slot), dtype=torch.int8, device=dev),
-                "to_move": torch.zeros((T, slot), dtype=torch.int8, device=dev),
-                "action_mask": torch.zeros((T, slot, nat.ACTIONS), dtype=torch.int8, device=dev)}
+        if layout not in ("time", "tile"):
+            raise ValueError("layout must be 'time' or 'tile'")
+        tiles = -(-n // 64)
+        if layout == "time":
+            slot = -(-n // 128) * 128 + (self.SLOT_PAD_BOARDS if pad_boards is None else int(pad_boards))
+            lead, ply_stride, tile_stride = (T, slot), slot, 64
+        else:
+            lead, ply_stride, tile_stride = (tiles, T, 64), 64, 64 * T
+        full = {"actions": torch.zeros(lead, dtype=torch.int32, device=dev),
+                "winner": torch.zeros(lead, dtype=torch.int8, device=dev),
+                "rewards": torch.zeros(lead + (2,), dtype=torch.int8, device=dev),
+                "done": torch.zeros(lead, dtype=torch.int8, device=dev),
+                "to_move": torch.zeros(lead, dtype=torch.int8, device=dev),
+                "action_mask": torch.zeros(lead + (nat.ACTIONS,), dtype=torch.int8, device=dev)}
         if self.observation is not None:
-            full["observation"] = torch.zeros((T, slot, 3, 3, 13), dtype=torch.int8, device=dev)
-        out = {k: v[:, :n] for k, v in full.items()}
-        out["_full"], out["_slot_boards"], out["_plies"] = full, slot, T
+            full["observation"] = torch.zeros(lead + (3, 3, 13), dtype=torch.int8, device=dev)
+        out = {k: (v[:, :n] if layout == "time" else v) for k, v in full.items()}
+        out.update(_full=full, _plies=T, _layout=layout, _ply_stride=ply_stride, _tile_stride=tile_stride,
+                   _slot_boards=ply_stride if layout == "time" else None)
         return out
 
-    def collect(self, plies: int, out: dict | None = None, count: bool = False, refresh: bool = True) -> dict:
+    def _last_ply(self, out: dict, key: str) -> torch.Tensor:
+        """The (N, ...) slice of trajectory entry `key` that belongs to the last ply (a view)."""
+        T, n = out["_plies"], self.num_envs
+        if out["_layout"] == "time":
+            return out[key][T - 1]
+        v = out[key][:, T - 1]  # (tiles, 64, ...)
+        return v.reshape((v.shape[0] * 64,) + tuple(v.shape[2:]))[:n]
+
+    def collect(self, plies: int, out: dict | None = None, count: bool = False, refresh: bool = True,
+                layout: str = "time") -> dict:
         """``plies`` masked-random plies with auto-reset in ONE launch (``gbl_collect``), EVERY ply materialised:
         entry t of the returned tensors -- "actions", "winner", "rewards", "done", "to_move", "action_mask",
-        "observation", each (plies, N, ...) -- is what ``rollout(1)`` called ``plies`` times would have left in the
-        attribute tensors after call t: the action played, its result, and the mask / observation of the agent to
-        move next.  The environment's own tensors (squares, to_move, done, turn, counters) hold the position after
-        the last ply; with ``refresh`` the ``action_mask`` / ``observation`` / ``actions`` / ``winner`` / ``rewards``
-        attributes are copied from the last slot (device copies of ~180 B per board: a pure collector that only
-        reads the trajectory passes ``refresh=False`` and calls ``refresh()`` before it next steps by hand).
+        "observation", each (plies, N, ...) in the default time-major layout -- is what ``rollout(1)`` called ``plies``
+        times would have left in the attribute tensors after call t: the action played, its result, and the mask /
+        observation of the agent to move next.  (``layout="tile"``, or buffers made with it: (tiles, plies, 64, ...),
+        see ``trajectory_buffers``.)  The environment's own tensors (squares, to_move, done, turn, counters) hold the
+        position after the last ply; with ``refresh`` the ``action_mask`` / ``observation`` / ``actions`` / ``winner`` /
+        ``rewards`` attributes are copied from the last ply (device copies of ~180 B per board: a pure collector that
+        only reads the trajectory passes ``refresh=False`` and calls ``refresh()`` before it next steps by hand).
         ``out``: a dict from ``trajectory_buffers(plies)`` to reuse (a replay buffer's staging area)."""
         if not self.auto_reset:
             raise ValueError("collect() plays with auto-reset; this environment was created with auto_reset=False")
         T = int(plies)
         if out is None:
-            out = self.trajectory_buffers(T)
+            out = self.trajectory_buffers(T, layout=layout)
         if out["_plies"] != T:
             raise ValueError("trajectory buffers were made for %d plies" % out["_plies"])
         f, n = out["_full"], self.num_envs
@@ -243,17 +266,18 @@ class BatchedGobblet:
                                         f["actions"].data_ptr(), f["winner"].data_ptr(), f["rewards"].data_ptr(),
                                         f["done"].data_ptr(), f["to_move"].data_ptr(), f["action_mask"].data_ptr(),
                                         f["observation"].data_ptr() if "observation" in f else None, n,
-                                        out["_slot_boards"], self.seed, self.env_base, self._ply, nat.ptr(self._ply_dev),
-                                        T, self.illegal_mode, self._counters.data_ptr() if count else None,
-                                        nat.ptr(self.turn), self._stream()), "gbl_collect")
+                                        out["_ply_stride"], out["_tile_stride"], self.seed, self.env_base, self._ply,
+                                        nat.ptr(self._ply_dev), T, self.illegal_mode,
+                                        self._counters.data_ptr() if count else None, nat.ptr(self.turn),
+                                        self._stream()), "gbl_collect")
         self._ply += T
         if not refresh:
             return out
         # keep the attribute tensors consistent with the position after the last ply
-        self.action_mask.copy_(out["action_mask"][T - 1]); self.actions.copy_(out["actions"][T - 1])
-        self.winner.copy_(out["winner"][T - 1]); self.rewards.copy_(out["rewards"][T - 1])
+        self.action_mask.copy_(self._last_ply(out, "action_mask")); self.actions.copy_(self._last_ply(out, "actions"))
+        self.winner.copy_(self._last_ply(out, "winner")); self.rewards.copy_(self._last_ply(out, "rewards"))
         if self.observation is not None:
-            self.observation.copy_(out["observation"][T - 1])
+            self.observation.copy_(self._last_ply(out, "observation"))
         return out
 
     # -- masked-uniform sampling (examples/example_basic.py:58-61) ----------------------------------------

@@ -226,22 +226,30 @@ int gbl_greedy_act_at(const int8_t *state, const int8_t *to_move, const int8_t *
                       int32_t *chosen_out, int8_t *cand_mask_out, int8_t *fallback_out, int64_t n, void *stream);
 
 /* Trajectory collection (K plies per launch with EVERY ply materialised).  `plies` masked-random
- * plies with auto-reset in ONE launch; ply t (t = 0 .. plies-1) leaves in slot t of the trajectory arrays exactly
- * what gbl_rollout(plies = 1) with ply index ply0 + t leaves in its output arrays:
- *   actions_traj int32[plies][slot_boards]      the action played at ply t
- *   winner_traj  int8 [plies][slot_boards]      check_for_winner() after it        reward_traj int8[plies][slot_boards][2]
- *   done_traj    int8 [plies][slot_boards]      1 where the episode ended on ply t (the board was then reset)
- *   to_move_traj int8 [plies][slot_boards]      the agent to move next -- the one mask / obs of the slot belong to
- *   mask_traj    int8 [plies][slot_boards][54]  obs_traj int8[plies][slot_boards][117]
- * (any of them may be NULL; board b of slot t is element t * slot_boards + b; slot_boards >= n, a multiple of 16,
- * so every slot starts 16-byte aligned).  state / to_move / done / turn / counters are read at entry and hold
- * the position after the last ply on return, as with gbl_rollout.  A consumer (replay buffer, trainer) reads
- * the whole trajectory after the launch; between plies nothing but the per-ply outputs touches HBM.
+ * plies with auto-reset in ONE launch; ply t (t = 0 .. plies-1) of board b leaves in element
+ *     cell(t, b) = t * ply_stride + (b / 64) * tile_stride + b % 64
+ * of the trajectory arrays exactly what gbl_rollout(plies = 1) with ply index ply0 + t leaves in element b of
+ * its output arrays:
+ *   actions_traj int32[cells]      the action played at ply t
+ *   winner_traj  int8 [cells]      check_for_winner() after it        reward_traj int8[cells][2]
+ *   done_traj    int8 [cells]      1 where the episode ended on ply t (the board was then reset)
+ *   to_move_traj int8 [cells]      the agent to move next -- the one mask / obs of the element belong to
+ *   mask_traj    int8 [cells][54]  obs_traj int8[cells][117]
+ * (any of them may be NULL).  The two strides, in boards and multiples of 16, choose the layout:
+ *   time-major  [plies][slot_boards]:  ply_stride = slot_boards >= n rounded up to 64, tile_stride = 64
+ *                                      (element (t, b) at t * slot_boards + b: one array slice per ply);
+ *   tile-major  [tiles][plies][64]:    ply_stride = 64, tile_stride = 64 * plies
+ *                                      (each tile of 64 boards keeps its whole trajectory contiguous: every
+ *                                      wavefront writes ONE sequential region per array).
+ * state / to_move / done / turn / counters are read at entry and hold the position after the last ply on
+ * return, as with gbl_rollout.  A consumer (replay buffer, trainer) reads the trajectory after the launch;
+ * between plies nothing but the per-ply outputs touches HBM.
  * ply_dev: NULL, or the device-resident base of the ply index as in gbl_rollout_at. */
 int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_traj, int8_t *winner_traj,
                 int8_t *reward_traj, int8_t *done_traj, int8_t *to_move_traj, int8_t *mask_traj, int8_t *obs_traj,
-                int64_t n, int64_t slot_boards, uint64_t seed, uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev,
-                uint32_t plies, int illegal_mode, int64_t *counters, int32_t *turn, void *stream);
+                int64_t n, int64_t ply_stride, int64_t tile_stride, uint64_t seed, uint64_t env_base, uint32_t ply0,
+                const uint32_t *ply_dev, uint32_t plies, int illegal_mode, int64_t *counters, int32_t *turn,
+                void *stream);
 /* *counter += by, enqueued on the stream (device uint32). */
 int gbl_counter_add(uint32_t *counter, uint32_t by, void *stream);
 

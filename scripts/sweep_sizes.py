@@ -32,8 +32,8 @@ def main():
     args = ap.parse_args()
     for mode in args.modes.split(","):
         for n in (int(s) for s in args.sizes.split(",")):
-            traj = mode.startswith("traj")
-            env = G.BatchedGobblet(n, "cuda:0", auto_reset=True, seed=0, with_observation=mode in ("full", "traj"))
+            traj = mode.startswith("traj") or mode.startswith("tile")
+            env = G.BatchedGobblet(n, "cuda:0", auto_reset=True, seed=0, with_observation=mode in ("full", "traj", "tile"))
             for _ in range(64):
                 env.rollout(1)
             env.device_ply()
@@ -42,7 +42,7 @@ def main():
             if traj:  # gbl_collect: args.traj plies per launch, every ply materialised in its trajectory slot
                 T = args.traj
                 launches = max(1, args.plies // T)  # (every launch reuses the same T slots)
-                buf = env.trajectory_buffers(T)
+                buf = env.trajectory_buffers(T, layout="tile" if mode.startswith("tile") else "time")
                 env.collect(T, out=buf, refresh=False)
                 torch.cuda.synchronize()
                 with torch.cuda.graph(g):
@@ -68,7 +68,8 @@ def main():
                 us.append(a.elapsed_time(b) * 1e3 / plies)
             # algorithmic bytes per env-step: SURVEY.md 8d (234 FULL / 117 MASK_ONLY); a trajectory launch reads and
             # writes the state once per T plies and writes the action: 178 + 55 / T (61 + 55 / T without observation)
-            bytes_per = {"full": 234, "mask": 117, "traj": 178 + 55 / args.traj, "trajmask": 61 + 55 / args.traj}[mode]
+            bytes_per = {"full": 234, "mask": 117, "traj": 178 + 57 / args.traj, "trajmask": 61 + 57 / args.traj,
+                         "tile": 178 + 57 / args.traj, "tilemask": 61 + 57 / args.traj}[mode]
             med = statistics.median(us)
             print(json.dumps({"tag": args.tag + (f":T{args.traj}" if traj else ""), "mode": mode, "boards": n, "us_per_ply": round(med, 3),
                               "best_us": round(min(us), 3), "frac_of_8TBps": round(bytes_per * n / med / 8e6, 4),

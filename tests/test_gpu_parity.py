@@ -881,6 +881,14 @@ def test_collect_equals_ply_by_ply_rollout(G, n, with_obs, illegal):
     a.rollout(5, count=True); b.rollout(5, count=True)  # not from the empty board, not from ply 0
     tr = a.collect(T, count=True)
     assert tr["_slot_boards"] % 16 == 0 and tr["_slot_boards"] >= n
+    a2 = G.BatchedGobblet(n, DEV, **kw)  # the same plies into tile-major buffers: (tiles, plies, 64, ...)
+    a2.rollout(5, count=True)
+    tt = a2.collect(T, count=True, layout="tile")
+    bb, ll = torch.arange(n, device=DEV) // 64, torch.arange(n, device=DEV) % 64
+    for key in ("actions", "winner", "rewards", "done", "to_move", "action_mask") + (("observation",) if with_obs else ()):
+        assert tt[key].shape[:3] == (-(-n // 64), T, 64)
+        assert torch.equal(tt[key][bb, :, ll].transpose(0, 1), tr[key]), key
+    assert torch.equal(a2.squares, a.squares) and torch.equal(a2.action_mask, a.action_mask) and torch.equal(a2.turn, a.turn)
     for t_ in range(T):
         b.rollout(1, count=True)
         assert torch.equal(tr["actions"][t_], b.actions), t_
