@@ -65,6 +65,14 @@ inline int nt_policy(int64_t n)
 #endif
 }
 
+// gbl_collect stores a trajectory of up to this many bytes with plain (cached) stores, a larger one non-temporally.
+// 0 = always non-temporal, the robust choice: plain stores win 5-12 % where the trajectory fits the Infinity Cache AND
+// the batch is 131 072 - 262 144 boards, but lose 15 % at 65 536 boards and 30 % once it does not fit (see k_collect).
+#ifndef GBL_COLLECT_CACHED_BYTES
+#define GBL_COLLECT_CACHED_BYTES ((int64_t)0)
+#endif
+constexpr int64_t kCollectCachedBytes = GBL_COLLECT_CACHED_BYTES;
+
 // LDS words for a tile image of ROWB-byte rows (+ slack for row_load's look-ahead dword)
 template <int ROWB>
 constexpr int image_words() { return kTile * ROWB / 4 + 4; }
@@ -502,7 +510,12 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_rollout(int8_t *__restrict_
 #ifndef GBL_X_COLLECT_WAVES
 #define GBL_X_COLLECT_WAVES 1
 #endif
-template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY>
+// NT: the trajectory rows are stored with the non-temporal hint (a trajectory larger than the Infinity Cache is a
+// write-once stream to HBM: 2^20 boards x 8 plies 34.6 vs 45.0 us per ply) or plainly (a trajectory that fits the
+// 256 MiB cache stays there for whoever reads it next and is overwritten there by the next launch: 131 072 boards x 8
+// plies 4.15 vs 4.76 us per ply, 262 144 x 4: 8.5 vs 9.5 -- but 65 536 x 16: 2.44 vs 2.12); the host decides by the
+// footprint against kCollectCachedBytes (gpurun_out/ab5, scripts/sweep_sizes.py with -DGBL_FORCE_COLLECT_NT=0|1).
+template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY, bool NT>
 __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n,
                                                 int64_t ntiles, uint64_t seed, uint64_t env_base,
                                                 const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies,
@@ -568,9 +581,9 @@ __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__r
             if (done_t) done_t[at] = (int8_t)dn;
             if (to_move_t) to_move_t[at] = (int8_t)mover;
         }
-        if (WITH_OBS) store_obs<true>(s_out, L, p, mover, obs_t + cell * kObs);
+        if (WITH_OBS) store_obs<NT>(s_out, L, p, mover, obs_t + cell * kObs);
         legal = legal54(p, mover);  // the next mover's: stored now, sampled from next ply
-        if (WITH_MASK) store_mask<true>(s_out, L, legal, mask_t + cell * kActions);
+        if (WITH_MASK) store_mask<NT>(s_out, L, legal, mask_t + cell * kActions);
     }
     wave_lds_fence();  // every lane's byte patches are in the state image
     tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
@@ -1157,20 +1170,31 @@ int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_t
         return fail(GBL_ERR_ALIGN, "counters must be 128-byte aligned");
     Geometry g = geometry(n);
     hipStream_t s = (hipStream_t)stream;
-#define GBL_COLLECT_K(M, O, D)                                                                                        \
-    hipLaunchKernelGGL((k_collect<M, O, D>), dim3(g.grid), dim3(64), 0, s, state, to_move, n, g.ntiles, seed, env_base, \
+    // bytes of trajectory rows this launch writes, against what the Infinity Cache keeps (see k_collect)
+    const int64_t row_bytes = (int64_t)plies * n * ((mask_traj ? kActions : 0) + (obs_traj ? kObs : 0) + 9);
+#ifdef GBL_FORCE_COLLECT_NT
+    const bool nt = (GBL_FORCE_COLLECT_NT) != 0;
+#else
+    const bool nt = row_bytes > kCollectCachedBytes;
+#endif
+#define GBL_COLLECT_K(M, O, D)                                  \
+    if (nt) GBL_COLLECT_KN(M, O, D, true);                      \
+    else GBL_COLLECT_KN(M, O, D, false)
+#define GBL_COLLECT_KN(M, O, D, N)                                                                                      \
+    hipLaunchKernelGGL((k_collect<M, O, D, N>), dim3(g.grid), dim3(64), 0, s, state, to_move, n, g.ntiles, seed, env_base, \
                        ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj, reward_traj,     \
                        done_traj,                                                                                      \
                        to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn)
 #define GBL_COLLECT(M, O)                                       \
-    if (ply_dev) GBL_COLLECT_K(M, O, true);                     \
-    else GBL_COLLECT_K(M, O, false)
+    if (ply_dev) { GBL_COLLECT_K(M, O, true); }                 \
+    else { GBL_COLLECT_K(M, O, false); }
     if (mask_traj && obs_traj) { GBL_COLLECT(true, true); }
     else if (mask_traj) { GBL_COLLECT(true, false); }
     else if (obs_traj) { GBL_COLLECT(false, true); }
     else { GBL_COLLECT(false, false); }
 #undef GBL_COLLECT
 #undef GBL_COLLECT_K
+#undef GBL_COLLECT_KN
     GBL_LAUNCHED("gbl_collect");
 }
 
