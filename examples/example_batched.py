@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The throughput path: N boards in lockstep on one MI355X.
 
-    python examples/example_batched.py --boards 1048576 --plies 200 --policy random|greedy
+    python examples/example_batched.py --boards 1048576 --plies 200 --policy random|greedy [--graph K] [--collect T]
 """
 import argparse
 import os
@@ -21,8 +21,31 @@ def main():
     ap.add_argument("--policy", default="random", choices=["random", "greedy"])
     ap.add_argument("--graph", type=int, default=0,
                     help="capture this many plies in one hipGraph and replay it (launch latency off the critical path)")
+    ap.add_argument("--collect", type=int, default=0,
+                    help="random policy only: T plies per launch with every ply kept (gbl_collect) -- what a rollout "
+                         "collector hands a trainer: trajectory tensors (T, N, ...)")
     args = ap.parse_args()
     env = G.BatchedGobblet(args.boards, "cuda:0", auto_reset=True, seed=0)
+    if args.collect:
+        assert args.policy == "random", "--collect plays masked-random moves"
+        T, launches = args.collect, max(1, args.plies // args.collect)
+        buf = env.trajectory_buffers(T)              # reused by every launch: the staging area of a replay buffer
+        env.collect(T, out=buf)                      # warm-up
+        wins = torch.zeros(3, dtype=torch.int64, device=env.device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(launches):
+            tr = env.collect(T, out=buf, refresh=False)
+            # a consumer would now read tr["observation"] (T,N,3,3,13), tr["action_mask"] (T,N,54), tr["actions"],
+            # tr["rewards"], tr["done"], tr["to_move"]; here: tally the results of the games that ended
+            wins += torch.bincount((tr["winner"][tr["done"] != 0] + 1).long(), minlength=3)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        games = int(wins[0] + wins[2])
+        print(f"{args.boards} boards x {launches * T} plies (random, {T} plies per launch, every ply kept): "
+              f"{args.boards * launches * T / dt:.3e} env-steps/s incl. the tally, {games} games finished, player_1 won "
+              f"{int(wins[2]) / max(1, games):.1%}")
+        return
     pol = G.GreedyGobbletPolicy(depth=2) if args.policy == "greedy" else None
     p1 = torch.zeros((), dtype=torch.int64, device=env.device)
     p2 = torch.zeros((), dtype=torch.int64, device=env.device)

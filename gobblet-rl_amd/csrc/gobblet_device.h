@@ -745,14 +745,21 @@ __device__ __forceinline__ void outcomes54(const Planes &p, int mover, uint64_t 
         uint32_t nTm = ~(TmR & ~lost), nTo = ~(ToR | gain);  // complements of the tops after the lift
         uint32_t W = 0, Z = 0, open = F3;
         if (WINS_ONLY) {
-#pragma unroll
-            for (int l = 0; l < 8; ++l) {
-                const uint32_t Lr = L[l] | (L[l] << 10) | (L[l] << 20);
-                uint32_t miss = Lr & nTm;
-                uint32_t multi = miss & ((miss | G3) - LOW3);
-                uint32_t mg = (multi + F3) & G3, mm = mg - (mg >> 9);
-                W |= miss & ~mm;
-            }
+            // Every completed line is the mover's and no line is complete before the drop, so the winning
+            // destinations are the "threat squares" of the mover's tops T after the lift: squares whose two partners
+            // on some line are both in T.  Per direction the partners are shifted onto the square (rows: neighbours
+            // at distance 1, columns 3, diagonal 4, anti-diagonal 2); the masks pick the squares for which that pair of
+            // shifts IS the line and cut off what a shift drags in from the neighbouring 10-bit field.
+            constexpr uint32_t M0 = 0x049u * LOW3, M1 = 0x092u * LOW3, M2 = 0x124u * LOW3;  // column 0 / 1 / 2 of the board
+            constexpr uint32_t R0 = 0x007u * LOW3, R1 = 0x038u * LOW3, R2 = 0x1C0u * LOW3;  // row 0 / 1 / 2
+            constexpr uint32_t B0 = 0x001u * LOW3, B2 = 0x004u * LOW3, B4 = 0x010u * LOW3, B6 = 0x040u * LOW3,
+                               B8 = 0x100u * LOW3;
+            const uint32_t T = ~nTm & F3;
+            W = ((T >> 1) & (T >> 2) & M0) | ((T << 1) & (T >> 1) & M1) | ((T << 1) & (T << 2) & M2)     // (0,1,2) (3,4,5) (6,7,8)
+              | ((T >> 3) & (T >> 6) & R0) | ((T << 3) & (T >> 3) & R1) | ((T << 3) & (T << 6) & R2)     // (0,3,6) (1,4,7) (2,5,8)
+              | ((T >> 4) & (T >> 8) & B0) | ((T << 4) & (T >> 4) & B4) | ((T << 4) & (T << 8) & B8)     // (0,4,8)
+              | ((T >> 2) & (T >> 4) & B2) | ((T << 2) & (T >> 2) & B4) | ((T << 2) & (T << 4) & B6);    // (2,4,6)
+            W &= nTm;  // (a square the mover already tops completes nothing by being dropped on)
         } else {
 #pragma unroll
         for (int l = 7; l >= 0; --l) {

@@ -671,7 +671,8 @@ def test_example_scripts_run(G):
             ["examples/example_batched.py", "--boards", "65536", "--plies", "40", "--policy", "random"],
             ["examples/example_batched.py", "--boards", "4096", "--plies", "12", "--policy", "greedy"],
             ["examples/example_batched.py", "--boards", "65536", "--plies", "40", "--policy", "random", "--graph", "8"],
-            ["examples/example_batched.py", "--boards", "4096", "--plies", "12", "--policy", "greedy", "--graph", "4"]]
+            ["examples/example_batched.py", "--boards", "4096", "--plies", "12", "--policy", "greedy", "--graph", "4"],
+            ["examples/example_batched.py", "--boards", "65536", "--plies", "48", "--policy", "random", "--collect", "16"]]
     for cmd in runs:
         r = subprocess.run([sys.executable] + cmd, cwd=root, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
