@@ -413,6 +413,10 @@ def main():
         roof = p.kernel_roofline(kernel_s, plies_timed, launches, timing)
         tkey = f"{args.mode}{'-noobs' if args.no_obs else ''}:{boards}" + (f":T{min(args.traj, K)}" if args.mode == "collect" else "")
         roof["traffic"], roof["traffic_source"] = committed_counter(tkey, "hbm_bytes_per_launch")
+        if args.mode == "collect" and roof["traffic"] is not None:
+            # the counters were taken on launches of exactly T plies; the timed launches may end with a shorter one
+            roof["traffic_plies_per_launch"] = min(args.traj, K)
+            roof["traffic_algorithmic_bytes"] = p.launch_bytes(min(args.traj, K))
         variant = "MASK_ONLY" if args.no_obs else "FULL"
         out = {
             "metric": "env-steps/sec at 2^20 parallel boards, 1/2/4/8 MI355X; bit-exact mask/winner",
