@@ -19,6 +19,18 @@ constexpr int kIters = 512, kChains = 8;
 
 #define I_v_add_u32(A) "v_add_u32 " A ", " A ", %[x]\n"
 #define I_v_and_b32(A) "v_and_b32 " A ", " A ", %[x]\n"
+#define I_v_or_b32(A) "v_or_b32 " A ", " A ", %[x]\n"
+#define I_v_xor_b32(A) "v_xor_b32 " A ", " A ", %[x]\n"
+#define I_v_sub_u32(A) "v_sub_u32 " A ", " A ", %[x]\n"
+#define I_v_not_b32(A) "v_not_b32 " A ", " A "\n"
+#define I_v_mov_b32(A) "v_mov_b32 " A ", %[x]\n"
+#define I_v_lshrrev(A) "v_lshrrev_b32 " A ", %[x], " A "\n"
+#define I_v_min_u32(A) "v_min_u32 " A ", " A ", %[x]\n"
+#define I_v_max_u32(A) "v_max_u32 " A ", " A ", %[x]\n"
+#define I_v_and_const(A) "v_and_b32 " A ", 0x7f7f7f7f, " A "\n"
+#define I_v_add_const(A) "v_add_u32 " A ", 0x7f7f7f7f, " A "\n"
+#define I_v_and_sgpr(A) "v_and_b32 " A ", s20, " A "\n"
+#define I_v_cmp_only(A) "v_cmp_lt_u32 vcc, " A ", %[x]\n"
 #define I_v_bitop3(A) "v_bitop3_b32 " A ", " A ", %[x], %[y] bitop3:0x96\n"
 #define I_v_or3(A) "v_or3_b32 " A ", " A ", %[x], %[y]\n"
 #define I_v_and_or(A) "v_and_or_b32 " A ", " A ", %[x], %[y]\n"
@@ -59,6 +71,18 @@ constexpr int kIters = 512, kChains = 8;
 enum Op {
     OP_v_add_u32,
     OP_v_and_b32,
+    OP_v_or_b32,
+    OP_v_xor_b32,
+    OP_v_sub_u32,
+    OP_v_not_b32,
+    OP_v_mov_b32,
+    OP_v_lshrrev,
+    OP_v_min_u32,
+    OP_v_max_u32,
+    OP_v_and_const,
+    OP_v_add_const,
+    OP_v_and_sgpr,
+    OP_v_cmp_only,
     OP_v_bitop3,
     OP_v_or3,
     OP_v_and_or,
@@ -97,8 +121,8 @@ enum Op {
     OP_v_lshl_add_u64,
     OP_COUNT
 };
-static const char *kNames[] = {"v_add_u32", "v_and_b32", "v_bitop3", "v_or3", "v_and_or", "v_lshl_or", "v_lshl_add", "v_add3", "v_bfe_u32", "v_bfi", "v_alignbyte", "v_alignbit", "v_perm", "v_bcnt", "v_ffbl", "v_ffbh", "v_mul_u24", "v_mad_u24", "v_mul_lo_u32", "v_mul_hi_u32", "v_dot4_u8", "v_dot8_u4", "v_sad_u8", "v_lshlrev", "v_cndmask", "v_cmp_cnd", "v_cmp_sgpr_cnd", "v_mov_dpp", "v_add_dpp", "v_and_sdwa", "v_mbcnt_lo", "v_readlane_add", "ds_bpermute", "ds_swizzle", "s_nop0", "v_mad_u64_u32", "v_lshrrev_b64", "v_lshl_add_u64"};
-static const int kPerBlock[] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 3, 1, 1, 1, 1, 1, 1};
+static const char *kNames[] = {"v_add_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_sub_u32", "v_not_b32", "v_mov_b32", "v_lshrrev", "v_min_u32", "v_max_u32", "v_and_const", "v_add_const", "v_and_sgpr", "v_cmp_only", "v_bitop3", "v_or3", "v_and_or", "v_lshl_or", "v_lshl_add", "v_add3", "v_bfe_u32", "v_bfi", "v_alignbyte", "v_alignbit", "v_perm", "v_bcnt", "v_ffbl", "v_ffbh", "v_mul_u24", "v_mad_u24", "v_mul_lo_u32", "v_mul_hi_u32", "v_dot4_u8", "v_dot8_u4", "v_sad_u8", "v_lshlrev", "v_cndmask", "v_cmp_cnd", "v_cmp_sgpr_cnd", "v_mov_dpp", "v_add_dpp", "v_and_sdwa", "v_mbcnt_lo", "v_readlane_add", "ds_bpermute", "ds_swizzle", "s_nop0", "v_mad_u64_u32", "v_lshrrev_b64", "v_lshl_add_u64"};
+static const int kPerBlock[] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 3, 1, 1, 1, 1, 1, 1};
 
 template <int OP>
 __global__ __launch_bounds__(256) void k_rate(uint32_t *out, unsigned long long *cycles, uint32_t seed)
@@ -134,6 +158,18 @@ __global__ __launch_bounds__(256) void k_rate(uint32_t *out, unsigned long long 
         switch (OP) {
             RUN32(v_add_u32)
             RUN32(v_and_b32)
+            RUN32(v_or_b32)
+            RUN32(v_xor_b32)
+            RUN32(v_sub_u32)
+            RUN32(v_not_b32)
+            RUN32(v_mov_b32)
+            RUN32(v_lshrrev)
+            RUN32(v_min_u32)
+            RUN32(v_max_u32)
+            RUN32(v_and_const)
+            RUN32(v_add_const)
+            RUN32(v_and_sgpr)
+            RUN32(v_cmp_only)
             RUN32(v_bitop3)
             RUN32(v_or3)
             RUN32(v_and_or)
