@@ -157,6 +157,7 @@ class _HipBoardEngine:
         self._agent = block[self._AGENT:self._AGENT + 1]
         self._fields = {k: self._record[o:o + size] for k, (o, size) in nat.REC_FIELDS.items()}
         self._stream = torch.cuda.current_stream(self.device)
+        self._index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
     def __del__(self):
         try:
@@ -169,12 +170,20 @@ class _HipBoardEngine:
         action) when a move is given -- as numpy arrays (copies)."""
         self._state[:] = squares
         base = self._dev
-        if action is None:
-            rc = self._lib.gbl_board_eval(base + self._STATE, None, None, base, 1, self._stream.cuda_stream)
-        else:
-            self._action[0], self._agent[0] = action, agent_index
-            rc = self._lib.gbl_board_eval(base + self._STATE, base + self._AGENT, base + self._ACTION, base, 1,
-                                          self._stream.cuda_stream)
+        other = torch.cuda.current_device() != self._index  # (a launch goes to the CURRENT device)
+        if other:
+            prev = torch.cuda.current_device()
+            torch.cuda.set_device(self._index)
+        try:
+            if action is None:
+                rc = self._lib.gbl_board_eval(base + self._STATE, None, None, base, 1, self._stream.cuda_stream)
+            else:
+                self._action[0], self._agent[0] = action, agent_index
+                rc = self._lib.gbl_board_eval(base + self._STATE, base + self._AGENT, base + self._ACTION, base, 1,
+                                              self._stream.cuda_stream)
+        finally:
+            if other:
+                torch.cuda.set_device(prev)
         nat.check(rc, "gbl_board_eval")
         self._stream.synchronize()
         return {k: v.copy() for k, v in self._fields.items()}

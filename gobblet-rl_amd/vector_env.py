@@ -262,6 +262,10 @@ class BatchedGobblet:
         if out["_plies"] != T:
             raise ValueError("trajectory buffers were made for %d plies" % out["_plies"])
         f, n = out["_full"], self.num_envs
+        cells = f["actions"].numel()  # (every array of the set has the same number of (ply, board) cells)
+        need = (T - 1) * out["_ply_stride"] + (-(-n // 64) - 1) * out["_tile_stride"] + 64
+        if f["actions"].device != self.device or cells < need - 64 + (n - 1) % 64 + 1 or ("observation" in f) != (self.observation is not None):
+            raise ValueError("trajectory buffers do not fit this environment (made by another one?)")
         nat.check(self._lib.gbl_collect(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
                                         f["actions"].data_ptr(), f["winner"].data_ptr(), f["rewards"].data_ptr(),
                                         f["done"].data_ptr(), f["to_move"].data_ptr(), f["action_mask"].data_ptr(),
