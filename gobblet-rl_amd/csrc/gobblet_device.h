@@ -61,16 +61,26 @@ __device__ __forceinline__ int64_t xcd_tile(uint32_t bid, int64_t ntiles)
 // Full tiles move as 16-byte vectors, lane l handling vectors l, l+64, ... : every wave
 // instruction covers 1 KiB of contiguous HBM.  All loads of a tile are issued before the first
 // dependent LDS write (and all LDS reads before the first store) so they overlap.
-// NT = non-temporal hint on the stores (write-once streams).  It is a TEMPLATE parameter on purpose:
+// NT = store policy (kStorePlain / kStoreStream / kStoreStreamDrop, see store16).  It is a TEMPLATE parameter on purpose:
 // as a runtime flag the `if (nt) nontemporal-store else store` pair is merged by the optimiser into
 // one plain store and the hint is silently lost.
 typedef uint32_t __attribute__((ext_vector_type(4))) vec4u;
 
-template <bool NT>
+// Store policies of a tile's 16-byte vectors.  kStoreStream = non-temporal hint (`nt`).  kStoreStreamDrop = `nt sc1`:
+// the same, and the line does not stay in the XCD's L2 -- for write-once streams and outputs nothing on the GPU reads
+// back (2-4 % over `nt` on the trajectory stream, 0.5-2 % on the one-ply kernels' observation stream, in-process A/B
+// scripts/ab_inproc.py; `sc1`, `sc0 sc1`, `sc0` without `nt`: 22 % slower at 2^20 boards).  There is no builtin for that
+// combination on a global store; the raw BUFFER store builtin takes the cache-policy bits (gfx940 encoding: nt = 2,
+// sc1 = 16), so the tile is addressed through a buffer descriptor of exactly its size.  (An inline-assembly store was
+// tried first and is WRONG: the compiler does not know it reads its data registers and overwrites them too early.)
+constexpr int kStorePlain = 0, kStoreStream = 1, kStoreStreamDrop = 2;
+
+template <int POLICY>
 __device__ __forceinline__ void store16(uint4 *dst, const uint4 &v)
 {
+    static_assert(POLICY == kStorePlain || POLICY == kStoreStream, "kStoreStreamDrop goes through a buffer descriptor (tile_out)");
 #ifndef GBL_HOST_EMU
-    if (NT) {
+    if (POLICY == kStoreStream) {
         vec4u t = {v.x, v.y, v.z, v.w};
         __builtin_nontemporal_store(t, reinterpret_cast<vec4u *>(dst));
         return;
@@ -139,7 +149,7 @@ __device__ __forceinline__ void tile_in(const int8_t *__restrict__ g, uint32_t *
     }
 }
 
-template <int ROWB, bool NT = false>
+template <int ROWB, int NT = kStorePlain>
 __device__ __forceinline__ void tile_out(int8_t *__restrict__ g, const uint32_t *lds, int lane, int rows)
 {
     constexpr int NV = kTile * ROWB / 16, FULL = NV / 64, REM = NV % 64;
@@ -153,9 +163,26 @@ __device__ __forceinline__ void tile_out(int8_t *__restrict__ g, const uint32_t 
 #pragma unroll
         for (int i = 0; i < FULL; ++i) v[i] = lv[lane + 64 * i];
         if (REM && lane < REM) v[FULL] = lv[lane + 64 * FULL];
+#ifndef GBL_HOST_EMU
+        if constexpr (NT == kStoreStreamDrop) {
+            // raw buffer stores with cache policy nt | sc1 (see store16); the descriptor covers exactly this tile
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g, 0, kTile * ROWB, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < FULL; ++i) store16<NT>(&gv[lane + 64 * i], v[i]);
-        if (REM && lane < REM) store16<NT>(&gv[lane + 64 * FULL], v[FULL]);
+            for (int i = 0; i < FULL; ++i) {
+                vec4u t = {v[i].x, v[i].y, v[i].z, v[i].w};
+                __builtin_amdgcn_raw_buffer_store_b128(t, rs, (lane + 64 * i) * 16, 0, 2 | 16);
+            }
+            if (REM && lane < REM) {
+                vec4u t = {v[FULL].x, v[FULL].y, v[FULL].z, v[FULL].w};
+                __builtin_amdgcn_raw_buffer_store_b128(t, rs, (lane + 64 * FULL) * 16, 0, 2 | 16);
+            }
+            return;
+        }
+#endif
+        constexpr int P = NT == kStoreStreamDrop ? kStoreStream : NT;  // (host emulation: a plain copy either way)
+#pragma unroll
+        for (int i = 0; i < FULL; ++i) store16<P>(&gv[lane + 64 * i], v[i]);
+        if (REM && lane < REM) store16<P>(&gv[lane + 64 * FULL], v[FULL]);
     } else {
         int bytes = rows * ROWB;
         const int8_t *lb = reinterpret_cast<const int8_t *>(lds);

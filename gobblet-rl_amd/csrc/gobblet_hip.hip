@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64) void k_observe(const int8_t *__restrict__ state
     wave_lds_fence();
     obs_scatter(s_obs, L.lane, planes_of(L, r), who != 0);
     wave_lds_fence();
-    tile_out<kObs, true>(obs + L.tile * (kTile * kObs), s_obs, L.lane, L.rows);
+    tile_out<kObs, kStoreStreamDrop>(obs + L.tile * (kTile * kObs), s_obs, L.lane, L.rows);
 }
 
 // gbl_board_eval: optional Board.play_turn, then one record per board with everything the reference derives
@@ -337,7 +337,7 @@ static_assert(image_words<kObs>() % 4 == 0 && image_words<kActions>() % 4 == 0 &
 // (2^22 boards: 169 -> 141 us) and loses ~2 % below that; the state rows are re-read next ply and stay
 // cached.  The host picks the variant from the batch size (nt_policy()).
 // the tile's observation rows (raw_env.observe of `observer`) through the image `img`; obs_tile: the tile's first row
-template <bool NT>
+template <int NT>
 __device__ __forceinline__ void store_obs(uint32_t *img, const Lane &L, const Planes &p, int observer,
                                           int8_t *__restrict__ obs_tile)
 {
@@ -350,7 +350,7 @@ __device__ __forceinline__ void store_obs(uint32_t *img, const Lane &L, const Pl
 }
 
 // the tile's mask rows from 54-bit sets; mask_tile: the tile's first row
-template <bool NT>
+template <int NT>
 __device__ __forceinline__ void store_mask(uint32_t *img, const Lane &L, uint64_t legal, int8_t *__restrict__ mask_tile)
 {
     uint32_t d[14];
@@ -367,13 +367,14 @@ __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, bool ma
                                            int8_t *__restrict__ obs_out)
 {
     wave_lds_fence();  // every lane's byte patches are in the image
-    tile_out<kCells, (NT & 4) != 0>(state + L.tile * (kTile * kCells), img, L.lane, L.rows);
+    tile_out<kCells, (NT & 4) ? kStoreStream : kStorePlain>(state + L.tile * (kTile * kCells), img, L.lane, L.rows);
     wave_lds_fence();
-    if (WITH_OBS) store_obs<(NT & 1) != 0>(img, L, p, observer, obs_out + L.tile * (kTile * kObs));
+    if (WITH_OBS) store_obs<(NT & 1) ? kStoreStreamDrop : kStorePlain>(img, L, p, observer, obs_out + L.tile * (kTile * kObs));
     // the next mover's legal mask is computed only now, behind the state and observation stores: the
     // sooner a wave's first stores are in flight, the shorter the launch's ramp-up
     if (WITH_MASK)
-        store_mask<(NT & 2) != 0>(img, L, mask_zero ? 0ull : legal54(p, observer), mask_out + L.tile * (kTile * kActions));
+        store_mask<(NT & 2) ? kStoreStreamDrop : kStorePlain>(img, L, mask_zero ? 0ull : legal54(p, observer),
+                                                         mask_out + L.tile * (kTile * kActions));
 }
 
 // (GBL_STAMP* : per-wavefront phase stamps of the diagnostic build, gobblet_diag.h; they expand to nothing here)
@@ -581,9 +582,10 @@ __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__r
             if (done_t) done_t[at] = (int8_t)dn;
             if (to_move_t) to_move_t[at] = (int8_t)mover;
         }
-        if (WITH_OBS) store_obs<NT>(s_out, L, p, mover, obs_t + cell * kObs);
+        constexpr int kPolicy = NT ? kStoreStreamDrop : kStorePlain;
+        if (WITH_OBS) store_obs<kPolicy>(s_out, L, p, mover, obs_t + cell * kObs);
         legal = legal54(p, mover);  // the next mover's: stored now, sampled from next ply
-        if (WITH_MASK) store_mask<NT>(s_out, L, legal, mask_t + cell * kActions);
+        if (WITH_MASK) store_mask<kPolicy>(s_out, L, legal, mask_t + cell * kActions);
     }
     wave_lds_fence();  // every lane's byte patches are in the state image
     tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);

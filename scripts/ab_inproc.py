@@ -4,7 +4,8 @@ dlopen'ed side by side and launched on the SAME buffers in turn (A B C A B C ...
 box are the same for all of them -- the run-to-run scatter of the trajectory stream is larger than
 most kernel variants' effect.
 
-    python scripts/ab_inproc.py BOARDS T STREAMS lib1.so lib2.so ...      STREAMS: all | rows | obs | mask"""
+    python scripts/ab_inproc.py BOARDS T STREAMS lib1.so lib2.so ...      STREAMS: all | rows | obs | mask | ply | plymask
+(ply / plymask: the one-ply pipeline instead, gbl_rollout_at with plies = 1, FULL / MASK_ONLY outputs; T is ignored)"""
 import ctypes as C
 import os
 import statistics
@@ -21,7 +22,7 @@ nat = G._native
 libs = []
 for p in paths:
     L = C.CDLL(os.path.abspath(p))
-    for name in ("gbl_collect", "gbl_counter_add"):
+    for name in ("gbl_collect", "gbl_counter_add", "gbl_rollout_at"):
         res, args = nat.SIGNATURES[name]
         getattr(L, name).restype, getattr(L, name).argtypes = res, args
     libs.append(L)
@@ -29,7 +30,11 @@ env = G.BatchedGobblet(n, "cuda:0", auto_reset=True, seed=0)
 env.rollout(64)
 buf = env.trajectory_buffers(T)
 f = buf["_full"]
-keys = {"all": tuple(f), "rows": ("action_mask", "observation"), "obs": ("observation",), "mask": ("action_mask",)}[streams]
+one_ply = streams in ("ply", "plymask")
+if one_ply:
+    T = 1
+keys = {"all": tuple(f), "rows": ("action_mask", "observation"), "obs": ("observation",), "mask": ("action_mask",),
+        "ply": (), "plymask": ()}[streams]
 P = {k: (v.data_ptr() if k in keys else None) for k, v in f.items()}
 ctr = torch.zeros(1, dtype=torch.int32, device="cuda:0")
 launches = max(2, 256 // T)
@@ -39,6 +44,13 @@ for L in libs:
     with torch.cuda.graph(g):
         s = nat.current_stream(torch.device("cuda:0"))
         for i in range(launches):
+            if one_ply:
+                rc = L.gbl_rollout_at(env.squares.data_ptr(), env.to_move.data_ptr(), env.done.data_ptr(), env.actions.data_ptr(),
+                                      env.winner.data_ptr(), env.rewards.data_ptr(), env.action_mask.data_ptr(),
+                                      env.observation.data_ptr() if streams == "ply" else None, n, 0, 0, i, ctr.data_ptr(), 1, 0,
+                                      None, None, s)
+                assert rc == 0
+                continue
             rc = L.gbl_collect(env.squares.data_ptr(), env.to_move.data_ptr(), env.done.data_ptr(), P["actions"], P["winner"],
                                P["rewards"], P["done"], P["to_move"], P["action_mask"], P["observation"], n, buf["_ply_stride"],
                                buf["_tile_stride"], 0, 0, i * T, ctr.data_ptr(), T, 0, None, None, s)
