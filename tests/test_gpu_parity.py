@@ -966,9 +966,13 @@ def test_bench_script_two_ranks_rehearsal(G):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import socket
+    with socket.socket() as sock:  # a free port for the rendezvous
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
            "--boards", "32768", "--dist-backend", "gloo", "--share-device"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
