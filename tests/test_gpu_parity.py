@@ -982,3 +982,21 @@ def test_bench_script_two_ranks_rehearsal(G):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_boards"] == 32768
     assert d["config"]["boards_per_gpu"] == 16384 and len(d["config"]["kernel_us_per_rank"]) == 2
     assert "configs" not in d and "cpu_baseline" not in d  # N = 1 only
+
+
+def test_collect_beyond_4gib(G):
+    """A trajectory whose observation array exceeds 2^32 bytes (2^20 boards x 40 plies x 117 B = 4.9 GB): slot
+    offsets must be 64-bit and the buffer descriptors of the streaming stores must reach every tile.  The first, a
+    middle and the last slot against the ply-by-ply pipeline, whole tensors."""
+    n, T, seed = 1 << 20, 40, 13
+    a = G.BatchedGobblet(n, DEV, auto_reset=True, seed=seed)
+    b = G.BatchedGobblet(n, DEV, auto_reset=True, seed=seed)
+    tr = a.collect(T, refresh=False)
+    assert tr["observation"].numel() > (1 << 32)
+    for t_ in range(T):
+        b.rollout(1)
+        if t_ in (0, 17, T - 1):
+            assert torch.equal(tr["observation"][t_], b.observation) and torch.equal(tr["action_mask"][t_], b.action_mask), t_
+            assert torch.equal(tr["actions"][t_], b.actions) and torch.equal(tr["done"][t_], b.done), t_
+    assert torch.equal(a.squares, b.squares) and torch.equal(a.to_move, b.to_move)
+    del tr
