@@ -56,6 +56,25 @@ while time.time() < t_end:
         assert np.array_equal(rew.cpu().numpy(), oo["reward"])
         if with_obs:
             assert np.array_equal(obs["observation"].cpu().numpy(), oo["obs"])
+    # a collected trajectory (gbl_collect, time- or tile-major) and a one-launch board evaluation (gbl_board_eval)
+    if auto:
+        T = int(master.integers(1, 12))
+        lay = str(master.choice(["time", "tile"]))
+        ply = env.ply
+        tr = env.collect(T, layout=lay)
+        torch.cuda.synchronize()
+        for tt in range(T):
+            oo = oracle.batch_rollout(s, tm, dn, seed, base, ply + tt, 1, illegal_mode=0 if illegal == "noop" else 1, threads=8)
+            pick = (lambda k: tr[k][tt]) if lay == "time" else (lambda k: tr[k][:, tt].reshape((-1,) + tuple(tr[k].shape[3:]))[:n])
+            assert np.array_equal(pick("actions").cpu().numpy(), oo["actions"]) and np.array_equal(pick("action_mask").cpu().numpy(), oo["mask"])
+            assert np.array_equal(pick("winner").cpu().numpy(), oo["winner"]) and np.array_equal(pick("to_move").cpu().numpy(), tm)
+            if with_obs:
+                assert np.array_equal(pick("observation").cpu().numpy(), oo["obs"])
+        assert np.array_equal(env.squares.cpu().numpy(), s)
+    ev = G.BatchedBoard(n, DEV, squares=t(s)).evaluate()
+    assert np.array_equal(ev["winner"].cpu().numpy(), oracle.batch_winner(s)) and np.array_equal(ev["flat"].cpu().numpy(), oracle.batch_flatboard(s))
+    assert np.array_equal(ev["mask1"].cpu().numpy(), oracle.batch_legal_mask(s, np.ones(n, np.int8)))
+    assert np.array_equal(ev["obs0"].cpu().numpy(), oracle.batch_observe(s, np.zeros(n, np.int8), 0))
     # board API + greedy on the current states
     b = G.BatchedBoard(n, DEV, squares=t(s))
     assert np.array_equal(b.check_for_winner().cpu().numpy(), oracle.batch_winner(s))
