@@ -31,6 +31,11 @@ constexpr int kIters = 512, kChains = 8;
 #define I_v_add_const(A) "v_add_u32 " A ", 0x7f7f7f7f, " A "\n"
 #define I_v_and_sgpr(A) "v_and_b32 " A ", s20, " A "\n"
 #define I_v_cmp_only(A) "v_cmp_lt_u32 vcc, " A ", %[x]\n"
+#define I_s_and_b32(A) "s_and_b32 s20, s20, s21\n"
+#define I_s_add_u32(A) "s_add_u32 s20, s20, s21\n"
+#define I_s_mul_i32(A) "s_mul_i32 s20, s20, s21\n"
+#define I_s_bcnt1_b64(A) "s_bcnt1_i32_b64 s20, s[20:21]\n"
+#define I_valu_salu_mix(A) "v_and_or_b32 " A ", " A ", %[x], %[y]\n s_and_b32 s20, s20, s21\n"
 #define I_v_bitop3(A) "v_bitop3_b32 " A ", " A ", %[x], %[y] bitop3:0x96\n"
 #define I_v_or3(A) "v_or3_b32 " A ", " A ", %[x], %[y]\n"
 #define I_v_and_or(A) "v_and_or_b32 " A ", " A ", %[x], %[y]\n"
@@ -83,6 +88,11 @@ enum Op {
     OP_v_add_const,
     OP_v_and_sgpr,
     OP_v_cmp_only,
+    OP_s_and_b32,
+    OP_s_add_u32,
+    OP_s_mul_i32,
+    OP_s_bcnt1_b64,
+    OP_valu_salu_mix,
     OP_v_bitop3,
     OP_v_or3,
     OP_v_and_or,
@@ -121,8 +131,8 @@ enum Op {
     OP_v_lshl_add_u64,
     OP_COUNT
 };
-static const char *kNames[] = {"v_add_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_sub_u32", "v_not_b32", "v_mov_b32", "v_lshrrev", "v_min_u32", "v_max_u32", "v_and_const", "v_add_const", "v_and_sgpr", "v_cmp_only", "v_bitop3", "v_or3", "v_and_or", "v_lshl_or", "v_lshl_add", "v_add3", "v_bfe_u32", "v_bfi", "v_alignbyte", "v_alignbit", "v_perm", "v_bcnt", "v_ffbl", "v_ffbh", "v_mul_u24", "v_mad_u24", "v_mul_lo_u32", "v_mul_hi_u32", "v_dot4_u8", "v_dot8_u4", "v_sad_u8", "v_lshlrev", "v_cndmask", "v_cmp_cnd", "v_cmp_sgpr_cnd", "v_mov_dpp", "v_add_dpp", "v_and_sdwa", "v_mbcnt_lo", "v_readlane_add", "ds_bpermute", "ds_swizzle", "s_nop0", "v_mad_u64_u32", "v_lshrrev_b64", "v_lshl_add_u64"};
-static const int kPerBlock[] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 3, 1, 1, 1, 1, 1, 1};
+static const char *kNames[] = {"v_add_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_sub_u32", "v_not_b32", "v_mov_b32", "v_lshrrev", "v_min_u32", "v_max_u32", "v_and_const", "v_add_const", "v_and_sgpr", "v_cmp_only", "s_and_b32", "s_add_u32", "s_mul_i32", "s_bcnt1_b64", "valu_salu_mix", "v_bitop3", "v_or3", "v_and_or", "v_lshl_or", "v_lshl_add", "v_add3", "v_bfe_u32", "v_bfi", "v_alignbyte", "v_alignbit", "v_perm", "v_bcnt", "v_ffbl", "v_ffbh", "v_mul_u24", "v_mad_u24", "v_mul_lo_u32", "v_mul_hi_u32", "v_dot4_u8", "v_dot8_u4", "v_sad_u8", "v_lshlrev", "v_cndmask", "v_cmp_cnd", "v_cmp_sgpr_cnd", "v_mov_dpp", "v_add_dpp", "v_and_sdwa", "v_mbcnt_lo", "v_readlane_add", "ds_bpermute", "ds_swizzle", "s_nop0", "v_mad_u64_u32", "v_lshrrev_b64", "v_lshl_add_u64"};
+static const int kPerBlock[] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 3, 1, 1, 1, 1, 1, 1};
 
 template <int OP>
 __global__ __launch_bounds__(256) void k_rate(uint32_t *out, unsigned long long *cycles, uint32_t seed)
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(256) void k_rate(uint32_t *out, unsigned long long 
         asm volatile(BLOCK8(I_##n) WAIT                                                         \
                      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) \
                      : [x] "v"(x), [y] "v"(y)                                                                       \
-                     : "vcc", "s20", "s21");                                                                        \
+                     : "vcc", "scc", "s20", "s21");                                                                        \
         break;
 #define RUN64(n)                                                                                                    \
     case OP_##n:                                                                                                    \
@@ -170,6 +180,11 @@ __global__ __launch_bounds__(256) void k_rate(uint32_t *out, unsigned long long 
             RUN32(v_add_const)
             RUN32(v_and_sgpr)
             RUN32(v_cmp_only)
+            RUN32(s_and_b32)
+            RUN32(s_add_u32)
+            RUN32(s_mul_i32)
+            RUN32(s_bcnt1_b64)
+            RUN32(valu_salu_mix)
             RUN32(v_bitop3)
             RUN32(v_or3)
             RUN32(v_and_or)
@@ -263,6 +278,7 @@ int main()
             res[v] = (double)s[s.size() / 2] / (kIters * kChains * kPerBlock[op]);
         }
         printf("%-20s %12.2f %12.2f %12.2f %12.2f\n", kNames[op], res[0], res[1], res[2], res[2] / 4);
+        fflush(stdout);
     }
     return 0;
 }
