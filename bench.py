@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--mode", choices=["collect", "fused", "step"], default="collect")
     ap.add_argument("--traj", type=int, default=0,
                     help="plies per launch in mode collect; 0 = by shard size (8 from 2^19 boards per GPU, 16 from 2^18, "
-                         "else 32: small shards amortise the launch over more plies), never more than half of --steps")
+                         "else 32: small shards amortise the launch over more plies), never more than --steps")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the K timed plies as one hipGraph; 0: eager launches")
     ap.add_argument("--no-obs", action="store_true",
                     help="MASK_ONLY variant (BASELINE.md: 117 algorithmic bytes per env-step): no observation tensor")
@@ -128,9 +128,13 @@ def cpu_baseline(boards, warmup, target_s):
 
 
 def auto_traj(boards, steps, requested=0):
-    """Plies per gbl_collect launch: the requested value, or by shard size; at least two launches per timed run."""
+    """Plies per gbl_collect launch: the requested value, or by shard size (large shards: shorter launches, so that a
+    launch's tail -- its last generation of wavefronts draining -- stays small; they never get more than half of a
+    timed run); never more than the timed run."""
     t = requested if requested > 0 else (8 if boards >= (1 << 19) else 16 if boards >= (1 << 18) else 32)
-    return max(1, min(t, max(1, steps // 2)))
+    if boards >= (1 << 19):
+        t = min(t, max(1, steps // 2))
+    return max(1, min(t, steps))
 
 
 def kernel_source_hash():
