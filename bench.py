@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--graph", type=int, default=1, help="1: replay the K timed plies as one hipGraph; 0: eager launches")
     ap.add_argument("--no-obs", action="store_true",
                     help="MASK_ONLY variant (BASELINE.md: 117 algorithmic bytes per env-step): no observation tensor")
+    ap.add_argument("--placement", choices=["auto", "spread", "any"], default="auto",
+                    help="placement of the trajectory arrays (BatchedGobblet.trajectory_buffers): auto = observation and "
+                         "mask arrays in different 96 GiB classes of HBM, found with a probe; any = as the allocator hands them out")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the sub-records of the other BASELINE configs")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -164,7 +167,7 @@ def committed_counter(key, field):
 class Pipeline:
     """One shard of boards and its launch sequence, with the ply index in device memory."""
 
-    def __init__(self, G, torch, boards, env_base, dev, no_obs=False, mode="collect", traj=32):
+    def __init__(self, G, torch, boards, env_base, dev, no_obs=False, mode="collect", traj=32, placement="auto"):
         self.G, self.torch, self.nat, self.lib = G, torch, G._native, G._native.lib()
         self.boards, self.dev, self.mode, self.no_obs, self.T = boards, dev, mode, no_obs, max(1, int(traj))
         env = self.env = G.BatchedGobblet(boards, dev, illegal_mode="noop", auto_reset=True, seed=0, env_base=env_base,
@@ -175,7 +178,7 @@ class Pipeline:
         self.ctr = torch.zeros(1, dtype=torch.int32, device=dev)  # plies played so far (keys the sampler)
         self.traj = None
         if mode == "collect":
-            self.traj = env.trajectory_buffers(self.T)
+            self.traj = env.trajectory_buffers(self.T, placement=placement)
             f = self.traj["_full"]
             self.TP = dict(ac=f["actions"].data_ptr(), wi=f["winner"].data_ptr(), rw=f["rewards"].data_ptr(),
                            dn=f["done"].data_ptr(), tm=f["to_move"].data_ptr(), mk=f["action_mask"].data_ptr(),
@@ -259,9 +262,9 @@ class Pipeline:
                 "mean_launch_us": kernel_s / launches * 1e6, "launches_timed": launches, "timing": timing}
 
 
-def short_run(G, torch, dev, boards, K, W, no_obs=False, mode="collect", traj=32):
+def short_run(G, torch, dev, boards, K, W, no_obs=False, mode="collect", traj=32, placement="auto"):
     """A sub-record: W warm-up plies, K plies as a hipGraph replayed once untimed, then timed between HIP events."""
-    p = Pipeline(G, torch, boards, 0, dev, no_obs=no_obs, mode=mode, traj=traj)
+    p = Pipeline(G, torch, boards, 0, dev, no_obs=no_obs, mode=mode, traj=traj, placement=placement)
     p.eager(W)
     g = p.capture(K)
     g.replay()
@@ -279,6 +282,8 @@ def short_run(G, torch, dev, boards, K, W, no_obs=False, mode="collect", traj=32
            "value": boards * K / s, "unit": "env-steps/s", "us_per_step": s / K * 1e6,
            "roofline": p.kernel_roofline(s, K, launches,
                                          "HIP events around the graph replay (includes kernel boundaries)")}
+    if p.traj is not None:
+        rec["trajectory_placement"] = p.traj["_placement"]
     del g, p
     return rec
 
@@ -356,7 +361,8 @@ def main():
         total = args.boards
     K, W = args.steps, args.warmup
     args.traj = auto_traj(boards, K, args.traj)
-    p = Pipeline(G, torch, boards, env_base, dev, no_obs=args.no_obs, mode=args.mode, traj=args.traj)
+    p = Pipeline(G, torch, boards, env_base, dev, no_obs=args.no_obs, mode=args.mode, traj=args.traj,
+                 placement=args.placement)
     nlaunch = len(p.plan(K))
     p.eager(W)  # warm-up plies (untimed): decorrelate game phases, warm caches / code objects
     torch.cuda.synchronize(dev)
@@ -444,7 +450,10 @@ def main():
                        "sharding": f"contiguous board ranges, {world} shard(s), no collective on the step path",
                        "launch": ("hipGraph replay of the K plies' launches (device-resident ply index; one untimed warm "
                                   "replay of the same graph = K more untimed plies before the timed one)") if graph is not None else "eager",
-                       "kernel_us_per_rank": per_rank_us, "kernel_us_max": max(per_rank_us)},
+                       "kernel_us_per_rank": per_rank_us, "kernel_us_max": max(per_rank_us),
+                       # where the observation / mask trajectory arrays lie (gobblet-rl_amd/placement.py): probe ratios
+                       # both / (obs alone + mask alone), ~1.0 = same 96 GiB class of HBM, ~0.8 = different classes
+                       "trajectory_placement": p.traj["_placement"] if p.traj is not None else None},
             "roofline": roof,
         }
         if world == 1 and not args.no_configs:
@@ -458,7 +467,8 @@ def main():
                     ("single_ply_131072", 131072, 200, False, "fused"), ("single_ply_4096", 4096, 200, False, "fused"),
                     ("single_ply_maskonly_1048576", 1 << 20, 200, True, "fused"),
                     ("single_ply_large_4194304", 1 << 22, 40, False, "fused")):
-                cfg[name] = short_run(G, torch, dev, n, k, W, no_obs=noobs, mode=mode, traj=auto_traj(n, k))
+                cfg[name] = short_run(G, torch, dev, n, k, W, no_obs=noobs, mode=mode, traj=auto_traj(n, k),
+                                      placement=args.placement)
             cfg["c5_greedy_65536"] = greedy_run(G, torch, dev)
             out["configs"] = cfg
         if world == 1 and not args.no_cpu_baseline:

@@ -3,6 +3,7 @@
 #include "gobblet_device.h"
 
 #include <stdio.h>
+#include <algorithm>
 #include <stdlib.h>
 #include <string.h>
 
@@ -607,6 +608,25 @@ __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__r
     GBL_STAMP_FLUSH(L.tile);
 }
 
+// gbl_placement_probe: the write pattern of k_collect without the game -- tile i of `plies` slots stores 64 rows of
+// 117 bytes into a and 64 rows of 54 bytes into b (zeros, `nt sc1` like the trajectory stream), one wavefront per
+// tile, identity tile map.  Timed with both streams, with a alone and with b alone (see the header).
+template <bool WITH_A, bool WITH_B>
+__global__ __launch_bounds__(64) void k_probe(int8_t *__restrict__ a, int8_t *__restrict__ b, int64_t ntiles, int plies)
+{
+    __shared__ uint32_t s_img[image_words<kObs>()];
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    obs_image_zero(s_img, lane);
+    wave_lds_fence();
+    for (int t = 0; t < plies; ++t) {
+        const int64_t cell = ((int64_t)t * ntiles + tile) * kTile;
+        if (WITH_A) tile_out<kObs, kStoreStreamDrop>(a + cell * kObs, s_img, lane, kTile);
+        if (WITH_B) tile_out<kActions, kStoreStreamDrop>(b + cell * kActions, s_img, lane, kTile);
+    }
+}
+
 // gbl_counter_add: the device-resident ply / call counter of the *_at entry points
 __global__ void k_counter_add(uint32_t *ctr, uint32_t by) { *ctr += by; }
 
@@ -1198,6 +1218,56 @@ int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_t
 #undef GBL_COLLECT_K
 #undef GBL_COLLECT_KN
     GBL_LAUNCHED("gbl_collect");
+}
+
+int gbl_placement_probe(void *a, int64_t a_bytes, void *b, int64_t b_bytes, float *us_both, float *us_a, float *us_b,
+                        void *stream)
+{
+    GBL_NEED(a, "a"); GBL_NEED(b, "b"); GBL_NEED(us_both, "us_both"); GBL_NEED(us_a, "us_a"); GBL_NEED(us_b, "us_b");
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 127u)
+        return fail(GBL_ERR_ALIGN, "a and b must be 128-byte aligned");
+    constexpr int kPlies = 4;
+    // an even number of tiles per slot: every slot of both arrays then starts on a 128-byte line
+    const int64_t tiles = std::min(a_bytes / ((int64_t)kPlies * kTile * kObs), b_bytes / ((int64_t)kPlies * kTile * kActions)) & ~(int64_t)1;
+    if (tiles < 2) return fail(GBL_ERR_ARG, "buffers too small to probe (a: 4 x 7488 bytes per tile, b: 4 x 3456)");
+    if (tiles > 0x7fffffff) return fail(GBL_ERR_ARG, "buffers too large to probe in one launch");
+    hipStream_t s = (hipStream_t)stream;
+    int8_t *pa = static_cast<int8_t *>(a), *pb = static_cast<int8_t *>(b);
+    auto launch = [&](int which) {
+        if (which == 0) hipLaunchKernelGGL((k_probe<true, true>), dim3((uint32_t)tiles), dim3(64), 0, s, pa, pb, tiles, kPlies);
+        else if (which == 1) hipLaunchKernelGGL((k_probe<true, false>), dim3((uint32_t)tiles), dim3(64), 0, s, pa, pb, tiles, kPlies);
+        else hipLaunchKernelGGL((k_probe<false, true>), dim3((uint32_t)tiles), dim3(64), 0, s, pa, pb, tiles, kPlies);
+        return hipGetLastError();
+    };
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ev[i]);
+    // a probe often runs on an idle device (the caller has just allocated memory): bring the clocks up first, then
+    // time the three variants back to back, several rounds, and keep each one's best
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = launch(0);
+    float best[3] = {0.f, 0.f, 0.f};
+    constexpr int kRounds = 4;
+    for (int round = 0; round < kRounds && e == hipSuccess; ++round) {
+        e = hipEventRecord(ev[0], s);
+        for (int which = 1; which <= 3 && e == hipSuccess; ++which) {  // a alone, b alone, both
+            e = launch(which % 3);
+            if (e == hipSuccess) e = hipEventRecord(ev[which], s);
+        }
+        if (e == hipSuccess) e = hipEventSynchronize(ev[3]);
+        for (int which = 1; which <= 3 && e == hipSuccess; ++which) {
+            float ms = 0.f;
+            e = hipEventElapsedTime(&ms, ev[which - 1], ev[which]);
+            float &slot = best[which % 3];
+            if (round == 0 || ms < slot) slot = ms;
+        }
+    }
+    for (int i = 0; i < 4; ++i)
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+    if (e != hipSuccess) return hip_fail(e, "gbl_placement_probe");
+    *us_both = best[0] * 1e3f;
+    *us_a = best[1] * 1e3f;
+    *us_b = best[2] * 1e3f;
+    return GBL_OK;
 }
 
 int gbl_decode_obs(const int8_t *obs, int8_t *state, int8_t *to_move, int64_t n, void *stream)

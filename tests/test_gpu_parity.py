@@ -1000,3 +1000,53 @@ def test_collect_beyond_4gib(G):
             assert torch.equal(tr["actions"][t_], b.actions) and torch.equal(tr["done"][t_], b.done), t_
     assert torch.equal(a.squares, b.squares) and torch.equal(a.to_move, b.to_move)
     del tr
+
+
+def test_placement_probe_and_spread_buffers(G):
+    """gbl_placement_probe writes zeros into exactly the bytes it was given and reports three positive times;
+    trajectory_buffers(placement="auto") at a size it probes hands back zero-filled arrays of the usual shapes, records
+    what it did, releases what it only held, and the trajectory collected into them is bit-identical to the one
+    collected into buffers placed as the allocator pleases."""
+    import ctypes as C
+    from gobblet_rl_amd import placement
+    nat, L = G._native, G._native.lib()
+    guard, na, nb = 4096, 96 << 20, 48 << 20
+    a = torch.full((na + 2 * guard,), 7, dtype=torch.uint8, device=DEV)
+    b = torch.full((nb + 2 * guard,), 9, dtype=torch.uint8, device=DEV)
+    both, ua, ub = C.c_float(), C.c_float(), C.c_float()
+    nat.check(L.gbl_placement_probe(a.data_ptr() + guard, na, b.data_ptr() + guard, nb, C.byref(both), C.byref(ua), C.byref(ub),
+                                    nat.current_stream(torch.device(DEV))))
+    torch.cuda.synchronize()
+    assert both.value > 0 and ua.value > 0 and ub.value > 0 and both.value < 2 * (ua.value + ub.value)
+    assert int(a[:guard].min()) == 7 and int(a[-guard:].min()) == 7 and int(b[:guard].min()) == 9 and int(b[-guard:].min()) == 9
+    tiles = min(na // (4 * 7488), nb // (4 * 3456)) & ~1      # what the probe covers: 4 slots of `tiles` tiles
+    assert int(a[guard:guard + 4 * tiles * 7488].max()) == 0 and int(b[guard:guard + 4 * tiles * 3456].max()) == 0
+    assert int(a[guard + 4 * tiles * 7488:guard + na].min()) == 7 and int(b[guard + 4 * tiles * 3456:guard + nb].min()) == 9
+    rc = L.gbl_placement_probe(a.data_ptr() + 64, na, b.data_ptr(), nb, C.byref(both), C.byref(ua), C.byref(ub), None)
+    assert rc == nat.ERR_ALIGN
+    rc = L.gbl_placement_probe(a.data_ptr(), 1000, b.data_ptr(), nb, C.byref(both), C.byref(ua), C.byref(ub), None)
+    assert rc == nat.ERR_ARG
+    del a, b
+
+    n, T, seed = 65536, 24, 5     # mask trajectory 81 MiB: large enough to be probed
+    kw = dict(auto_reset=True, seed=seed)
+    e1, e2 = G.BatchedGobblet(n, DEV, **kw), G.BatchedGobblet(n, DEV, **kw)
+    free0, _ = torch.cuda.mem_get_info()
+    spread = e1.trajectory_buffers(T)  # placement="auto"
+    info = spread["_placement"]
+    assert set(info) >= {"spread", "ratio", "probes", "skipped_gib", "seconds"} and 1 <= len(info["probes"]) <= placement.MAX_PROBES
+    assert 0.5 < info["ratio"] < 1.2 and info["skipped_gib"] * placement.GIB <= placement.MAX_SKIP_BYTES
+    assert spread["observation"].shape == (T, n, 3, 3, 13) and spread["action_mask"].shape == (T, n, 54)
+    assert int(spread["_full"]["observation"].abs().max()) == 0 and int(spread["_full"]["action_mask"].abs().max()) == 0
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 2 * placement.GIB          # spacers and rejected candidates went back to the driver
+    plain = e2.trajectory_buffers(T, placement="any")
+    assert plain["_placement"]["spread"] is False
+    e1.collect(T, out=spread); e2.collect(T, out=plain)
+    for key in ("actions", "winner", "rewards", "done", "to_move", "action_mask", "observation"):
+        assert torch.equal(spread[key], plain[key]), key
+    assert torch.equal(e1.squares, e2.squares)
+    with pytest.raises(ValueError):
+        G.BatchedGobblet(64, DEV, auto_reset=True).trajectory_buffers(4, placement="spread")  # too small to probe
+    small = G.BatchedGobblet(64, DEV, auto_reset=True).trajectory_buffers(4)
+    assert small["_placement"]["spread"] is False and "too small" in small["_placement"]["why"]
