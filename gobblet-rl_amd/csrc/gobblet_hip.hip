@@ -1291,14 +1291,18 @@ int gbl_validate(const int8_t *state, int8_t *flags, int64_t n, void *stream)
 }
 
 namespace {
-// Wavefronts per tile.  Measured on depth 2 (scripts/bench_greedy.py, 65 536 / 262 144 / 2^20 boards):
+// Wavefronts per tile (depth 2).  Round 1 (scripts/bench_greedy.py, 65 536 / 262 144 / 2^20 boards):
 // 1: 49 / 155 / 518 us, 2: 43 / 139 / 487, 4: 41 / 121 / 451, 8: 40 / 136 / 520, 16: 50 / 176 / 679.
-int greedy_waves(int depth)
+// Round 2 (scripts/ab_greedy.py, in-process): 8 wavefronts shorten a lone tile's serial chain -- 4 096 / 16 384 boards
+// 11.2 / 11.4 -> 10.0 / 10.2 us -- are level at 65 536 - 131 072 boards (18.1 us both) and lose 2-4 % beyond, where
+// the CUs' issue rate decides: small batches take 8, the others 4.
+int greedy_waves(int depth, int64_t n)
 {
-#ifdef GBL_FORCE_GREEDY_WAVES  // 1, 2 or 4: A/B builds (scripts/build_variant.sh)
+#ifdef GBL_FORCE_GREEDY_WAVES  // 1, 2, 4 or 8: A/B builds (scripts/build_variant.sh)
+    (void)depth; (void)n;
     return GBL_FORCE_GREEDY_WAVES;
 #else
-    return depth == 1 ? 1 : 4;
+    return depth == 1 ? 1 : n <= 32768 ? 8 : 4;
 #endif
 }
 
@@ -1311,7 +1315,8 @@ void launch_greedy(int waves, const Geometry &g, hipStream_t stream, const int8_
     hipLaunchKernelGGL(k_greedy<W>, dim3(g.grid), dim3(64 * W), 0, stream, state, to_move, mask, hist, depth,      \
                        action_out, cand_mask_out, fallback_out, n, g.ntiles, hist_rw, final_out, seed, env_base, \
                        call, call_dev)
-    if (waves >= 4) GBL_GREEDY(4);
+    if (waves >= 8) GBL_GREEDY(8);
+    else if (waves >= 4) GBL_GREEDY(4);
     else if (waves == 2) GBL_GREEDY(2);
     else GBL_GREEDY(1);
 #undef GBL_GREEDY
@@ -1326,7 +1331,7 @@ int gbl_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask, c
     if (depth < 1 || depth > 3) return fail(GBL_ERR_ARG, "depth must be 1, 2 or 3");
     GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask, "mask"); GBL_ALIGNED(cand_mask_out, "cand_mask_out");
     if (hist && (reinterpret_cast<uintptr_t>(hist) & 1u)) return fail(GBL_ERR_ALIGN, "hist must be 2-byte aligned");
-    launch_greedy(greedy_waves(depth), geometry(n), (hipStream_t)stream, state, to_move, mask, hist, depth, action_out,
+    launch_greedy(greedy_waves(depth, n), geometry(n), (hipStream_t)stream, state, to_move, mask, hist, depth, action_out,
                   cand_mask_out, fallback_out, n, nullptr, nullptr, 0, 0, 0);
     GBL_LAUNCHED("gbl_greedy");
 }
@@ -1348,7 +1353,7 @@ int gbl_greedy_act_at(const int8_t *state, const int8_t *to_move, const int8_t *
     if (depth < 1 || depth > 3) return fail(GBL_ERR_ARG, "depth must be 1, 2 or 3");
     GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask, "mask"); GBL_ALIGNED(cand_mask_out, "cand_mask_out");
     if (hist && (reinterpret_cast<uintptr_t>(hist) & 1u)) return fail(GBL_ERR_ALIGN, "hist must be 2-byte aligned");
-    launch_greedy(greedy_waves(depth), geometry(n), (hipStream_t)stream, state, to_move, mask, nullptr, depth, chosen_out,
+    launch_greedy(greedy_waves(depth, n), geometry(n), (hipStream_t)stream, state, to_move, mask, nullptr, depth, chosen_out,
                   cand_mask_out, fallback_out, n, hist, action_out, seed, env_base, call, call_dev);
     GBL_LAUNCHED("gbl_greedy_act");
 }

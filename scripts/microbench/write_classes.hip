@@ -54,6 +54,35 @@ __global__ __launch_bounds__(64) void k_write(Streams s, int64_t ntiles, int pli
     }
 }
 
+
+// Model of a wavefront that has `think` x 64 clocks of game logic per ply in front of its stores (SPLIT = false), and of
+// the same work dealt over two wavefronts of a workgroup: wavefront 0 thinks, wavefront 1 stores the previous ply
+// (SPLIT = true) -- does decoupling store issue from the computing wavefront pay at small grids?
+template <bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 128 : 64) void k_think(Streams s, int64_t ntiles, int plies, int think)
+{
+    __shared__ uint32_t img[64 * 117 / 4 + 4];
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    const int64_t tile = blockIdx.x;
+    for (int i = threadIdx.x; i < 64 * 117 / 4 + 4; i += SPLIT ? 128 : 64) img[i] = 0;
+    __syncthreads();
+    for (int t = 0; t < plies + (SPLIT ? 1 : 0); ++t) {
+        if (!SPLIT || role == 0) {
+            if (t < plies)
+                for (int i = 0; i < think; ++i) __builtin_amdgcn_s_sleep(1);
+        }
+        if (!SPLIT || role == 1) {
+            const int tt = SPLIT ? t - 1 : t;
+            if (tt >= 0) {
+                const int64_t cell = ((int64_t)tt * ntiles + tile) * 64;
+                if (s.obs[0]) tile_out<117, 18>(s.obs[0] + cell * 117, img, lane);
+                if (s.mask[0]) tile_out<54, 18>(s.mask[0] + cell * 54, img, lane);
+            }
+        }
+        if (SPLIT) __syncthreads();
+    }
+}
+
 static hipEvent_t e0, e1;
 
 static int g_aux = 18;
@@ -113,14 +142,15 @@ int main(int argc, char **argv)
     printf("classes of the chunks:");
     for (int c = 0; c < nchunk; ++c) printf(" %c", 'A' + cls[c]);
     printf("   (%zu classes)\n", rep.size());
-    if (rep.size() < 3) { printf("fewer than three classes inside this arena\n"); return 0; }
+    if (rep.size() < 2) { printf("one class only inside this arena\n"); return 0; }
+    if (rep.size() < 3) { printf("(two classes only inside this arena: the lines with class C use B instead)\n"); rep.push_back(rep[1]); }
     // two chunks of each of the first three classes, where available
     int first[3], second[3];
     for (int k = 0; k < 3; ++k) {
         first[k] = rep[k];
         second[k] = -1;
         for (int c = 0; c < nchunk; ++c)
-            if (cls[c] == k && c != first[k]) { second[k] = c; break; }
+            if (cls[c] == cls[rep[k]] && c != first[k]) { second[k] = c; break; }
     }
     const int A = first[0], B = first[1], Cc = first[2], A2 = second[0] >= 0 ? second[0] : first[0];
     const double step_bytes = (double)boards * (117 + 54);
@@ -143,6 +173,23 @@ int main(int argc, char **argv)
     report("obs plies alternate A / C, mask plies alternate B / C", Streams{{chunk(A), chunk(Cc)}, {chunk(B, mask_off), chunk(Cc, mask_off)}}, step_bytes);
     report("obs plies alternate A / B, mask in C", Streams{{chunk(A), chunk(B)}, {chunk(Cc, mask_off), chunk(Cc, mask_off)}}, step_bytes);
     (void)half;
+    printf("\nthink time per ply in front of the stores (x 64 clocks), obs in A / mask in B, us per ply: one wavefront per tile | a computing and a storing wavefront per tile\n");
+    for (int think : {0, 15, 30, 45, 60, 90}) {
+        float best[2] = {1e30f, 1e30f};
+        Streams st{{chunk(A), chunk(A)}, {chunk(B, mask_off), chunk(B, mask_off)}};
+        for (int r = -1; r < 5; ++r)
+            for (int split = 0; split < 2; ++split) {
+                CK(hipEventRecord(e0, 0));
+                if (split) hipLaunchKernelGGL(k_think<true>, dim3((uint32_t)ntiles), dim3(128), 0, 0, st, ntiles, T, think);
+                else hipLaunchKernelGGL(k_think<false>, dim3((uint32_t)ntiles), dim3(64), 0, 0, st, ntiles, T, think);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (r >= 0) best[split] = std::min(best[split], ms);
+            }
+        printf("  think %3d: %6.2f | %6.2f\n", think, best[0] * 1e3f / T, best[1] * 1e3f / T);
+    }
     printf("\nstore cache policy (sc0 = 1, nt = 2, sc1 = 16) x placement, obs + mask, us per ply:\n");
     for (int aux : {0, 2, 18, 16, 1, 17, 19}) {
         g_aux = aux;

@@ -51,7 +51,8 @@ def main():
     for name in ("bench_default", "bench_driver_cmd", "bench_single_ply", "bench_stepmode", "bench_maskonly",
                  "bench_c4_shard_131072", "greedy_65536", "greedy_1048576", "greedy_policy", "playouts"):
         shutil.copy(os.path.join(SRC, name + ".json"), os.path.join(dst, name + ".json"))
-    for name in ("facade.txt", "valu_rates.txt", "winner_lanes.txt"):
+    for name in ("facade.txt", "valu_rates.txt", "winner_lanes.txt", "write_classes.txt", "placement_probe_check.txt",
+                 "placement_ab.txt"):
         shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
     for run in ("collect", "single", "step", "greedy"):
         open(os.path.join(dst, f"{run}_kernel_stats.csv"), "w").write(

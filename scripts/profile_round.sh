@@ -21,6 +21,19 @@ python scripts/bench_playouts.py > $O/playouts.json 2> /dev/null
 python scripts/bench_facade.py > $O/facade.txt
 scripts/microbench/valu_rates > $O/valu_rates.txt
 scripts/microbench/winner_lanes > $O/winner_lanes.txt
+# ---- placement of the trajectory arrays -------------------------------------------------------
+scripts/microbench/write_classes 160 > $O/write_classes.txt
+scripts/microbench/write_classes 160 131072 32 | grep -v "^  policy" >> $O/write_classes.txt
+python scripts/placement_probe_check.py 224 > $O/placement_probe_check.txt 2> /dev/null
+python scripts/placement_probe_check.py 224 131072 32 >> $O/placement_probe_check.txt 2> /dev/null
+for i in 1 2 3 4 5; do   # fresh processes: placed by the probe / as the allocator hands the arrays out
+  for pl in auto any; do
+    python bench.py --no-configs --no-cpu-baseline --placement $pl 2> /dev/null | python -c "
+import json, sys
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('run $i placement $pl: %.3e env-steps/s, %.2f us per ply, roofline.frac %.3f, %s' % (d['value'], d['ms_per_step'] * 1e3, d['roofline']['frac'], json.dumps(d['config']['trajectory_placement'])))" >> $O/placement_ab.txt
+  done
+done
 echo "bench lines done"
 # ---- kernel traces (durations) ------------------------------------------------------------------------------
 rocprofv3 --kernel-trace --stats -d $O/collect_stats -o p -- python3 bench.py --steps 320 --no-configs --no-cpu-baseline > $O/collect_stats.log 2>&1
