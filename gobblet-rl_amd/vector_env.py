@@ -310,6 +310,33 @@ class BatchedGobblet:
             self.observation.copy_(self._last_ply(out, "observation"))
         return out
 
+    def step_into(self, actions, out: dict, t: int):
+        """``step(actions)`` with this ply's outputs written straight into slot ``t`` of time-major trajectory buffers
+        (``trajectory_buffers``) -- the collector loop of a policy that lives outside the library (the reference's
+        Tianshou / RLlib training loops: policy(obs, mask) -> env.step -> buffer.add), without a copy per ply:
+        ``out["action_mask"][t]``, ``["observation"][t]``, ``["winner"][t]``, ``["rewards"][t]`` come from the kernel,
+        ``["actions"][t]``, ``["done"][t]``, ``["to_move"][t]`` are small device copies.  Returns the views
+        (observation[t], action_mask[t]) the policy reads for the next ply.  The environment's own ``action_mask`` /
+        ``observation`` / ``winner`` / ``rewards`` attributes are NOT updated (call ``refresh()`` before stepping by
+        hand again); ``squares`` / ``to_move`` / ``done`` / ``turn`` are, as always."""
+        if out["_layout"] != "time":
+            raise ValueError("step_into() writes time-major trajectory buffers")
+        t = int(t)
+        if not 0 <= t < out["_plies"]:
+            raise IndexError("slot %d of a %d-ply trajectory" % (t, out["_plies"]))
+        f, n = out["_full"], self.num_envs
+        if f["actions"].device != self.device or f["actions"].shape[1] < n or ("observation" in f) != (self.observation is not None):
+            raise ValueError("trajectory buffers do not fit this environment (made by another one?)")
+        a = _as_i32(actions, n, self.device, "actions")
+        obs_t = f["observation"][t] if "observation" in f else None
+        nat.check(self._lib.gbl_step(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
+                                     a.data_ptr(), f["winner"][t].data_ptr(), f["rewards"][t].data_ptr(),
+                                     f["action_mask"][t].data_ptr(), nat.ptr(obs_t), nat.ptr(self.turn), n,
+                                     self.illegal_mode, int(self.auto_reset), self._stream()), "gbl_step")
+        self._ply += 1
+        out["actions"][t].copy_(a); out["done"][t].copy_(self.done); out["to_move"][t].copy_(self.to_move)
+        return (out["observation"][t] if obs_t is not None else None), out["action_mask"][t]
+
     # -- masked-uniform sampling (examples/example_basic.py:58-61) ----------------------------------------
     def sample_actions(self, out: torch.Tensor | None = None) -> torch.Tensor:
         """One uniformly random legal action per board from the current action_mask, keyed by

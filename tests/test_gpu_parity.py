@@ -1050,3 +1050,32 @@ def test_placement_probe_and_spread_buffers(G):
         G.BatchedGobblet(64, DEV, auto_reset=True).trajectory_buffers(4, placement="spread")  # too small to probe
     small = G.BatchedGobblet(64, DEV, auto_reset=True).trajectory_buffers(4)
     assert small["_placement"]["spread"] is False and "too small" in small["_placement"]["why"]
+
+
+@pytest.mark.parametrize("n,illegal,auto_reset", [(4099, "noop", True), (300, "terminate", False)])
+def test_step_into_trajectory_slots(G, n, illegal, auto_reset):
+    """step_into(): an external policy's ply written straight into slot t of the trajectory buffers == step() followed
+    by copies, slot by slot (the policy here: the library's sampler on the previous slot's mask, and a few illegal
+    actions thrown in)."""
+    T, seed = 9, 3
+    kw = dict(auto_reset=auto_reset, seed=seed, illegal_mode=illegal, track_turn=True)
+    a, b = G.BatchedGobblet(n, DEV, **kw), G.BatchedGobblet(n, DEV, **kw)
+    out = a.trajectory_buffers(T)
+    mask = a.action_mask
+    for t_ in range(T):
+        acts = b.sample_actions().clone()       # from b's current mask (== the mask a's policy sees)
+        assert torch.equal(mask, b.action_mask)
+        acts[::7] = (acts[::7] + 11) % 60        # some illegal / out-of-range actions
+        obs_t, mask = a.step_into(acts, out, t_)
+        b.step(acts)
+        assert torch.equal(out["action_mask"][t_], b.action_mask) and torch.equal(out["observation"][t_], b.observation), t_
+        assert torch.equal(out["winner"][t_], b.winner) and torch.equal(out["rewards"][t_], b.rewards), t_
+        assert torch.equal(out["done"][t_], b.done) and torch.equal(out["to_move"][t_], b.to_move), t_
+        assert torch.equal(out["actions"][t_], acts) and obs_t.data_ptr() == out["observation"][t_].data_ptr()
+    assert torch.equal(a.squares, b.squares) and torch.equal(a.turn, b.turn) and a.ply == b.ply
+    pad = out["_full"]["observation"][:, n:]
+    assert int(pad.abs().sum()) == 0
+    with pytest.raises(IndexError):
+        a.step_into(acts, out, T)
+    with pytest.raises(ValueError):
+        a.step_into(acts, a.trajectory_buffers(2, layout="tile"), 0)
