@@ -190,6 +190,44 @@ __device__ __forceinline__ void tile_out(int8_t *__restrict__ g, const uint32_t 
     }
 }
 
+// tile_out in two halves, for a wavefront that takes a FULL tile's image over from another one: tile_fetch copies
+// the image into registers (after which the image may be rebuilt), tile_store sends them out.
+template <int ROWB>
+__device__ __forceinline__ void tile_fetch(const uint32_t *lds, int lane, uint4 (&v)[kTile * ROWB / 16 / 64 + 1])
+{
+    constexpr int NV = kTile * ROWB / 16, FULL = NV / 64, REM = NV % 64;
+    const uint4 *lv = reinterpret_cast<const uint4 *>(lds);
+#pragma unroll
+    for (int i = 0; i < FULL; ++i) v[i] = lv[lane + 64 * i];
+    v[FULL] = lv[REM && lane < REM ? lane + 64 * FULL : lane];
+}
+
+template <int ROWB, int NT = kStorePlain>
+__device__ __forceinline__ void tile_store(int8_t *__restrict__ g, const uint4 (&v)[kTile * ROWB / 16 / 64 + 1], int lane)
+{
+    constexpr int NV = kTile * ROWB / 16, FULL = NV / 64, REM = NV % 64;
+#ifndef GBL_HOST_EMU
+    if constexpr (NT == kStoreStreamDrop) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g, 0, kTile * ROWB, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < FULL; ++i) {
+            vec4u t = {v[i].x, v[i].y, v[i].z, v[i].w};
+            __builtin_amdgcn_raw_buffer_store_b128(t, rs, (lane + 64 * i) * 16, 0, 2 | 16);
+        }
+        if (REM && lane < REM) {
+            vec4u t = {v[FULL].x, v[FULL].y, v[FULL].z, v[FULL].w};
+            __builtin_amdgcn_raw_buffer_store_b128(t, rs, (lane + 64 * FULL) * 16, 0, 2 | 16);
+        }
+        return;
+    }
+#endif
+    constexpr int P = NT == kStoreStreamDrop ? kStoreStream : NT;
+    uint4 *gv = reinterpret_cast<uint4 *>(g);
+#pragma unroll
+    for (int i = 0; i < FULL; ++i) store16<P>(&gv[lane + 64 * i], v[i]);
+    if (REM && lane < REM) store16<P>(&gv[lane + 64 * FULL], v[FULL]);
+}
+
 // Orders this wave's LDS accesses across lanes.  A workgroup is ONE wavefront, whose LDS
 // instructions execute in issue order, so no s_barrier and no vmcnt drain is needed (a
 // __syncthreads() would also wait for every outstanding global store); the fence only keeps the

@@ -608,6 +608,145 @@ __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__r
     GBL_STAMP_FLUSH(L.tile);
 }
 
+// gbl_collect for grids that fit the chip in one batch (up to kCollect2MaxTiles tiles): TWO wavefronts per tile.  A
+// wavefront whose stores are held back at issue cannot compute, and with eight or sixteen wavefronts per CU all in step
+// nothing else fills the gap (the think-time model).  So the roles are dealt out: wavefront 0 plays the
+// game -- pick, move, winner, auto-reset, tallies, the observation image, the next mask, its image -- and never
+// issues a trajectory store; wavefront 1 takes the finished images over into registers (after which wavefront 0
+// rebuilds them for the next ply) and does nothing but store.  Two barriers per ply: "images ready" and "images
+// taken".  Bit for bit the trajectories of k_collect.
+constexpr int64_t kCollect2MaxTiles = 2048;  // 8 workgroups per CU (110 VGPRs: 4 wavefronts per SIMD); 4096 tiles would need two batches: 7.45 -> 7.81 us per ply
+
+// (LDS traffic only: no vmcnt wait -- the storing wavefront's stores stay in flight across the barrier)
+__device__ __forceinline__ void pair_barrier()
+{
+#ifndef GBL_HOST_EMU
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY>
+__global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n,
+                                                 int64_t ntiles, uint64_t seed, uint64_t env_base,
+                                                 const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies,
+                                                 int8_t *__restrict__ done, int64_t ply_stride, int64_t tile_stride,
+                                                 int32_t *__restrict__ actions_t, int8_t *__restrict__ winner_t,
+                                                 int8_t *__restrict__ reward_t, int8_t *__restrict__ done_t,
+                                                 int8_t *__restrict__ to_move_t, int8_t *__restrict__ mask_t,
+                                                 int8_t *__restrict__ obs_t, int illegal_mode,
+                                                 int64_t *__restrict__ counters, int32_t *__restrict__ turn)
+{
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    __shared__ uint32_t s_obs[WITH_OBS ? image_words<kObs>() : 4];
+    __shared__ uint32_t s_mask[WITH_MASK ? image_words<kActions>() : 4];
+    __shared__ uint32_t s_small[kTile][2];  // per board: the action; winner | reward << 8 | done << 24 | to_move << 25
+    if (DEV_PLY) ply0 += *ply_dev;
+    const int role = threadIdx.x >> 6;
+    Lane L;
+    L.tile = (int64_t)blockIdx.x;
+    L.lane = threadIdx.x & 63;
+    if (L.tile >= ntiles) return;  // (the same for both wavefronts of the workgroup)
+    const int64_t left = n - L.tile * kTile;
+    L.rows = left < kTile ? (int)left : kTile;
+    L.valid = L.lane < L.rows;
+    L.b = L.tile * kTile + L.lane;
+    constexpr int kPolicy = kStoreStreamDrop;
+    if (role == 1) {
+        // ---- the storing wavefront ---------------------------------------------------------------------------------
+        for (uint32_t t = 0; t < plies; ++t) {
+            const int64_t cell = (int64_t)t * ply_stride + L.tile * tile_stride;
+            uint4 vo[kTile * kObs / 16 / 64 + 1], vm[kTile * kActions / 16 / 64 + 1];
+            pair_barrier();  // images ready
+            const uint32_t act = s_small[L.lane][0], sc = s_small[L.lane][1];
+            if (L.rows == kTile) {
+                if (WITH_OBS) tile_fetch<kObs>(s_obs, L.lane, vo);
+                if (WITH_MASK) tile_fetch<kActions>(s_mask, L.lane, vm);
+            } else {  // the ragged last tile goes out byte by byte, straight from the images
+                if (WITH_OBS) tile_out<kObs, kPolicy>(obs_t + cell * kObs, s_obs, L.lane, L.rows);
+                if (WITH_MASK) tile_out<kActions, kPolicy>(mask_t + cell * kActions, s_mask, L.lane, L.rows);
+            }
+            pair_barrier();  // images taken
+            if (L.valid) {
+                const int64_t at = cell + L.lane;
+                if (actions_t) actions_t[at] = (int32_t)act;
+                if (winner_t) winner_t[at] = (int8_t)(sc & 0xFFu);
+                if (reward_t) reinterpret_cast<uint16_t *>(reward_t)[at] = (uint16_t)((sc >> 8) & 0xFFFFu);
+                if (done_t) done_t[at] = (int8_t)((sc >> 24) & 1u);
+                if (to_move_t) to_move_t[at] = (int8_t)((sc >> 25) & 1u);
+            }
+            if (L.rows == kTile) {
+                if (WITH_OBS) tile_store<kObs, kPolicy>(obs_t + cell * kObs, vo, L.lane);
+                if (WITH_MASK) tile_store<kActions, kPolicy>(mask_t + cell * kActions, vm, L.lane);
+            }
+        }
+        return;
+    }
+    // ---- the playing wavefront (k_collect's loop without its trajectory stores) -------------------------------------
+    int mover = to_move[L.valid ? L.b : n - 1];
+    uint32_t r[7];
+    Draw4 block{{0u, 0u, 0u, 0u}};
+    load_state(state, s_state, L, r, [&] { block = draw_block(seed, env_base + (uint64_t)L.b, ply0); });
+    mover = L.valid && mover != 0;
+    Planes p = planes_of(L, r);
+    const ImageRow row{reinterpret_cast<uint8_t *>(s_state) + L.lane * kCells};
+    uint32_t games = 0, w1 = 0, w2 = 0;
+    Ply y{0, 0, 0, false, false};
+    int dn = 0, tcount = 0;
+    bool treset = false;
+    uint64_t legal = legal54(p, mover);
+    for (uint32_t t = 0; t < plies; ++t) {
+        const uint32_t ply = ply0 + t;
+        const int action = pick54(legal, draw_word(block, ply));
+        if (t + 1 < plies && ((ply + 1) & 3u) == 0) block = draw_block(seed, env_base + (uint64_t)L.b, ply + 1);
+        y = play_ply(p, row, mover, legal, action, illegal_mode);
+        dn = y.terminal ? 1 : 0;
+        if (y.terminal) {  // raw_env.reset, gobblet.py:275-290
+            p = Planes{0u, 0u, 0u};
+            mover = 0;
+            row.reset();
+        }
+        tcount = next_turn(tcount, y, 1);
+        treset = treset || y.terminal;
+        if (counters) {
+            games += __popcll(__ballot(L.valid && y.terminal));
+            w1 += __popcll(__ballot(L.valid && y.winner == 1));
+            w2 += __popcll(__ballot(L.valid && y.winner == -1));
+        }
+        legal = legal54(p, mover);  // the next mover's: stored now, sampled from next ply
+        if (t) pair_barrier();      // the images of the previous ply have been taken
+        s_small[L.lane][0] = (uint32_t)action;
+        s_small[L.lane][1] = ((uint32_t)y.winner & 0xFFu) | (((uint32_t)y.r0 & 0xFFu) << 8) | (((uint32_t)y.r1 & 0xFFu) << 16) |
+                             ((uint32_t)dn << 24) | ((uint32_t)mover << 25);
+        if (WITH_OBS) {
+            obs_image_zero(s_obs, L.lane);
+            wave_lds_fence();
+            obs_scatter(s_obs, L.lane, p, mover);
+        }
+        if (WITH_MASK) {
+            uint32_t d[14];
+            mask_row(legal, d);
+            row_stage<kActions>(s_mask, L.lane, d);
+        }
+        pair_barrier();  // images ready
+    }
+    pair_barrier();  // (the last ply's images taken: pairs with the storing wavefront's second barrier)
+    wave_lds_fence();
+    tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
+    if (L.valid) {
+        to_move[L.b] = (int8_t)mover;
+        done[L.b] = (int8_t)dn;
+        if (turn) turn[L.b] = treset ? tcount : turn[L.b] + tcount;
+    }
+    if (counters && L.lane == 0) {
+        unsigned long long *c = reinterpret_cast<unsigned long long *>(counters) +
+                                (size_t)(L.tile % GBL_COUNTER_STRIPES) * GBL_COUNTER_STRIDE;
+        atomicAdd(c + 0, (unsigned long long)L.rows * plies);
+        if (games) atomicAdd(c + 1, (unsigned long long)games);
+        if (w1) atomicAdd(c + 2, (unsigned long long)w1);
+        if (w2) atomicAdd(c + 3, (unsigned long long)w2);
+    }
+}
+
 // gbl_placement_probe: the write pattern of k_collect without the game -- tile i of `plies` slots stores 64 rows of
 // 117 bytes into a and 64 rows of 54 bytes into b (zeros, `nt sc1` like the trajectory stream), one wavefront per
 // tile, identity tile map.  Timed with both streams, with a alone and with b alone (see the header).
@@ -1199,9 +1338,19 @@ int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_t
 #else
     const bool nt = row_bytes > kCollectCachedBytes;
 #endif
+#ifdef GBL_FORCE_COLLECT_PAIR  // 0 / 1: A/B builds
+    const bool pair = (GBL_FORCE_COLLECT_PAIR) != 0;
+#else
+    const bool pair = g.ntiles <= kCollect2MaxTiles && nt && (mask_traj || obs_traj);
+#endif
 #define GBL_COLLECT_K(M, O, D)                                  \
-    if (nt) GBL_COLLECT_KN(M, O, D, true);                      \
+    if (pair) GBL_COLLECT_K2(M, O, D);                          \
+    else if (nt) GBL_COLLECT_KN(M, O, D, true);                 \
     else GBL_COLLECT_KN(M, O, D, false)
+#define GBL_COLLECT_K2(M, O, D)                                                                                         \
+    hipLaunchKernelGGL((k_collect2<M, O, D>), dim3((uint32_t)g.ntiles), dim3(128), 0, s, state, to_move, n, g.ntiles, seed, \
+                       env_base, ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj,        \
+                       reward_traj, done_traj, to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn)
 #define GBL_COLLECT_KN(M, O, D, N)                                                                                      \
     hipLaunchKernelGGL((k_collect<M, O, D, N>), dim3(g.grid), dim3(64), 0, s, state, to_move, n, g.ntiles, seed, env_base, \
                        ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj, reward_traj,     \
@@ -1217,6 +1366,7 @@ int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_t
 #undef GBL_COLLECT
 #undef GBL_COLLECT_K
 #undef GBL_COLLECT_KN
+#undef GBL_COLLECT_K2
     GBL_LAUNCHED("gbl_collect");
 }
 
