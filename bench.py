@@ -252,7 +252,9 @@ class Pipeline:
         """kernel_s: summed duration of the dominant kernel over `launches` launches that played `plies_timed` plies."""
         total_bytes = sum(self.launch_bytes(pl) for _, pl in self.plan(plies_timed))
         achieved = total_bytes / kernel_s / 1e9
-        name = {"step": "k_step", "fused": "k_rollout (plies=1)", "collect": f"k_collect ({self.T} plies per launch)"}[self.mode]
+        # (grids of up to 2048 tiles run the two-wavefronts-per-tile form of the kernel, k_collect2)
+        collect = "k_collect2" if -(-self.boards // 64) <= 2048 else "k_collect"
+        name = {"step": "k_step", "fused": "k_rollout (plies=1)", "collect": f"{collect} ({self.T} plies per launch)"}[self.mode]
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                 "kernel": name + ("<mask>" if self.no_obs else "<mask,obs>"),
