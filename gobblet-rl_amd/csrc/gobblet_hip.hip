@@ -613,7 +613,7 @@ __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__r
 // nothing else fills the gap (the think-time model).  So the roles are dealt out: wavefront 0 plays the
 // game -- pick, move, winner, auto-reset, tallies, the observation image, the next mask, its image -- and never
 // issues a trajectory store; wavefront 1 takes the finished images over into registers (after which wavefront 0
-// rebuilds them for the next ply) and does nothing but store.  Two barriers per ply: "images ready" and "images
+// rebuilds them for the next ply; the observation image comes back zeroed) and does nothing but store.  Two barriers per ply: "images ready" and "images
 // taken".  Bit for bit the trajectories of k_collect.
 constexpr int64_t kCollect2MaxTiles = 2048;  // 8 workgroups per CU (110 VGPRs: 4 wavefronts per SIMD); 4096 tiles would need two batches: 7.45 -> 7.81 us per ply
 
@@ -665,6 +665,10 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
                 if (WITH_OBS) tile_out<kObs, kPolicy>(obs_t + cell * kObs, s_obs, L.lane, L.rows);
                 if (WITH_MASK) tile_out<kActions, kPolicy>(mask_t + cell * kActions, s_mask, L.lane, L.rows);
             }
+            if (WITH_OBS) {  // hand the observation image back zeroed: off the playing wavefront's path
+                wave_lds_fence();
+                obs_image_zero(s_obs, L.lane);
+            }
             pair_barrier();  // images taken
             if (L.valid) {
                 const int64_t at = cell + L.lane;
@@ -694,6 +698,10 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
     int dn = 0, tcount = 0;
     bool treset = false;
     uint64_t legal = legal54(p, mover);
+    if (WITH_OBS) {  // the first ply's observation image (later ones come back zeroed from the storing wavefront)
+        obs_image_zero(s_obs, L.lane);
+        wave_lds_fence();
+    }
     for (uint32_t t = 0; t < plies; ++t) {
         const uint32_t ply = ply0 + t;
         const int action = pick54(legal, draw_word(block, ply));
@@ -717,11 +725,7 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
         s_small[L.lane][0] = (uint32_t)action;
         s_small[L.lane][1] = ((uint32_t)y.winner & 0xFFu) | (((uint32_t)y.r0 & 0xFFu) << 8) | (((uint32_t)y.r1 & 0xFFu) << 16) |
                              ((uint32_t)dn << 24) | ((uint32_t)mover << 25);
-        if (WITH_OBS) {
-            obs_image_zero(s_obs, L.lane);
-            wave_lds_fence();
-            obs_scatter(s_obs, L.lane, p, mover);
-        }
+        if (WITH_OBS) obs_scatter(s_obs, L.lane, p, mover);  // (into the zeroed image)
         if (WITH_MASK) {
             uint32_t d[14];
             mask_row(legal, d);
