@@ -66,7 +66,7 @@ SIGNATURES = {
     "gbl_counter_add": (_int, [_vp, _u32, _vp]),
     "gbl_collect": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u64, _u64, _u32, _vp, _u32,
                            _int, _vp, _vp, _vp]),
-    "gbl_placement_probe": (_int, [_vp, _i64, _vp, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float),
+    "gbl_placement_probe": (_int, [_vp, _i64, _vp, _i64, _i64, _int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                    C.POINTER(C.c_float), _vp]),
 }
 

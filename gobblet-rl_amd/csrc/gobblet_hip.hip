@@ -1374,15 +1374,24 @@ int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_t
     GBL_LAUNCHED("gbl_collect");
 }
 
-int gbl_placement_probe(void *a, int64_t a_bytes, void *b, int64_t b_bytes, float *us_both, float *us_a, float *us_b,
-                        void *stream)
+int gbl_placement_probe(void *a, int64_t a_bytes, void *b, int64_t b_bytes, int64_t slot_boards, int plies, float *us_both,
+                        float *us_a, float *us_b, void *stream)
 {
     GBL_NEED(a, "a"); GBL_NEED(b, "b"); GBL_NEED(us_both, "us_both"); GBL_NEED(us_a, "us_a"); GBL_NEED(us_b, "us_b");
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 127u)
         return fail(GBL_ERR_ALIGN, "a and b must be 128-byte aligned");
-    constexpr int kPlies = 4;
-    // an even number of tiles per slot: every slot of both arrays then starts on a 128-byte line
-    const int64_t tiles = std::min(a_bytes / ((int64_t)kPlies * kTile * kObs), b_bytes / ((int64_t)kPlies * kTile * kActions)) & ~(int64_t)1;
+    int kPlies = 4;
+    int64_t tiles;
+    if (slot_boards > 0) {  // the geometry of a time-major trajectory: `plies` slots of slot_boards boards
+        if (plies < 1 || (slot_boards & 127)) return fail(GBL_ERR_ARG, "slot_boards: a multiple of 128 boards; plies >= 1");
+        kPlies = plies;
+        tiles = slot_boards / kTile;
+        if (a_bytes < (int64_t)plies * slot_boards * kObs || b_bytes < (int64_t)plies * slot_boards * kActions)
+            return fail(GBL_ERR_ARG, "buffers smaller than plies x slot_boards rows");
+    } else {
+        // an even number of tiles per slot: every slot of both arrays then starts on a 128-byte line
+        tiles = std::min(a_bytes / ((int64_t)kPlies * kTile * kObs), b_bytes / ((int64_t)kPlies * kTile * kActions)) & ~(int64_t)1;
+    }
     if (tiles < 2) return fail(GBL_ERR_ARG, "buffers too small to probe (a: 4 x 7488 bytes per tile, b: 4 x 3456)");
     if (tiles > 0x7fffffff) return fail(GBL_ERR_ARG, "buffers too large to probe in one launch");
     hipStream_t s = (hipStream_t)stream;

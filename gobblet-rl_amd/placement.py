@@ -24,7 +24,7 @@ from . import _native as nat
 
 GIB = 1 << 30
 MIN_BYTES = 64 << 20       # below this a probe says nothing (and the arrays live in the 256 MiB Infinity Cache anyway)
-ACCEPT_RATIO = 0.88        # stop searching at a pair this good (us_both / (us_a + us_b)); such pairs ran at full rate
+ACCEPT_RATIO = 0.83        # stop searching at a pair this good (us_both / (us_a + us_b)); 0.86 already costs 3 %
 SPREAD_RATIO = 0.93        # reported as "spread" below this
 SAME_RATIO = 0.96          # above this the pair simply shares a class
 STEP_BYTES = 8 * GIB
@@ -33,17 +33,18 @@ MAX_PROBES = 16
 RESERVE_BYTES = 4 * GIB    # never take the device's last few GiB for spacers
 
 
-def probe(a: torch.Tensor, b: torch.Tensor) -> tuple[float, float, float]:
-    """(us_both, us_a, us_b) of ``gbl_placement_probe`` on two device tensors.  OVERWRITES both with zeros."""
+def probe(a: torch.Tensor, b: torch.Tensor, slot_boards: int = 0, plies: int = 0) -> tuple[float, float, float]:
+    """(us_both, us_a, us_b) of ``gbl_placement_probe`` on two device tensors; slot_boards / plies: the geometry of the
+    time-major trajectory they will hold (0: four slots over the smaller one).  OVERWRITES both with zeros."""
     both, ua, ub = C.c_float(), C.c_float(), C.c_float()
     nat.check(nat.lib().gbl_placement_probe(a.data_ptr(), a.numel() * a.element_size(), b.data_ptr(),
-                                            b.numel() * b.element_size(), C.byref(both), C.byref(ua), C.byref(ub),
-                                            nat.current_stream(a.device)), "gbl_placement_probe")
+                                            b.numel() * b.element_size(), int(slot_boards), int(plies), C.byref(both),
+                                            C.byref(ua), C.byref(ub), nat.current_stream(a.device)), "gbl_placement_probe")
     return both.value, ua.value, ub.value
 
 
 def spread_pair(make_a, make_b, step_bytes: int = STEP_BYTES, max_skip_bytes: int = MAX_SKIP_BYTES,
-                max_probes: int = MAX_PROBES):
+                max_probes: int = MAX_PROBES, slot_boards: int = 0, plies: int = 0):
     """``(a, b) = (make_a(), make_b())`` placed so that writes to ``a`` and to ``b`` overlap.  Returns (a, b, info);
     info records every probe.  Both arrays come back zero-filled.  If no pair is clean, the best one seen is returned."""
     t0 = time.perf_counter()
@@ -54,7 +55,7 @@ def spread_pair(make_a, make_b, step_bytes: int = STEP_BYTES, max_skip_bytes: in
 
     def try_pair(ia, ib):
         nonlocal best
-        us_both, us_a, us_b = probe(pool["a"][ia], pool["b"][ib])
+        us_both, us_a, us_b = probe(pool["a"][ia], pool["b"][ib], slot_boards, plies)
         ratio = us_both / max(us_a + us_b, 1e-9)
         tried.append(round(ratio, 3))
         if best[0] is None or ratio < best[0]:

@@ -245,7 +245,8 @@ class BatchedGobblet:
         if placement == "spread" and not probeable:
             raise ValueError("placement='spread' needs an observation trajectory and at least 64 MiB of mask trajectory")
         if placement != "any" and probeable:
-            full["observation"], full["action_mask"], placed = _placement.spread_pair(make_obs, make_mask)
+            geometry = dict(slot_boards=ply_stride, plies=T) if layout == "time" and ply_stride % 128 == 0 else {}
+            full["observation"], full["action_mask"], placed = _placement.spread_pair(make_obs, make_mask, **geometry)
         else:
             if self.observation is not None:
                 full["observation"] = make_obs()

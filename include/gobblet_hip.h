@@ -259,12 +259,16 @@ int gbl_counter_add(uint32_t *counter, uint32_t by, void *stream);
  * gbl_collect then takes the SUM of what its observation stream and its mask stream take alone (33 us per ply at 2^20
  * boards), against 27 us when the two arrays lie in different classes.  Physical addresses are not
  * visible to a process, so the property is measured: the probe replays gbl_collect's store pattern (64 x 117 bytes
- * into a, 64 x 54 bytes into b per wavefront, four slots) with both streams, with a alone and with b alone, and
- * reports the three times in microseconds.  us_both close to us_a + us_b: the two buffers share a class; us_both
- * about 0.8 of the sum: they do not.  OVERWRITES both buffers with zeros; blocks the host until the probe has run
- * (not capturable into a graph); buffers of less than about 64 MiB are too small for a meaningful answer. */
-int gbl_placement_probe(void *a, int64_t a_bytes, void *b, int64_t b_bytes, float *us_both, float *us_a, float *us_b,
-                        void *stream);
+ * into a, 64 x 54 bytes into b per wavefront and slot) with both streams, with a alone and with b alone, and reports
+ * the three times in microseconds.  us_both close to us_a + us_b: the two buffers share a class; us_both about 0.8
+ * of the sum: they do not.  slot_boards > 0 (a multiple of 128) and plies: the geometry of the time-major trajectory
+ * the buffers will hold -- slot t of a at t * slot_boards * 117 bytes, of b at t * slot_boards * 54 -- so that the
+ * probe pairs exactly the regions the kernel writes together (it matters when an array straddles two classes);
+ * slot_boards = 0: four slots spread over the whole of the smaller buffer.  OVERWRITES both buffers with zeros; blocks
+ * the host until the probe has run (not capturable into a graph); buffers of less than about 64 MiB are too small for
+ * a meaningful answer. */
+int gbl_placement_probe(void *a, int64_t a_bytes, void *b, int64_t b_bytes, int64_t slot_boards, int plies, float *us_both,
+                        float *us_a, float *us_b, void *stream);
 
 #ifdef __cplusplus
 }

@@ -50,7 +50,7 @@ def collect_us(obs_off, mask_off, reps=3):
 
 def probe(obs_off, mask_off):
     both, ua, ub = C.c_float(), C.c_float(), C.c_float()
-    nat.check(L.gbl_placement_probe(base + obs_off, obs_bytes, base + mask_off, mask_bytes, C.byref(both), C.byref(ua), C.byref(ub),
+    nat.check(L.gbl_placement_probe(base + obs_off, obs_bytes, base + mask_off, mask_bytes, slot, T, C.byref(both), C.byref(ua), C.byref(ub),
                                     nat.current_stream(dev)))
     return both.value, ua.value, ub.value
 

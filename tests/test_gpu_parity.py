@@ -1017,7 +1017,7 @@ def test_placement_probe_and_spread_buffers(G):
     a = torch.full((na + 2 * guard,), 7, dtype=torch.uint8, device=DEV)
     b = torch.full((nb + 2 * guard,), 9, dtype=torch.uint8, device=DEV)
     both, ua, ub = C.c_float(), C.c_float(), C.c_float()
-    nat.check(L.gbl_placement_probe(a.data_ptr() + guard, na, b.data_ptr() + guard, nb, C.byref(both), C.byref(ua), C.byref(ub),
+    nat.check(L.gbl_placement_probe(a.data_ptr() + guard, na, b.data_ptr() + guard, nb, 0, 0, C.byref(both), C.byref(ua), C.byref(ub),
                                     nat.current_stream(torch.device(DEV))))
     torch.cuda.synchronize()
     assert both.value > 0 and ua.value > 0 and ub.value > 0 and both.value < 2 * (ua.value + ub.value)
@@ -1025,10 +1025,18 @@ def test_placement_probe_and_spread_buffers(G):
     tiles = min(na // (4 * 7488), nb // (4 * 3456)) & ~1      # what the probe covers: 4 slots of `tiles` tiles
     assert int(a[guard:guard + 4 * tiles * 7488].max()) == 0 and int(b[guard:guard + 4 * tiles * 3456].max()) == 0
     assert int(a[guard + 4 * tiles * 7488:guard + na].min()) == 7 and int(b[guard + 4 * tiles * 3456:guard + nb].min()) == 9
-    rc = L.gbl_placement_probe(a.data_ptr() + 64, na, b.data_ptr(), nb, C.byref(both), C.byref(ua), C.byref(ub), None)
+    rc = L.gbl_placement_probe(a.data_ptr() + 64, na, b.data_ptr(), nb, 0, 0, C.byref(both), C.byref(ua), C.byref(ub), None)
     assert rc == nat.ERR_ALIGN
-    rc = L.gbl_placement_probe(a.data_ptr(), 1000, b.data_ptr(), nb, C.byref(both), C.byref(ua), C.byref(ub), None)
+    rc = L.gbl_placement_probe(a.data_ptr(), 1000, b.data_ptr(), nb, 0, 0, C.byref(both), C.byref(ua), C.byref(ub), None)
     assert rc == nat.ERR_ARG
+    # the trajectory's own geometry: 3 slots of 8192 boards; a slot count the buffers cannot hold is refused
+    a[guard:guard + na] = 7; b[guard:guard + nb] = 9
+    nat.check(L.gbl_placement_probe(a.data_ptr() + guard, na, b.data_ptr() + guard, nb, 8192, 3, C.byref(both), C.byref(ua), C.byref(ub), None))
+    torch.cuda.synchronize()
+    assert int(a[guard:guard + 3 * 8192 * 117].max()) == 0 and int(a[guard + 3 * 8192 * 117:guard + na].min()) == 7
+    assert int(b[guard:guard + 3 * 8192 * 54].max()) == 0 and int(b[guard + 3 * 8192 * 54:guard + nb].min()) == 9
+    assert L.gbl_placement_probe(a.data_ptr() + guard, na, b.data_ptr() + guard, nb, 8192, 4000, C.byref(both), C.byref(ua), C.byref(ub), None) == nat.ERR_ARG
+    assert L.gbl_placement_probe(a.data_ptr() + guard, na, b.data_ptr() + guard, nb, 8200, 3, C.byref(both), C.byref(ua), C.byref(ub), None) == nat.ERR_ARG
     del a, b
 
     n, T, seed = 65536, 24, 5     # mask trajectory 81 MiB: large enough to be probed
