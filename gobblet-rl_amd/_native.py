@@ -55,6 +55,7 @@ SIGNATURES = {
     "gbl_pinned_alloc": (_int, [_i64, C.POINTER(_vp), C.POINTER(_vp)]),
     "gbl_pinned_free": (_int, [_vp]),
     "gbl_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
+    "gbl_step_into": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
     "gbl_sample": (_int, [_vp, _vp, _i64, _u64, _u64, _u32, _vp]),
     "gbl_rollout": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u64, _u64, _u32, _u32, _int, _vp, _vp, _vp]),
     "gbl_decode_obs": (_int, [_vp, _vp, _vp, _i64, _vp]),

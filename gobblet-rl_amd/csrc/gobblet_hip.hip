@@ -389,7 +389,8 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_step(int8_t *__restrict__ s
                                              int64_t n, int64_t ntiles, int illegal_mode, int auto_reset,
                                              int8_t *__restrict__ winner_out, int8_t *__restrict__ reward_out,
                                              int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out,
-                                             int32_t *__restrict__ turn)
+                                             int32_t *__restrict__ turn, int32_t *__restrict__ actions_copy,
+                                             int8_t *__restrict__ done_copy, int8_t *__restrict__ to_move_copy)
 {
     constexpr int kImg = out_image_words<WITH_MASK, WITH_OBS>();
     __shared__ uint32_t s_imgs[kStepWaves * kImg];
@@ -420,6 +421,10 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_step(int8_t *__restrict__ s
         if (reward_out)
             reinterpret_cast<uint16_t *>(reward_out)[L.b] = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
         if (turn) turn[L.b] = next_turn(turn[L.b], y, auto_reset);
+        // gbl_step_into: the ply's scalars also into a trajectory slot
+        if (actions_copy) actions_copy[L.b] = action;
+        if (done_copy) done_copy[L.b] = (int8_t)dn;
+        if (to_move_copy) to_move_copy[L.b] = (int8_t)mover;
     }
 }
 
@@ -1201,6 +1206,14 @@ int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *action
              int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int64_t n, int illegal_mode,
              int auto_reset, void *stream)
 {
+    return gbl_step_into(state, to_move, done, actions, winner_out, reward_out, mask_out, obs_out, turn, nullptr, nullptr,
+                         nullptr, n, illegal_mode, auto_reset, stream);
+}
+
+int gbl_step_into(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out,
+                  int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int32_t *actions_out,
+                  int8_t *done_out, int8_t *to_move_out, int64_t n, int illegal_mode, int auto_reset, void *stream)
+{
     GBL_CHECK_N(n);
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done"); GBL_NEED(actions, "actions");
     if (illegal_mode != GBL_ILLEGAL_NOOP && illegal_mode != GBL_ILLEGAL_TERMINATE)
@@ -1210,13 +1223,16 @@ int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *action
         return fail(GBL_ERR_ALIGN, "reward_out must be 2-byte aligned");
     if (turn && (reinterpret_cast<uintptr_t>(turn) & 3u)) return fail(GBL_ERR_ALIGN, "turn must be 4-byte aligned");
     if (reinterpret_cast<uintptr_t>(actions) & 3u) return fail(GBL_ERR_ALIGN, "actions must be 4-byte aligned");
+    if (actions_out && (reinterpret_cast<uintptr_t>(actions_out) & 3u))
+        return fail(GBL_ERR_ALIGN, "actions_out must be 4-byte aligned");
     Geometry g = geometry(n, kStepWaves);
     hipStream_t s = (hipStream_t)stream;
     auto_reset = auto_reset != 0;
     const int nt = nt_policy(n);
 #define GBL_STEP_NT(M, O, NT)                                                                                       \
     hipLaunchKernelGGL((k_step<M, O, NT>), dim3(g.grid), dim3(64 * kStepWaves), 0, s, state, to_move, done, actions, \
-                       n, g.ntiles, illegal_mode, auto_reset, winner_out, reward_out, mask_out, obs_out, turn)
+                       n, g.ntiles, illegal_mode, auto_reset, winner_out, reward_out, mask_out, obs_out, turn,      \
+                       actions_out, done_out, to_move_out)
 #define GBL_STEP(M, O)                                          \
     if (nt == 3) GBL_STEP_NT(M, O, 3);                          \
     else GBL_STEP_NT(M, O, 1);

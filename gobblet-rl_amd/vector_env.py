@@ -316,7 +316,7 @@ class BatchedGobblet:
         (``trajectory_buffers``) -- the collector loop of a policy that lives outside the library (the reference's
         Tianshou / RLlib training loops: policy(obs, mask) -> env.step -> buffer.add), without a copy per ply:
         ``out["action_mask"][t]``, ``["observation"][t]``, ``["winner"][t]``, ``["rewards"][t]`` come from the kernel,
-        ``["actions"][t]``, ``["done"][t]``, ``["to_move"][t]`` are small device copies.  Returns the views
+        and so do ``["actions"][t]``, ``["done"][t]``, ``["to_move"][t]`` (``gbl_step_into``: one launch).  Returns the views
         (observation[t], action_mask[t]) the policy reads for the next ply.  The environment's own ``action_mask`` /
         ``observation`` / ``winner`` / ``rewards`` attributes are NOT updated (call ``refresh()`` before stepping by
         hand again); ``squares`` / ``to_move`` / ``done`` / ``turn`` are, as always."""
@@ -330,12 +330,12 @@ class BatchedGobblet:
             raise ValueError("trajectory buffers do not fit this environment (made by another one?)")
         a = _as_i32(actions, n, self.device, "actions")
         obs_t = f["observation"][t] if "observation" in f else None
-        nat.check(self._lib.gbl_step(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
-                                     a.data_ptr(), f["winner"][t].data_ptr(), f["rewards"][t].data_ptr(),
-                                     f["action_mask"][t].data_ptr(), nat.ptr(obs_t), nat.ptr(self.turn), n,
-                                     self.illegal_mode, int(self.auto_reset), self._stream()), "gbl_step")
+        nat.check(self._lib.gbl_step_into(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
+                                          a.data_ptr(), f["winner"][t].data_ptr(), f["rewards"][t].data_ptr(),
+                                          f["action_mask"][t].data_ptr(), nat.ptr(obs_t), nat.ptr(self.turn),
+                                          f["actions"][t].data_ptr(), f["done"][t].data_ptr(), f["to_move"][t].data_ptr(),
+                                          n, self.illegal_mode, int(self.auto_reset), self._stream()), "gbl_step_into")
         self._ply += 1
-        out["actions"][t].copy_(a); out["done"][t].copy_(self.done); out["to_move"][t].copy_(self.to_move)
         return (out["observation"][t] if obs_t is not None else None), out["action_mask"][t]
 
     # -- masked-uniform sampling (examples/example_basic.py:58-61) ----------------------------------------

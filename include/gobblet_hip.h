@@ -119,6 +119,14 @@ int gbl_observe(const int8_t *state, const int8_t *to_move, int agent_sel, int8_
 int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out,
              int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int64_t n, int illegal_mode,
              int auto_reset, void *stream);
+/* gbl_step for a collector whose policy lives outside the library (the loop of the reference's Tianshou / RLlib
+ * trainers: policy(obs, mask) -> env.step -> buffer.add): the same ply, with mask_out / obs_out / winner_out /
+ * reward_out pointing at slot t of trajectory arrays, and in the same launch copies of the ply's other scalars into
+ * that slot (each may be NULL): actions_out int32[n] = the actions played, done_out int8[n] = done after the ply,
+ * to_move_out int8[n] = the agent to move next. */
+int gbl_step_into(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out,
+                  int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int32_t *actions_out,
+                  int8_t *done_out, int8_t *to_move_out, int64_t n, int illegal_mode, int auto_reset, void *stream);
 
 /* Host memory that the kernels read and write directly (pinned and mapped into the device's address space), for
  * callers that want a result on the host without a separate copy -- the single-environment facade keeps its

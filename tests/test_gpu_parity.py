@@ -615,7 +615,7 @@ def test_out_of_bounds_canaries(G, n):
     state, tm, dn = selfplay(n, 12, seed=n)
     a = oracle.batch_sample(oracle.batch_legal_mask(state, tm), 1, 0, 0)
     sizes = {"state": 27 * n, "tm": n, "dn": n, "act": 4 * n, "win": n, "rew": 2 * n, "mask": 54 * n, "obs": 117 * n,
-             "flat": 9 * n, "cov": 27 * n, "turn": 4 * n, "rec": 432 * n}
+             "flat": 9 * n, "cov": 27 * n, "turn": 4 * n, "rec": 432 * n, "act2": 4 * n, "dn2": n, "tm2": n}
     bufs = {k: guarded(v) for k, v in sizes.items()}
     p = {k: bufs[k][1] for k in bufs}
     p["state"].copy_(t(state).view(torch.uint8).reshape(-1)); p["tm"].copy_(t(tm).view(torch.uint8))
@@ -627,6 +627,8 @@ def test_out_of_bounds_canaries(G, n):
                              ptr["obs"], ptr["turn"], n, 0, auto, None))
         nat.check(L.gbl_rollout(ptr["state"], ptr["tm"], ptr["dn"], ptr["act"], ptr["win"], ptr["rew"], ptr["mask"],
                                 ptr["obs"], n, 3, 0, 5, 2, 0, None, ptr["turn"], None))
+        nat.check(L.gbl_step_into(ptr["state"], ptr["tm"], ptr["dn"], ptr["act"], ptr["win"], ptr["rew"], ptr["mask"],
+                                  ptr["obs"], ptr["turn"], ptr["act2"], ptr["dn2"], ptr["tm2"], n, 0, auto, None))
     nat.check(L.gbl_legal_mask(ptr["state"], ptr["tm"], ptr["mask"], n, None))
     nat.check(L.gbl_observe(ptr["state"], ptr["tm"], -1, ptr["obs"], n, None))
     nat.check(L.gbl_sample(ptr["mask"], ptr["act"], n, 1, 0, 0, None))
