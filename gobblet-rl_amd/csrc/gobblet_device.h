@@ -919,6 +919,47 @@ __device__ __forceinline__ GreedyHead greedy_head(const Planes &p, int me, uint6
     return h;
 }
 
+// Placements from hand on the same square, one size above the other.  If placing a piece of ours from hand on q
+// leaves the opponent no winning reply, placing a LARGER piece from hand on q leaves none either: the two positions
+// differ only in the level of our piece on q, the opponent's replies elsewhere find the same tops (ours on q in both),
+// and of the replies onto q the larger piece admits a subset.  Which piece of a size stands on q is invisible to the
+// opponent's terms (see dup), and reply_is_plain() reads tops and what lies under the OPPONENT's pieces, so it is the
+// same for both -- hence: the smaller placement evaluated cheaply with summary 0 => the larger one has summary 0, and
+// is not evaluated at all (a summary of 0 leaves no trace in the candidate sets).  ~40 % of the pairs on the
+// masked-random mix.  Placements whose stand-in has a winning reply, or went to the exact evaluation, get a second round.
+struct GreedyDom {
+    uint64_t first;    // evaluated in the first round: h.todo & ~h.dup minus the held ones
+    uint32_t shift[3]; // 9 * (piece that places size k from hand), 63 = no such piece
+    uint32_t dst[3];   // its destinations among the candidates (9 bits)
+};
+
+__device__ __forceinline__ GreedyDom greedy_dominance(const GreedyHead &h, const Planes &p, int me)
+{
+    const uint64_t w0 = h.todo & ~h.dup;
+    const uint32_t mine = me ? (p.nz & p.neg) : (p.nz & ~p.neg);
+    GreedyDom d;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t lvl = (mine >> (9 * k)) & 0x1FFu, oddp = (p.odd >> (9 * k)) & 0x1FFu;
+        const bool even_in_hand = (lvl & oddp) == 0, odd_in_hand = (lvl & ~oddp) == 0;  // piece 2k / 2k + 1 (numbers 2k+1 / 2k+2)
+        d.shift[k] = even_in_hand ? 18u * k : odd_in_hand ? 18u * k + 9u : 63u;
+        d.dst[k] = d.shift[k] < 63u ? (uint32_t)(w0 >> d.shift[k]) & 0x1FFu : 0u;
+    }
+    const uint32_t held1 = d.dst[1] & d.dst[0], held2 = d.dst[2] & (d.dst[0] | d.dst[1]);
+    d.first = w0 & ~(((uint64_t)held1 << (d.shift[1] & 63u)) | ((uint64_t)held2 << (d.shift[2] & 63u)));
+    return d;
+}
+
+// the held placements that need an evaluation after all; bad: candidates of the first round with a winning reply
+// (summary bit 0) or sent to the exact evaluation
+__device__ __forceinline__ uint64_t greedy_second_round(const GreedyDom &d, uint64_t bad)
+{
+    const uint32_t bad0 = (uint32_t)(bad >> (d.shift[0] & 63u)) & d.dst[0], bad1 = (uint32_t)(bad >> (d.shift[1] & 63u)) & d.dst[1];
+    const uint32_t need1 = d.dst[1] & bad0;                                    // (stand-in: the small placement)
+    const uint32_t need2 = d.dst[2] & (bad0 | (~d.dst[0] & bad1));             // (small if there is one, else medium)
+    return ((uint64_t)need1 << (d.shift[1] & 63u)) | ((uint64_t)need2 << (d.shift[2] & 63u));
+}
+
 // What the depth-2 loop needs to know about candidate `a` (:107-126), packed in 16 bits:
 //   bit 0      the opponent has a winning reply            (ow != 0)
 //   bits 1-6   the first winning reply f

@@ -882,6 +882,7 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
     __shared__ unsigned long long s_flegal[kTile];
     __shared__ int s_deferred;
     __shared__ uint16_t s_again[kTile * kActions];  // pairs that need the exact evaluation (greedy_reply<true>)
+    __shared__ unsigned long long s_defer[kTile];   // ... as per-board candidate sets (first round)
     GBL_STAMP(0);
     GBL_STAMP_REAL(0);
     Lane L;
@@ -894,6 +895,7 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
         L.b = L.tile * kTile + L.lane;
     }
     GreedyHead h{0ull, 0ull, 0ull, 0ull, 0, -1};
+    GreedyDom dom{0ull, {63u, 63u, 63u}, {0u, 0u, 0u}};
     uint32_t prev3 = 0x00FFFFFFu;
     int total = 0, me = 0;
     if (owner) {
@@ -936,13 +938,27 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
             s_second[L.lane] = 0ull;
             s_block[L.lane] = 0ull;
             s_flegal[L.lane] = 0ull;
-            s_work[L.lane] = h.todo & ~h.dup;  // twin placements are not evaluated a second time
+            // twin placements are not evaluated a second time, and placements from hand behind a smaller one on the
+            // same square only if that one turns out not to be calm (greedy_dominance)
+            dom = greedy_dominance(h, p, me);
+            s_work[L.lane] = dom.first;
+            s_defer[L.lane] = 0ull;
             if (L.lane == 0) s_deferred = 0;
         }
     }
     GBL_STAMP(1);
     GBL_STAMP_DECL(2);
     if (depth > 1) {
+        auto record = [&](uint32_t o, uint32_t a, uint32_t sum) {
+            if (sum & 1u) {
+                s_reply[o][a] = (uint16_t)sum;
+                atomicOr(&s_threat[o], 1ull << a);
+                if (sum & (1u << 7)) atomicOr(&s_second[o], 1ull << a);
+                if (sum & (1u << 8)) atomicOr(&s_block[o], 1ull << a);
+                if ((s_legal[o] >> ((sum >> 1) & 63u)) & 1ull) atomicOr(&s_flegal[o], 1ull << a);
+            }
+            if (sum >> 15) atomicOr(&s_allwin[o], 1ull << a);
+        };
         pool_fence<W>();
         // The pair lists, by all W wavefronts: lane = board.  One ballot per candidate compacts the boards that have
         // it (no per-lane loop, no divergence); the order of a list is irrelevant, results land in per-board sets.
@@ -975,26 +991,24 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
             }
             return s_pair[w * kSegCap + (g - start)];
         };
-        auto record = [&](uint32_t o, uint32_t a, uint32_t sum) {
-            if (sum & 1u) {
-                s_reply[o][a] = (uint16_t)sum;
-                atomicOr(&s_threat[o], 1ull << a);
-                if (sum & (1u << 7)) atomicOr(&s_second[o], 1ull << a);
-                if (sum & (1u << 8)) atomicOr(&s_block[o], 1ull << a);
-                if ((s_legal[o] >> ((sum >> 1) & 63u)) & 1ull) atomicOr(&s_flegal[o], 1ull << a);
-            }
-            if (sum >> 15) atomicOr(&s_allwin[o], 1ull << a);
-        };
         // first round: the cheap evaluation; the few pairs where a lift could hand us a line are set aside
         for (int g = slot; g < total; g += kTile * W) {
             const uint32_t pair = pair_at(g), o = pair >> 8, a = pair & 0xFFu;
             const Planes q{s_board[o][0], s_board[o][1], s_board[o][2]};
             const uint32_t sum = greedy_reply<false>(q, (int)s_board[o][3], s_legal[o], a);
-            if (sum == kGreedyDefer)
+            if (sum == kGreedyDefer) {
                 s_again[atomicAdd(&s_deferred, 1)] = (uint16_t)pair;
-            else
+                atomicOr(&s_defer[o], 1ull << a);
+            } else {
                 record(o, a, sum);
+            }
         }
+        pool_fence<W>();
+        // the placements held back behind a smaller one on the same square whose stand-in was not calm join the exact
+        // round (a couple per board: they fit the round the set-aside pairs need anyway)
+        if (owner)
+            for (uint64_t it = greedy_second_round(dom, s_threat[L.lane] | s_defer[L.lane]); it; it &= it - 1)
+                s_again[atomicAdd(&s_deferred, 1)] = (uint16_t)(((uint32_t)L.lane << 8) | (uint32_t)__builtin_ctzll(it));
         pool_fence<W>();
         GBL_STAMP_SET(2);
         const int again = s_deferred;

@@ -133,6 +133,8 @@ def greedy_act(state, to_move, hist, seed, env_base, call, mask=None, depth=2):
 
 
 def greedy_stats():
-    """(pairs evaluated, pairs deferred to the exact evaluation, cheap != exact) since the library was loaded."""
-    o = np.zeros(3, np.int64)
+    """(pairs evaluated, pairs deferred to the exact evaluation, cross-check failures -- cheap != exact, closed form !=
+    loop form, a held placement with a non-zero summary --, placements held back behind a smaller one on the same
+    square, held placements evaluated after all) since the library was loaded."""
+    o = np.zeros(5, np.int64)
     lib().emu_greedy_stats(_p(o)); return tuple(int(x) for x in o)

@@ -362,12 +362,14 @@ void emu_decode_obs(const int8_t *obs, int8_t *state, int8_t *to_move, int64_t n
 
 // statistics of the pooled flow: pairs evaluated, pairs deferred to the exact evaluation, and pairs whose
 // cheap evaluation differs from the exact one (a bug if ever non-zero)
-static int64_t g_pairs = 0, g_deferred = 0, g_fast_mismatch = 0;
+static int64_t g_pairs = 0, g_deferred = 0, g_fast_mismatch = 0, g_held = 0, g_held_back = 0;
 void emu_greedy_stats(int64_t *out)
 {
     out[0] = g_pairs;
     out[1] = g_deferred;
     out[2] = g_fast_mismatch;
+    out[3] = g_held;
+    out[4] = g_held_back;
 }
 
 // pooled != 0: the kernel's flow (candidate lists of a tile back to back, every pair evaluated by
@@ -413,10 +415,16 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
         }
         static uint16_t pair[64 * kActions], reply[64][kActions];
         uint64_t threat[64] = {0}, allwin[64] = {0}, second[64] = {0}, block[64] = {0}, flegal[64] = {0};
+        // first round: the candidates minus the placements held back behind a smaller one on the same square
+        // (greedy_dominance); the held ones whose stand-in turned out not to be calm join the exact round
+        GreedyDom DOM[64];
+        uint64_t deferred_set[64] = {0};
         int total = 0;
-        for (int l = 0; l < 64; ++l)
-            for (uint64_t it = H[l].todo & ~H[l].dup; it; it &= it - 1)
+        for (int l = 0; l < 64; ++l) {
+            DOM[l] = greedy_dominance(H[l], P[l], ME[l]);
+            for (uint64_t it = pooled ? DOM[l].first : 0ull; it; it &= it - 1)
                 pair[total++] = (uint16_t)((l << 8) | __builtin_ctzll(it));
+        }
         static uint16_t again[64 * kActions];
         int deferred = 0;
         auto record = [&](uint32_t o, uint32_t a, uint32_t sum) {
@@ -429,16 +437,34 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
             }
             if (sum >> 15) allwin[o] |= 1ull << a;
         };
-        for (int g = 0; pooled && g < total; ++g) {
-            uint32_t o = pair[g] >> 8, a = pair[g] & 0xFFu;
-            uint32_t sum = greedy_reply<false>(P[o], ME[o], H[o].legal_me, a);
-            g_pairs++;
-            if (sum == kGreedyDefer) {
-                again[deferred++] = pair[g];
-                g_deferred++;
-            } else {
-                record(o, a, sum);
-                if (sum != greedy_reply<true>(P[o], ME[o], H[o].legal_me, a)) g_fast_mismatch++;  // must stay 0
+        auto cheap_round = [&](int from, int to) {
+            for (int g = from; g < to; ++g) {
+                uint32_t o = pair[g] >> 8, a = pair[g] & 0xFFu;
+                uint32_t sum = greedy_reply<false>(P[o], ME[o], H[o].legal_me, a);
+                g_pairs++;
+                if (sum == kGreedyDefer) {
+                    again[deferred++] = pair[g];
+                    deferred_set[o] |= 1ull << a;
+                    g_deferred++;
+                } else {
+                    record(o, a, sum);
+                    if (sum != greedy_reply<true>(P[o], ME[o], H[o].legal_me, a)) g_fast_mismatch++;  // must stay 0
+                }
+            }
+        };
+        cheap_round(0, total);
+        if (pooled) {
+            for (int l = 0; l < 64; ++l) {
+                const uint64_t w0 = H[l].todo & ~H[l].dup, held = w0 & ~DOM[l].first;
+                const uint64_t second_round = greedy_second_round(DOM[l], threat[l] | deferred_set[l]);
+                if (second_round & ~held) g_fast_mismatch++;  // only held candidates can come back
+                // (they join the exact round, as in the kernel)
+                for (uint64_t it = second_round; it; it &= it - 1) again[deferred++] = (uint16_t)((l << 8) | __builtin_ctzll(it));
+                // the rule itself: a held candidate that is never evaluated has summary 0
+                for (uint64_t it = held & ~second_round; it; it &= it - 1)
+                    if (greedy_reply<true>(P[l], ME[l], H[l].legal_me, (uint32_t)__builtin_ctzll(it)) != 0) g_fast_mismatch++;
+                g_held += __builtin_popcountll(held);
+                g_held_back += __builtin_popcountll(second_round);
             }
         }
         for (int g = 0; g < deferred; ++g) {
