@@ -960,6 +960,88 @@ __device__ __forceinline__ uint64_t greedy_second_round(const GreedyDom &d, uint
     return ((uint64_t)need1 << (d.shift[1] & 63u)) | ((uint64_t)need2 << (d.shift[2] & 63u));
 }
 
+// A root position on which the OPPONENT, were it to move, has no winning move: then no placement of ours from hand
+// gives it one.  (A reply that wins after our placement on q is legal on the root too -- we only covered q -- and leaves
+// the same tops except that q is ours instead of what it was, or, if it gobbles our new piece, exactly the same tops:
+// it wins on the root as well.)  Such a placement has summary 0 unless a lift by the opponent could hand US a line
+// (reply_is_plain false), which with "have" = our tops and our pieces directly under the opponent's is the case iff
+// q completes a line inside have: the threat squares of have, or every q if have holds a line already.  So on a quiet
+// root the placements from hand on non-risky squares are not evaluated at all, and those on risky squares go straight
+// to the exact evaluation.  Half of the boards of the masked-random mix are quiet; a third of the first-round pairs go.
+struct GreedyQuiet {
+    bool quiet;          // the opponent has no winning move on the root
+    uint32_t risky;      // 9 bits: squares where a placement of ours is not "plain" (0x1FF if have already holds a line)
+    uint64_t from_hand;  // all placements of our pieces still in hand (54-bit set)
+};
+
+// all placements of `me`'s pieces that are still in hand (54-bit set)
+__device__ __forceinline__ uint64_t greedy_from_hand(const Planes &p, int me)
+{
+    const uint32_t mine = me ? (p.nz & p.neg) : (p.nz & ~p.neg);
+    uint64_t from_hand = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t lvl = (mine >> (9 * k)) & 0x1FFu, oddp = (p.odd >> (9 * k)) & 0x1FFu;
+        if ((lvl & oddp) == 0) from_hand |= 0x1FFull << (18 * k);        // piece 2k
+        if ((lvl & ~oddp) == 0) from_hand |= 0x1FFull << (18 * k + 9);   // piece 2k + 1
+    }
+    return from_hand;
+}
+
+__device__ __forceinline__ GreedyQuiet greedy_quiet_root(const Planes &p, int me)
+{
+    GreedyQuiet g;
+    uint64_t ow, ol;
+    outcomes54(p, 1 - me, ow, ol);  // (the general form: the root itself need not be free of lines)
+    g.quiet = (ow & legal54(p, 1 - me)) == 0;
+    const uint32_t mine = me ? (p.nz & p.neg) : (p.nz & ~p.neg);
+    const uint32_t othr = me ? (p.nz & ~p.neg) : (p.nz & p.neg);
+    g.from_hand = greedy_from_hand(p, me);
+    // have: as in reply_is_plain(d1, opponent) -- our tops, and ours directly below a piece of the opponent's
+    const uint32_t t0 = mine & 0x1FFu, t1 = (mine >> 9) & 0x1FFu, t2 = (mine >> 18) & 0x1FFu;
+    const uint32_t m1 = (othr >> 9) & 0x1FFu, m2 = (othr >> 18) & 0x1FFu, m0 = othr & 0x1FFu;
+    const uint32_t o1 = m1 | t1, o2 = m2 | t2;
+    const uint32_t To = t2 | (~o2 & (t1 | (~o1 & t0)));
+    const uint32_t X = (m1 & t0) | (m2 & (t1 | (~o1 & t0)));
+    const uint32_t T = (To | X) & 0x1FFu;
+    (void)m0;
+    constexpr uint32_t L[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x111u, 0x054u};
+    uint32_t risky = 0;
+    bool full = false;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        const uint32_t miss = L[l] & ~T;
+        full = full || miss == 0;
+        if ((miss & (miss - 1)) == 0) risky |= miss;  // exactly one square missing: that square completes the line
+    }
+    g.risky = full ? 0x1FFu : risky;
+    return g;
+}
+
+// The candidates' way through the kernel: `first` are evaluated cheaply in the pooled round, `exact` go straight to the
+// exact round, and greedy_second_round() names those that join it depending on the first round's results.
+struct GreedyPlan {
+    GreedyDom dom;
+    uint64_t exact;
+};
+
+__device__ __forceinline__ GreedyPlan greedy_plan(const GreedyHead &h, const Planes &p, int me, const GreedyQuiet &g)
+{
+    GreedyPlan plan;
+    if (g.quiet) {
+        const uint64_t w0 = h.todo & ~h.dup;
+        uint64_t risky54 = g.risky;
+        risky54 |= risky54 << 9;
+        risky54 |= risky54 << 18 | risky54 << 36;
+        plan.dom = GreedyDom{w0 & ~g.from_hand, {63u, 63u, 63u}, {0u, 0u, 0u}};
+        plan.exact = w0 & g.from_hand & risky54;
+    } else {
+        plan.dom = greedy_dominance(h, p, me);
+        plan.exact = 0;
+    }
+    return plan;
+}
+
 // What the depth-2 loop needs to know about candidate `a` (:107-126), packed in 16 bits:
 //   bit 0      the opponent has a winning reply            (ow != 0)
 //   bits 1-6   the first winning reply f

@@ -883,6 +883,7 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
     __shared__ int s_deferred;
     __shared__ uint16_t s_again[kTile * kActions];  // pairs that need the exact evaluation (greedy_reply<true>)
     __shared__ unsigned long long s_defer[kTile];   // ... as per-board candidate sets (first round)
+    __shared__ uint32_t s_quiet[kTile];             // per board: bit 0 quiet root, bits 1-9 risky squares (greedy_quiet_root)
     GBL_STAMP(0);
     GBL_STAMP_REAL(0);
     Lane L;
@@ -895,23 +896,41 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
         L.b = L.tile * kTile + L.lane;
     }
     GreedyHead h{0ull, 0ull, 0ull, 0ull, 0, -1};
-    GreedyDom dom{0ull, {63u, 63u, 63u}, {0u, 0u, 0u}};
-    uint32_t prev3 = 0x00FFFFFFu;
+    GreedyPlan plan{GreedyDom{0ull, {63u, 63u, 63u}, {0u, 0u, 0u}}, 0ull};
+    Planes p{0u, 0u, 0u};
+    uint32_t prev3 = 0x00FFFFFFu, h0 = 0xFFFFu, h1 = 0xFFFFu, h2 = 0xFFFFu;
     int total = 0, me = 0;
     if (owner) {
         // per-board scalars first, branch-free from a clamped index: in flight together with the tile (see k_step);
         // the history of BOTH agents (6 bytes, 2-byte aligned), the mover picks its three below
         const int64_t bs = L.valid ? L.b : n - 1;
         const int tm = to_move[bs];
-        uint32_t h0 = 0xFFFFu, h1 = 0xFFFFu, h2 = 0xFFFFu;
         if (hist) {
             const uint16_t *hp = reinterpret_cast<const uint16_t *>(hist + bs * 6);
             h0 = hp[0]; h1 = hp[1]; h2 = hp[2];
         }
         uint32_t r[7];
         load_state(state, s_state, L, r);
-        Planes p = planes_of(L, r);
+        p = planes_of(L, r);
         me = L.valid ? (tm != 0) : 0;
+        if (depth > 1) {
+            s_board[L.lane][0] = p.nz;
+            s_board[L.lane][1] = p.neg;
+            s_board[L.lane][2] = p.odd;
+            s_board[L.lane][3] = (uint32_t)me;
+        }
+    }
+    // While the owners walk depth 1, the second wavefront finds out for every board whether the OPPONENT could win on
+    // the root at once (greedy_quiet_root: as expensive as the depth-1 walk itself, and off the owners' serial path).
+    if (depth > 1 && W > 1) {
+        pool_fence<W>();
+        if ((slot >> 6) == 1) {
+            const Planes q{s_board[L.lane][0], s_board[L.lane][1], s_board[L.lane][2]};
+            const GreedyQuiet g = greedy_quiet_root(q, (int)s_board[L.lane][3]);
+            s_quiet[L.lane] = (g.quiet ? 1u : 0u) | (g.risky << 1);
+        }
+    }
+    if (owner) {
         uint64_t mask;
         if (mask_in) {
             tile_in<kActions>(mask_in + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
@@ -928,22 +947,31 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
             prev3 = me ? ((h1 >> 8) | (h2 << 8)) & 0x00FFFFFFu : (h0 | (h1 << 16)) & 0x00FFFFFFu;
         h = greedy_head(p, me, mask, depth);  // invalid lanes: empty mask, nothing to do
         if (depth > 1) {
-            s_board[L.lane][0] = p.nz;
-            s_board[L.lane][1] = p.neg;
-            s_board[L.lane][2] = p.odd;
-            s_board[L.lane][3] = (uint32_t)me;
             s_legal[L.lane] = h.legal_me;
             s_threat[L.lane] = 0ull;
             s_allwin[L.lane] = 0ull;
             s_second[L.lane] = 0ull;
             s_block[L.lane] = 0ull;
             s_flegal[L.lane] = 0ull;
-            // twin placements are not evaluated a second time, and placements from hand behind a smaller one on the
-            // same square only if that one turns out not to be calm (greedy_dominance)
-            dom = greedy_dominance(h, p, me);
-            s_work[L.lane] = dom.first;
             s_defer[L.lane] = 0ull;
             if (L.lane == 0) s_deferred = 0;
+        }
+    }
+    if (depth > 1) {
+        if (W > 1) pool_fence<W>();  // the second wavefront's verdicts are in
+        if (owner) {
+            // twin placements are not evaluated a second time; placements from hand not at all on a root where the
+            // opponent has no winning move (greedy_quiet_root), else behind a smaller one on the same square only
+            // if that one turns out not to be calm (greedy_dominance)
+            GreedyQuiet g;
+            if (W > 1) {
+                const uint32_t v = s_quiet[L.lane];
+                g = GreedyQuiet{(v & 1u) != 0, v >> 1, greedy_from_hand(p, me)};
+            } else {
+                g = greedy_quiet_root(p, me);
+            }
+            plan = greedy_plan(h, p, me, g);
+            s_work[L.lane] = plan.dom.first;
         }
     }
     GBL_STAMP(1);
@@ -1007,7 +1035,7 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
         // the placements held back behind a smaller one on the same square whose stand-in was not calm join the exact
         // round (a couple per board: they fit the round the set-aside pairs need anyway)
         if (owner)
-            for (uint64_t it = greedy_second_round(dom, s_threat[L.lane] | s_defer[L.lane]); it; it &= it - 1)
+            for (uint64_t it = greedy_second_round(plan.dom, s_threat[L.lane] | s_defer[L.lane]) | plan.exact; it; it &= it - 1)
                 s_again[atomicAdd(&s_deferred, 1)] = (uint16_t)(((uint32_t)L.lane << 8) | (uint32_t)__builtin_ctzll(it));
         pool_fence<W>();
         GBL_STAMP_SET(2);

@@ -1,3 +1,5 @@
+#include <stdlib.h>
+#include <stdio.h>
 // emu_device.cpp -- TEST INFRASTRUCTURE: compiles gobblet-rl_amd/csrc/gobblet_device.h for the
 // HOST, with shims for the handful of AMDGPU builtins it uses, and walks the same
 // tile -> LDS image -> row-per-lane -> lane body -> LDS image -> tile sequence the gfx950
@@ -418,10 +420,12 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
         // first round: the candidates minus the placements held back behind a smaller one on the same square
         // (greedy_dominance); the held ones whose stand-in turned out not to be calm join the exact round
         GreedyDom DOM[64];
+        GreedyPlan PLAN[64];
         uint64_t deferred_set[64] = {0};
         int total = 0;
         for (int l = 0; l < 64; ++l) {
-            DOM[l] = greedy_dominance(H[l], P[l], ME[l]);
+            PLAN[l] = greedy_plan(H[l], P[l], ME[l], greedy_quiet_root(P[l], ME[l]));
+            DOM[l] = PLAN[l].dom;
             for (uint64_t it = pooled ? DOM[l].first : 0ull; it; it &= it - 1)
                 pair[total++] = (uint16_t)((l << 8) | __builtin_ctzll(it));
         }
@@ -456,7 +460,7 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
         if (pooled) {
             for (int l = 0; l < 64; ++l) {
                 const uint64_t w0 = H[l].todo & ~H[l].dup, held = w0 & ~DOM[l].first;
-                const uint64_t second_round = greedy_second_round(DOM[l], threat[l] | deferred_set[l]);
+                const uint64_t second_round = greedy_second_round(DOM[l], threat[l] | deferred_set[l]) | PLAN[l].exact;
                 if (second_round & ~held) g_fast_mismatch++;  // only held candidates can come back
                 // (they join the exact round, as in the kernel)
                 for (uint64_t it = second_round; it; it &= it - 1) again[deferred++] = (uint16_t)((l << 8) | __builtin_ctzll(it));
