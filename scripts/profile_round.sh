@@ -7,6 +7,9 @@ export TMPDIR=/tmp
 O=gpurun_out/final
 rm -rf $O && mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1   # (no compiler may run under the profiler's preload)
+for m in valu_rates winner_lanes write_classes; do   # the microbenchmarks this script runs
+  [ scripts/microbench/$m -nt scripts/microbench/$m.hip ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scripts/microbench/$m scripts/microbench/$m.hip >> $O/build.log 2>&1
+done
 # ---- bench lines --------------------------------------------------------------------------------------------
 python bench.py > $O/bench_default.json
 python bench.py --gpus 1 --steps 20 --warmup 5 --no-configs --no-cpu-baseline > $O/bench_driver_cmd.json
