@@ -252,3 +252,49 @@ def test_facade_has_no_public_backend_switch():
     assert G.gobblet_v1.raw_env.metadata["is_parallelizable"] is False
     with pytest.raises(NotImplementedError):
         G.gobblet_v1.parallel_env()
+
+
+def test_placement_search_logic(monkeypatch):
+    """placement.spread_pair with a scripted probe (no GPU): it stops at the first clean pair, otherwise takes the best
+    pair it saw, alternates which array it re-allocates, honours the probe and spacer budgets, probes a new candidate
+    against one representative unless that pair is in between, and returns zero-filled arrays."""
+    import torch
+    from gobblet_rl_amd import placement
+
+    made = {"a": 0, "b": 0}
+
+    def make(kind):
+        def f():
+            made[kind] += 1
+            return torch.full((1024,), made[kind], dtype=torch.uint8)  # (the value tells which candidate it is)
+        return f
+
+    def run(ratios, **kw):
+        made["a"] = made["b"] = 0
+        script, seen = list(ratios), []
+
+        def fake_probe(a, b, slot_boards=0, plies=0):
+            seen.append((int(a[0]), int(b[0]), slot_boards, plies))
+            r = script.pop(0) if script else 1.0
+            return 100.0 * r, 60.0, 40.0
+
+        monkeypatch.setattr(placement, "probe", fake_probe)
+        monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (1 << 40, 1 << 40))
+        a, b, info = placement.spread_pair(make("a"), make("b"), step_bytes=1 << 16, **kw)
+        assert int(a.max()) == 0 and int(b.max()) == 0   # handed back zero-filled
+        return seen, info
+
+    seen, info = run([0.80])                              # clean at once: one probe, nothing skipped
+    assert seen == [(1, 1, 0, 0)] and info["probes"] == [0.8] and info["skipped_gib"] == 0 and info["spread"]
+    seen, info = run([1.0, 0.99, 1.0, 0.81], slot_boards=1024, plies=8)
+    # a new mask array, then a new observation array, then a new mask array: each against the other's first candidate
+    assert [s[:2] for s in seen] == [(1, 1), (1, 2), (2, 1), (1, 3)] and all(s[2:] == (1024, 8) for s in seen)
+    assert info["ratio"] == 0.81 and info["spread"] and len(info["probes"]) == 4
+    seen, info = run([1.0, 0.94, 0.93])                   # in between (0.94): the new array also meets the other candidates
+    assert [s[:2] for s in seen][:4] == [(1, 1), (1, 2), (2, 1), (2, 2)]
+    seen, info = run([1.0] * 40)                          # never clean: the probe budget ends the search, best = first
+    assert len(seen) == placement.MAX_PROBES and info["ratio"] == 1.0 and not info["spread"]
+    seen, info = run([1.0, 0.97, 0.9, 0.95, 0.99], max_probes=5)
+    assert info["ratio"] == 0.9 and info["spread"] and len(seen) == 5
+    seen, info = run([1.0] * 40, max_skip_bytes=3 << 16)  # the spacer budget: three steps of 64 KiB
+    assert len(seen) == 4 and info["skipped_gib"] == 0
