@@ -132,10 +132,10 @@ def cpu_baseline(boards, warmup, target_s):
 
 def auto_traj(boards, steps, requested=0):
     """Plies per gbl_collect launch: the requested value, or by shard size (large shards: shorter launches, so that a
-    launch's tail -- its last generation of wavefronts draining -- stays small; they never get more than half of a
-    timed run); never more than the timed run."""
+    launch's tail -- its last generation of wavefronts draining -- stays small; chosen automatically they never get
+    more than half of a timed run); never more than the timed run."""
     t = requested if requested > 0 else (8 if boards >= (1 << 19) else 16 if boards >= (1 << 18) else 32)
-    if boards >= (1 << 19):
+    if boards >= (1 << 19) and requested <= 0:
         t = min(t, max(1, steps // 2))
     return max(1, min(t, steps))
 
