@@ -383,7 +383,9 @@ __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, bool ma
 // gbl_step: fused raw_env.step + observe(next mover) over a tile of boards.
 // (argument order: what a wavefront needs first comes first -- the first 16 dwords are preloaded into SGPRs at
 // wave launch, -amdgpu-kernarg-preload-count, so the tile loads do not wait for a kernel-argument fetch)
-template <bool WITH_MASK, bool WITH_OBS, int NT>
+// INTO: gbl_step_into -- the ply's scalars also go to a trajectory slot (a template parameter: as run-time tests of
+// three more pointers the plain step paid 0.5 us at 2^20 boards)
+template <bool WITH_MASK, bool WITH_OBS, int NT, bool INTO>
 __global__ __launch_bounds__(64 * kStepWaves) void k_step(int8_t *__restrict__ state, int8_t *__restrict__ to_move,
                                              int8_t *__restrict__ done, const int32_t *__restrict__ actions,
                                              int64_t n, int64_t ntiles, int illegal_mode, int auto_reset,
@@ -421,10 +423,11 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_step(int8_t *__restrict__ s
         if (reward_out)
             reinterpret_cast<uint16_t *>(reward_out)[L.b] = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
         if (turn) turn[L.b] = next_turn(turn[L.b], y, auto_reset);
-        // gbl_step_into: the ply's scalars also into a trajectory slot
-        if (actions_copy) actions_copy[L.b] = action;
-        if (done_copy) done_copy[L.b] = (int8_t)dn;
-        if (to_move_copy) to_move_copy[L.b] = (int8_t)mover;
+        if (INTO) {
+            if (actions_copy) actions_copy[L.b] = action;
+            if (done_copy) done_copy[L.b] = (int8_t)dn;
+            if (to_move_copy) to_move_copy[L.b] = (int8_t)mover;
+        }
     }
 }
 
@@ -1271,19 +1274,24 @@ int gbl_step_into(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *a
     hipStream_t s = (hipStream_t)stream;
     auto_reset = auto_reset != 0;
     const int nt = nt_policy(n);
-#define GBL_STEP_NT(M, O, NT)                                                                                       \
-    hipLaunchKernelGGL((k_step<M, O, NT>), dim3(g.grid), dim3(64 * kStepWaves), 0, s, state, to_move, done, actions, \
-                       n, g.ntiles, illegal_mode, auto_reset, winner_out, reward_out, mask_out, obs_out, turn,      \
+    const bool into = actions_out || done_out || to_move_out;
+#define GBL_STEP_I(M, O, NT, I)                                                                                          \
+    hipLaunchKernelGGL((k_step<M, O, NT, I>), dim3(g.grid), dim3(64 * kStepWaves), 0, s, state, to_move, done, actions, \
+                       n, g.ntiles, illegal_mode, auto_reset, winner_out, reward_out, mask_out, obs_out, turn,         \
                        actions_out, done_out, to_move_out)
+#define GBL_STEP_NT(M, O, NT)                                   \
+    if (into) GBL_STEP_I(M, O, NT, true);                       \
+    else GBL_STEP_I(M, O, NT, false)
 #define GBL_STEP(M, O)                                          \
-    if (nt == 3) GBL_STEP_NT(M, O, 3);                          \
-    else GBL_STEP_NT(M, O, 1);
+    if (nt == 3) { GBL_STEP_NT(M, O, 3); }                      \
+    else { GBL_STEP_NT(M, O, 1); }
     if (mask_out && obs_out) GBL_STEP(true, true)
     else if (mask_out) GBL_STEP(true, false)
     else if (obs_out) GBL_STEP(false, true)
     else GBL_STEP(false, false)
 #undef GBL_STEP
 #undef GBL_STEP_NT
+#undef GBL_STEP_I
     GBL_LAUNCHED("gbl_step");
 }
 
