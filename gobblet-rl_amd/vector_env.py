@@ -244,7 +244,14 @@ class BatchedGobblet:
         probeable = self.observation is not None and cells * nat.ACTIONS >= _placement.MIN_BYTES
         if placement == "spread" and not probeable:
             raise ValueError("placement='spread' needs an observation trajectory and at least 64 MiB of mask trajectory")
-        if placement != "any" and probeable:
+        capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if capturing and placement == "spread":
+            raise ValueError("placement='spread' probes and synchronises: not inside a graph capture")
+        if placement != "any" and probeable and capturing:
+            # (the probe synchronises, which would break the capture: buffers made inside one lie as allocated)
+            full["observation"], full["action_mask"] = make_obs(), make_mask()
+            placed["why"] = "inside a graph capture"
+        elif placement != "any" and probeable:
             geometry = dict(slot_boards=ply_stride, plies=T) if layout == "time" and ply_stride % 128 == 0 else {}
             full["observation"], full["action_mask"], placed = _placement.spread_pair(make_obs, make_mask, **geometry)
         else:

@@ -1059,6 +1059,20 @@ def test_placement_probe_and_spread_buffers(G):
     for key in ("actions", "winner", "rewards", "done", "to_move", "action_mask", "observation"):
         assert torch.equal(spread[key], plain[key]), key
     assert torch.equal(e1.squares, e2.squares)
+    # inside a graph capture nothing may synchronise: buffers made there are not probed (and the capture survives)
+    e3 = G.BatchedGobblet(n, DEV, **kw)
+    e3.device_ply()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            tr = e3.collect(T, refresh=False)
+            e3.advance_ply()
+        g.replay()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert tr["_placement"]["why"] == "inside a graph capture" and torch.equal(tr["actions"], plain["actions"])
     with pytest.raises(ValueError):
         G.BatchedGobblet(64, DEV, auto_reset=True).trajectory_buffers(4, placement="spread")  # too small to probe
     small = G.BatchedGobblet(64, DEV, auto_reset=True).trajectory_buffers(4)
