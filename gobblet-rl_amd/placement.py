@@ -37,9 +37,11 @@ def probe(a: torch.Tensor, b: torch.Tensor, slot_boards: int = 0, plies: int = 0
     """(us_both, us_a, us_b) of ``gbl_placement_probe`` on two device tensors; slot_boards / plies: the geometry of the
     time-major trajectory they will hold (0: four slots over the smaller one).  OVERWRITES both with zeros."""
     both, ua, ub = C.c_float(), C.c_float(), C.c_float()
-    nat.check(nat.lib().gbl_placement_probe(a.data_ptr(), a.numel() * a.element_size(), b.data_ptr(),
-                                            b.numel() * b.element_size(), int(slot_boards), int(plies), C.byref(both),
-                                            C.byref(ua), C.byref(ub), nat.current_stream(a.device)), "gbl_placement_probe")
+    with torch.cuda.device(a.device):  # (the probe creates events and launches: on the arrays' device)
+        nat.check(nat.lib().gbl_placement_probe(a.data_ptr(), a.numel() * a.element_size(), b.data_ptr(),
+                                                b.numel() * b.element_size(), int(slot_boards), int(plies),
+                                                C.byref(both), C.byref(ua), C.byref(ub),
+                                                nat.current_stream(a.device)), "gbl_placement_probe")
     return both.value, ua.value, ub.value
 
 
