@@ -8,7 +8,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libgobblet_emu.so")
-_SRCS = [os.path.join(_HERE, "emu_device.cpp"),
+_SRCS = [os.path.join(_HERE, "emu_device.cpp"), os.path.join(_HERE, "greedy_root_rule.h"),
          os.path.join(_HERE, "..", "..", "gobblet-rl_amd", "csrc", "gobblet_device.h")]
 
 
@@ -130,6 +130,16 @@ def greedy_act(state, to_move, hist, seed, env_base, call, mask=None, depth=2):
     lib().emu_greedy(_p(state), _p(to_move), _p(mask), None, C.c_int(depth), _p(act), _p(cm), _p(fb), C.c_int64(n),
                      C.c_int(1), _p(hist), _p(out), C.c_uint64(seed), C.c_uint64(env_base), C.c_uint32(call))
     return out, act, cm, fb
+
+
+def greedy_root_rule(state, to_move, mask=None):
+    """tests/emu/greedy_root_rule.h against the exact evaluation: (boards, candidates settled from the root, of them with
+    a winning reply, placements left to the exact evaluation, mismatches)."""
+    n = len(to_move)
+    o = np.zeros(5, np.int64)
+    lib().emu_greedy_root_rule(_p(np.ascontiguousarray(state)), _p(np.ascontiguousarray(to_move)),
+                               None if mask is None else _p(np.ascontiguousarray(mask)), C.c_int64(n), _p(o))
+    return tuple(int(x) for x in o)
 
 
 def greedy_stats():

@@ -38,6 +38,7 @@ static uint32_t g_next_d0[64];  // what lane l receives from __shfl_down(d[0], 1
 #define __shfl_down(v, delta) (g_next_d0[lane])
 
 #include "../../gobblet-rl_amd/csrc/gobblet_device.h"
+#include "greedy_root_rule.h"
 
 using namespace gbl;
 
@@ -365,6 +366,42 @@ void emu_decode_obs(const int8_t *obs, int8_t *state, int8_t *to_move, int64_t n
 // statistics of the pooled flow: pairs evaluated, pairs deferred to the exact evaluation, and pairs whose
 // cheap evaluation differs from the exact one (a bug if ever non-zero)
 static int64_t g_pairs = 0, g_deferred = 0, g_fast_mismatch = 0, g_held = 0, g_held_back = 0;
+// The rule of greedy_root_rule.h against the exact evaluation, on every candidate it would settle.
+// out: boards, candidates settled from the root, of them with a winning reply, placements sent to the exact evaluation
+// (risky squares), MISMATCHES (summary or candidate-set bits differ from greedy_reply<true>: must be 0)
+void emu_greedy_root_rule(const int8_t *state, const int8_t *to_move, const int8_t *mask_in, int64_t n, int64_t *out)
+{
+    for (int k = 0; k < 5; ++k) out[k] = 0;
+    for (int64_t b = 0; b < n; ++b) {
+        uint32_t r[7] = {0, 0, 0, 0, 0, 0, 0};
+        memcpy(r, state + b * kCells, kCells);
+        const Planes p = make_planes(r);
+        const int me = to_move[b] != 0;
+        uint64_t mask = legal54(p, me);
+        if (mask_in) {
+            mask = 0;
+            for (int a = 0; a < kActions; ++a) mask |= (uint64_t)(mask_in[b * kActions + a] != 0) << a;
+        }
+        const GreedyHead h = greedy_head(p, me, mask, 2);
+        const GreedyRoot g = greedy_root(p, me);
+        const uint64_t w0 = h.todo & ~h.dup, hand = w0 & greedy_from_hand(p, me), resolved = hand & ~spread9(g.risky);
+        const GreedyHandSets hs = greedy_hand_sets(p, me, g.replies, h.legal_me);
+        out[0]++;
+        out[3] += __builtin_popcountll(hand & ~resolved);
+        for (uint64_t it = resolved; it; it &= it - 1) {
+            const uint32_t a = (uint32_t)__builtin_ctzll(it);
+            const uint32_t want = greedy_reply<true>(p, me, h.legal_me, a);
+            const uint32_t got = greedy_hand_summary(p, me, g.replies, h.legal_me, a);
+            const bool fl = (want & 1u) && ((h.legal_me >> ((want >> 1) & 63u)) & 1ull);
+            out[1]++;
+            out[2] += want & 1u;
+            if (want != got || ((hs.threat >> a) & 1ull) != (want & 1u) || ((hs.second >> a) & 1ull) != ((want >> 7) & 1u) ||
+                ((hs.block >> a) & 1ull) != ((want >> 8) & 1u) || ((hs.flegal >> a) & 1ull) != (fl ? 1u : 0u))
+                out[4]++;
+        }
+    }
+}
+
 void emu_greedy_stats(int64_t *out)
 {
     out[0] = g_pairs;

@@ -267,3 +267,18 @@ def test_greedy_policy_step_selfplay():
         a = np.where(d1 != 0, 0, o[0]).astype(np.int32)
         oracle.batch_step(s1, t1, d1, a, auto_reset=True)
     assert fallbacks > 100 and (h_ora >= 0).all()
+
+
+def test_greedy_root_rule(boards):
+    """tests/emu/greedy_root_rule.h (not in the product yet): the summaries of our placements from hand,
+    derived from the opponent's winning moves on the ROOT alone, equal the exact depth-2 evaluation on every candidate --
+    selfplay positions, the dense random boards of the golden set (both movers), restricted masks."""
+    state, tm, dn, rng = selfplay_states(8000, 30, seed=11)
+    live = oracle.batch_winner(state) == 0
+    dense = boards["squares"][boards["winner"] == 0]
+    state = np.ascontiguousarray(np.concatenate([state[live], dense, dense]))
+    tm = np.ascontiguousarray(np.concatenate([tm[live], np.zeros(len(dense), np.int8), np.ones(len(dense), np.int8)]))
+    n_boards, settled, threatened, left, bad = emu.greedy_root_rule(state, tm)
+    assert bad == 0 and n_boards == len(state) and settled > 8 * n_boards and threatened > 0.2 * settled and left > 0
+    m = np.ascontiguousarray((oracle.batch_legal_mask(state, tm) * (rng.random((len(state), 54)) < 0.6)).astype(np.int8))
+    assert emu.greedy_root_rule(state, tm, mask=m)[4] == 0
