@@ -65,18 +65,24 @@ def main():
     traffic = {}
     rows = ["kernel,counter,dispatches,mean_value_KB"]
     for key, run, kernel in (("collect:1048576:T8", "collect", "k_collect<true, true"),
-                             ("fused:1048576", "single", "k_rollout<true, true")):
+                             ("fused:1048576", "single", "k_rollout<true, true"),
+                             ("collect:131072:T32", "shard_131072_T32", "k_collect2<true, true"),
+                             ("collect:131072:T20", "shard_131072_T20", "k_collect2<true, true"),
+                             ("collect:262144:T16", "shard_262144_T16", "k_collect<true, true"),
+                             ("collect:524288:T8", "shard_524288_T8", "k_collect<true, true")):
+        if not os.path.exists(os.path.join(SRC, f"{run}_pmc_FETCH_SIZE", "p_results.db")):
+            continue
         kb = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             kb[c], n = counter_mean(os.path.join(SRC, f"{run}_pmc_{c}", "p_results.db"), kernel, c)
-            rows.append(f"{kernel.replace(',', ';')},{c},{n},{kb[c]:.3f}")
+            rows.append(f"{kernel.replace(',', ';')} [{key}],{c},{n},{kb[c]:.3f}")
         traffic[key] = {
             # gfx950 reports half of wide coalesced reads (MI355X_MICROARCH.md): FETCH_SIZE is doubled
             "hbm_bytes_per_launch": (2 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024,
             "FETCH_SIZE_KB": kb["FETCH_SIZE"], "WRITE_SIZE_KB": kb["WRITE_SIZE"], "kernel_source_hash": khash,
             "source": f"profiles/{rnd}/pmc_summary.csv",
-            "note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, eager launches of {kernel}...>, 2^20 "
-                    f"boards; FETCH_SIZE doubled per MI355X_MICROARCH.md (scripts/profile_round.sh + profile_collect.py)"}
+            "note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, eager launches of {kernel}...>, "
+                    f"{key.split(':')[1]} boards; FETCH_SIZE doubled per MI355X_MICROARCH.md (scripts/profile_round.sh + profile_collect.py)"}
     open(os.path.join(dst, "pmc_summary.csv"), "w").write("\n".join(rows) + "\n")
     # ---- SQ counters ------------------------------------------------------------------------------------------------
     for m, kernel, what in (("traj", "k_collect<true, true", "gbl_collect FULL, 8 plies per launch, 2^20 boards"),

@@ -50,6 +50,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d $O/collect_pmc_$c -o p -- python3 scripts/run_eager.py traj 1048576 6 8 > $O/collect_pmc_$c.log 2>&1
   rocprofv3 --pmc $c -d $O/single_pmc_$c -o p -- python3 scripts/run_eager.py full 1048576 20 > $O/single_pmc_$c.log 2>&1
 done
+# (the shards of BASELINE C4 at 8 / 4 / 2 GPUs, at the plies per launch bench.py picks for --steps 1000 and for --steps 20)
+for cfg in "131072 32" "131072 20" "262144 16" "524288 8"; do
+  set -- $cfg
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c -d $O/shard_$1_T$2_pmc_$c -o p -- python3 scripts/run_eager.py traj $1 6 $2 > $O/shard_$1_T$2_pmc_$c.log 2>&1
+  done
+done
 # ---- SQ counters ------------------------------------------------------------------------------------------------
 SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES"
 SQ2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
