@@ -9,10 +9,12 @@ process usually come from the same class, which made the trajectory stream 20 % 
 
 A process cannot see physical addresses, so the class is measured: ``gbl_placement_probe`` replays the kernel's store
 pattern on two buffers (both, a alone, b alone; ratio both / (a + b) ~1.0 inside one class, ~0.80 across two, in between
-when an array itself straddles two classes).  ``spread_pair`` keeps a small pool of candidates for either array --
-every new candidate allocated behind an 8 GiB spacer, so that it comes from another of the driver's physical blocks
-(the class changes every 8-64 GiB along a process's allocations) -- probes the new candidate against the pool of the
-other array, stops at the first clean pair, and releases everything else (spacers included) at the end."""
+when an array itself straddles two classes).  ``spread_pair`` carves either array from the start of a BLOCK of its own
+(a power of two of at least 2 GiB, one ``hipMalloc``): small allocations of a process all come from one neighbourhood
+of physical memory whatever is allocated in between (twelve candidates behind 8 GiB spacers each: the same ratio twelve
+times), whereas blocks of 2 GiB and more come from all over the device and change class every few blocks.  It keeps a
+small pool of blocks for either array, probes a new one against the other array's first, stops at the first clean pair
+and releases the other blocks at the end."""
 from __future__ import annotations
 
 import ctypes as C
@@ -27,10 +29,10 @@ MIN_BYTES = 64 << 20       # below this a probe says nothing (and the arrays liv
 ACCEPT_RATIO = 0.83        # stop searching at a pair this good (us_both / (us_a + us_b)); 0.86 already costs 3 %
 SPREAD_RATIO = 0.93        # reported as "spread" below this
 SAME_RATIO = 0.96          # above this the pair simply shares a class
-STEP_BYTES = 8 * GIB
-MAX_SKIP_BYTES = 96 * GIB  # spacers held at most, transiently (a class is 96 GiB)
+MIN_BLOCK_BYTES = 2 * GIB  # an array is carved from a block of its own of at least this size
+MAX_HOLD_BYTES = 64 * GIB  # blocks held at most while searching
 MAX_PROBES = 16
-RESERVE_BYTES = 4 * GIB    # never take the device's last few GiB for spacers
+RESERVE_BYTES = 4 * GIB    # never take the device's last few GiB for the search
 
 
 def probe(a: torch.Tensor, b: torch.Tensor, slot_boards: int = 0, plies: int = 0) -> tuple[float, float, float]:
@@ -45,39 +47,47 @@ def probe(a: torch.Tensor, b: torch.Tensor, slot_boards: int = 0, plies: int = 0
     return both.value, ua.value, ub.value
 
 
-def spread_pair(make_a, make_b, step_bytes: int = STEP_BYTES, max_skip_bytes: int = MAX_SKIP_BYTES,
-                max_probes: int = MAX_PROBES, slot_boards: int = 0, plies: int = 0):
-    """``(a, b) = (make_a(), make_b())`` placed so that writes to ``a`` and to ``b`` overlap.  Returns (a, b, info);
-    info records every probe.  Both arrays come back zero-filled.  If no pair is clean, the best one seen is returned."""
+def block_bytes(nbytes: int) -> int:
+    """The block an array of nbytes is carved from: a power of two, at least MIN_BLOCK_BYTES."""
+    return max(MIN_BLOCK_BYTES, 1 << max(0, int(nbytes) - 1).bit_length())
+
+
+def spread_pair(bytes_a: int, bytes_b: int, device, slot_boards: int = 0, plies: int = 0, max_probes: int = MAX_PROBES,
+                max_hold_bytes: int = MAX_HOLD_BYTES, alloc=None):
+    """Two zero-filled uint8 tensors of bytes_a / bytes_b bytes on `device` (each the head of a block of its own, see the
+    module docstring), placed so that writes to them overlap.  Returns (a, b, info); info records every probe.  If no
+    pair is clean, the best one seen is returned.  alloc(nbytes): the allocator (tests script it)."""
     t0 = time.perf_counter()
-    pool = {"a": [make_a()], "b": [make_b()]}
-    dev = pool["a"][0].device
-    tried, spacers, skipped = [], [], 0
+    dev = torch.device(device)
+    alloc = alloc or (lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=dev))
+    size = {"a": int(bytes_a), "b": int(bytes_b)}
+    block = {k: block_bytes(v) for k, v in size.items()}
+    pool = {"a": [alloc(block["a"])], "b": [alloc(block["b"])]}
+    held = block["a"] + block["b"]
+    tried = []
     best = (None, 0, 0)  # ratio, index into pool a, index into pool b
 
     def try_pair(ia, ib):
         nonlocal best
-        us_both, us_a, us_b = probe(pool["a"][ia], pool["b"][ib], slot_boards, plies)
+        us_both, us_a, us_b = probe(pool["a"][ia][:size["a"]], pool["b"][ib][:size["b"]], slot_boards, plies)
         ratio = us_both / max(us_a + us_b, 1e-9)
         tried.append(round(ratio, 3))
         if best[0] is None or ratio < best[0]:
             best = (ratio, ia, ib)
 
     try_pair(0, 0)
-    grow = "b"  # candidates are added alternately: a new mask array first (the smaller one)
+    grow = "b"  # blocks are added alternately: one for the mask array first (the smaller one)
     while best[0] > ACCEPT_RATIO and len(tried) < max_probes:
-        nbytes = sum(t.numel() * t.element_size() for t in (pool["a"][0], pool["b"][0]))
-        free, _ = torch.cuda.mem_get_info(dev)
-        if skipped + step_bytes > max_skip_bytes or free < step_bytes + RESERVE_BYTES + nbytes:
+        free = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else 1 << 62
+        if held + block[grow] > max_hold_bytes or free < block[grow] + RESERVE_BYTES:
             break
         try:
-            spacers.append(torch.empty(step_bytes, dtype=torch.uint8, device=dev))
-            pool[grow].append(make_a() if grow == "a" else make_b())
+            pool[grow].append(alloc(block[grow]))
         except torch.OutOfMemoryError:
             break
-        skipped += step_bytes
+        held += block[grow]
         new, other = len(pool[grow]) - 1, "b" if grow == "a" else "a"
-        # against the other array's first candidate; against the rest only if that pair is neither clean nor a plain
+        # against the other array's first block; against the rest only if that pair is neither clean nor a plain
         # conflict (an array that straddles two classes), since all members of a pool probed alike so far
         for k in range(len(pool[other])):
             if best[0] <= ACCEPT_RATIO or len(tried) >= max_probes or (k > 0 and tried[-1] > SAME_RATIO):
@@ -85,11 +95,12 @@ def spread_pair(make_a, make_b, step_bytes: int = STEP_BYTES, max_skip_bytes: in
             try_pair(*((new, k) if grow == "a" else (k, new)))
         grow = other
     ratio, ia, ib = best
-    a, b = pool["a"][ia], pool["b"][ib]
+    a, b = pool["a"][ia][:size["a"]], pool["b"][ib][:size["b"]]
     a.zero_(); b.zero_()  # (a probe writes only zeros, but say so explicitly)
-    released = len(spacers) + len(pool["a"]) + len(pool["b"]) - 2
-    pool.clear(); spacers.clear()
-    if released:
-        torch.cuda.empty_cache()  # hand the spacers and rejected candidates back to the driver
+    released = len(pool["a"]) + len(pool["b"]) - 2
+    pool.clear()
+    if released and dev.type == "cuda":
+        torch.cuda.empty_cache()  # hand the rejected blocks back to the driver
     return a, b, {"spread": bool(ratio <= SPREAD_RATIO), "ratio": round(ratio, 3), "probes": tried,
-                  "skipped_gib": skipped // GIB, "seconds": round(time.perf_counter() - t0, 3)}
+                  "block_gib": [block["a"] / GIB, block["b"] / GIB], "held_gib": round(held / GIB, 1),
+                  "seconds": round(time.perf_counter() - t0, 3)}

@@ -39,8 +39,8 @@ for rnd in range(3):
     both, ua, ub = placement.probe(env.observation.view(-1), env.action_mask.view(-1))
     env.refresh()
     t_any = timed(env)
-    obs, mask, info = placement.spread_pair(lambda: torch.zeros((n, 3, 3, 13), dtype=torch.int8, device=dev),
-                                            lambda: torch.zeros((n, 54), dtype=torch.int8, device=dev))
+    a, b, info = placement.spread_pair(n * 117, n * 54, dev)
+    obs, mask = a.view(torch.int8).view(n, 3, 3, 13), b.view(torch.int8).view(n, 54)
     env2 = G.BatchedGobblet(n, dev, auto_reset=True, seed=0)
     env2.observation, env2.action_mask = obs, mask
     env2.refresh()

@@ -255,22 +255,21 @@ def test_facade_has_no_public_backend_switch():
 
 
 def test_placement_search_logic(monkeypatch):
-    """placement.spread_pair with a scripted probe (no GPU): it stops at the first clean pair, otherwise takes the best
-    pair it saw, alternates which array it re-allocates, honours the probe and spacer budgets, probes a new candidate
-    against one representative unless that pair is in between, and returns zero-filled arrays."""
+    """placement.spread_pair with a scripted probe and allocator (no GPU): either array is the head of a block of its
+    own; it stops at the first clean pair, otherwise takes the best pair it saw, alternates which array gets a new
+    block, honours the probe and memory budgets, probes a new block against one representative unless that pair is in
+    between, and returns zero-filled arrays of the sizes asked for."""
     import torch
     from gobblet_rl_amd import placement
 
-    made = {"a": 0, "b": 0}
+    made = []
 
-    def make(kind):
-        def f():
-            made[kind] += 1
-            return torch.full((1024,), made[kind], dtype=torch.uint8)  # (the value tells which candidate it is)
-        return f
+    def alloc(nbytes):
+        made.append(nbytes)
+        return torch.full((4096,), len(made), dtype=torch.uint8)  # (a stand-in for the block; the value tells which)
 
     def run(ratios, **kw):
-        made["a"] = made["b"] = 0
+        made.clear()
         script, seen = list(ratios), []
 
         def fake_probe(a, b, slot_boards=0, plies=0):
@@ -279,22 +278,23 @@ def test_placement_search_logic(monkeypatch):
             return 100.0 * r, 60.0, 40.0
 
         monkeypatch.setattr(placement, "probe", fake_probe)
-        monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (1 << 40, 1 << 40))
-        a, b, info = placement.spread_pair(make("a"), make("b"), step_bytes=1 << 16, **kw)
-        assert int(a.max()) == 0 and int(b.max()) == 0   # handed back zero-filled
+        a, b, info = placement.spread_pair(1000, 500, "cpu", alloc=alloc, **kw)
+        assert a.numel() == 1000 and b.numel() == 500 and int(a.max()) == 0 and int(b.max()) == 0
+        assert all(m == placement.MIN_BLOCK_BYTES for m in made)   # (blocks: powers of two of at least 2 GiB)
         return seen, info
 
-    seen, info = run([0.80])                              # clean at once: one probe, nothing skipped
-    assert seen == [(1, 1, 0, 0)] and info["probes"] == [0.8] and info["skipped_gib"] == 0 and info["spread"]
+    assert placement.block_bytes(1) == 2 << 30 and placement.block_bytes((2 << 30) + 1) == 4 << 30 and placement.block_bytes(4 << 30) == 4 << 30
+    seen, info = run([0.80])                              # clean at once: one probe, two blocks
+    assert seen == [(1, 2, 0, 0)] and info["probes"] == [0.8] and info["held_gib"] == 4.0 and info["spread"]
     seen, info = run([1.0, 0.99, 1.0, 0.81], slot_boards=1024, plies=8)
-    # a new mask array, then a new observation array, then a new mask array: each against the other's first candidate
-    assert [s[:2] for s in seen] == [(1, 1), (1, 2), (2, 1), (1, 3)] and all(s[2:] == (1024, 8) for s in seen)
+    # a new mask block (3), then a new observation block (4), then a new mask block (5): each against the other's first
+    assert [s[:2] for s in seen] == [(1, 2), (1, 3), (4, 2), (1, 5)] and all(s[2:] == (1024, 8) for s in seen)
     assert info["ratio"] == 0.81 and info["spread"] and len(info["probes"]) == 4
-    seen, info = run([1.0, 0.94, 0.93])                   # in between (0.94): the new array also meets the other candidates
-    assert [s[:2] for s in seen][:4] == [(1, 1), (1, 2), (2, 1), (2, 2)]
+    seen, info = run([1.0, 0.94, 0.93])                   # in between (0.93): the new block also meets the other blocks
+    assert [s[:2] for s in seen][:4] == [(1, 2), (1, 3), (4, 2), (4, 3)]
     seen, info = run([1.0] * 40)                          # never clean: the probe budget ends the search, best = first
     assert len(seen) == placement.MAX_PROBES and info["ratio"] == 1.0 and not info["spread"]
     seen, info = run([1.0, 0.97, 0.9, 0.95, 0.99], max_probes=5)
     assert info["ratio"] == 0.9 and info["spread"] and len(seen) == 5
-    seen, info = run([1.0] * 40, max_skip_bytes=3 << 16)  # the spacer budget: three steps of 64 KiB
-    assert len(seen) == 4 and info["skipped_gib"] == 0
+    seen, info = run([1.0] * 40, max_hold_bytes=10 << 30)  # the memory budget: five blocks of 2 GiB
+    assert len(seen) == 4 and info["held_gib"] == 10.0
