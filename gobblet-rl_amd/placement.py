@@ -13,8 +13,9 @@ when an array itself straddles two classes).  ``spread_pair`` carves either arra
 (a power of two of at least 2 GiB, one ``hipMalloc``): small allocations of a process all come from one neighbourhood
 of physical memory whatever is allocated in between (twelve candidates behind 8 GiB spacers each: the same ratio twelve
 times), whereas blocks of 2 GiB and more come from all over the device and change class every few blocks.  It keeps a
-small pool of blocks for either array, probes a new one against the other array's first, stops at the first clean pair
-and releases the other blocks at the end."""
+small pool of blocks for either array, probes a new one against the other array's first -- leaving a gap of 2, 4, 8 ...
+GiB in front of it after every plain conflict, because on a fresh device consecutive blocks can stay inside one 96 GiB
+class -- stops at the first clean pair and releases the other blocks and the gaps at the end."""
 from __future__ import annotations
 
 import ctypes as C
@@ -30,7 +31,8 @@ ACCEPT_RATIO = 0.83        # stop searching at a pair this good (us_both / (us_a
 SPREAD_RATIO = 0.93        # reported as "spread" below this
 SAME_RATIO = 0.96          # above this the pair simply shares a class
 MIN_BLOCK_BYTES = 2 * GIB  # an array is carved from a block of its own of at least this size
-MAX_HOLD_BYTES = 64 * GIB  # blocks held at most while searching
+MAX_HOLD_BYTES = 144 * GIB # blocks and gaps held at most while searching (a class is 96 GiB)
+MAX_SKIP_BYTES = 32 * GIB  # the largest single gap
 MAX_PROBES = 16
 RESERVE_BYTES = 4 * GIB    # never take the device's last few GiB for the search
 
@@ -77,11 +79,18 @@ def spread_pair(bytes_a: int, bytes_b: int, device, slot_boards: int = 0, plies:
 
     try_pair(0, 0)
     grow = "b"  # blocks are added alternately: one for the mask array first (the smaller one)
+    skips, skip = [], MIN_BLOCK_BYTES
     while best[0] > ACCEPT_RATIO and len(tried) < max_probes:
         free = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else 1 << 62
         if held + block[grow] > max_hold_bytes or free < block[grow] + RESERVE_BYTES:
             break
         try:
+            # On a fresh device consecutive blocks can stay inside one class for tens of GiB (a class is 96 GiB): after a
+            # plain conflict leave a gap first, twice as large each time
+            if tried[-1] > SAME_RATIO and held + skip + block[grow] <= max_hold_bytes and free >= skip + block[grow] + RESERVE_BYTES:
+                skips.append(alloc(skip))
+                held += skip
+                skip = min(2 * skip, MAX_SKIP_BYTES)
             pool[grow].append(alloc(block[grow]))
         except torch.OutOfMemoryError:
             break
@@ -97,8 +106,9 @@ def spread_pair(bytes_a: int, bytes_b: int, device, slot_boards: int = 0, plies:
     ratio, ia, ib = best
     a, b = pool["a"][ia][:size["a"]], pool["b"][ib][:size["b"]]
     a.zero_(); b.zero_()  # (a probe writes only zeros, but say so explicitly)
-    released = len(pool["a"]) + len(pool["b"]) - 2
+    released = len(pool["a"]) + len(pool["b"]) - 2 + len(skips)
     pool.clear()
+    skips.clear()
     if released and dev.type == "cuda":
         torch.cuda.empty_cache()  # hand the rejected blocks back to the driver
     return a, b, {"spread": bool(ratio <= SPREAD_RATIO), "ratio": round(ratio, 3), "probes": tried,

@@ -280,21 +280,26 @@ def test_placement_search_logic(monkeypatch):
         monkeypatch.setattr(placement, "probe", fake_probe)
         a, b, info = placement.spread_pair(1000, 500, "cpu", alloc=alloc, **kw)
         assert a.numel() == 1000 and b.numel() == 500 and int(a.max()) == 0 and int(b.max()) == 0
-        assert all(m == placement.MIN_BLOCK_BYTES for m in made)   # (blocks: powers of two of at least 2 GiB)
+        assert all(m >= placement.MIN_BLOCK_BYTES and m & (m - 1) == 0 for m in made)   # (blocks and gaps: powers of two >= 2 GiB)
         return seen, info
 
     assert placement.block_bytes(1) == 2 << 30 and placement.block_bytes((2 << 30) + 1) == 4 << 30 and placement.block_bytes(4 << 30) == 4 << 30
     seen, info = run([0.80])                              # clean at once: one probe, two blocks
     assert seen == [(1, 2, 0, 0)] and info["probes"] == [0.8] and info["held_gib"] == 4.0 and info["spread"]
     seen, info = run([1.0, 0.99, 1.0, 0.81], slot_boards=1024, plies=8)
-    # a new mask block (3), then a new observation block (4), then a new mask block (5): each against the other's first
-    assert [s[:2] for s in seen] == [(1, 2), (1, 3), (4, 2), (1, 5)] and all(s[2:] == (1024, 8) for s in seen)
-    assert info["ratio"] == 0.81 and info["spread"] and len(info["probes"]) == 4
-    seen, info = run([1.0, 0.94, 0.93])                   # in between (0.93): the new block also meets the other blocks
-    assert [s[:2] for s in seen][:4] == [(1, 2), (1, 3), (4, 2), (4, 3)]
-    seen, info = run([1.0] * 40)                          # never clean: the probe budget ends the search, best = first
-    assert len(seen) == placement.MAX_PROBES and info["ratio"] == 1.0 and not info["spread"]
+    # after every plain conflict a gap (allocations 3, 5, 7: 2, 4, 8 GiB), then a new mask block (4), a new observation
+    # block (6), a new mask block (8): each against the other array's first block
+    assert [s[:2] for s in seen] == [(1, 2), (1, 4), (6, 2), (1, 8)] and all(s[2:] == (1024, 8) for s in seen)
+    assert [m >> 30 for m in made] == [2, 2, 2, 2, 4, 2, 8, 2]
+    assert info["ratio"] == 0.81 and info["spread"] and len(info["probes"]) == 4 and info["held_gib"] == 24.0
+    seen, info = run([1.0, 0.94, 0.93])                   # in between: no gap, and the new block also meets the other blocks
+    assert [s[:2] for s in seen][:4] == [(1, 2), (1, 4), (5, 2), (5, 4)]
+    seen, info = run([1.0] * 40)                          # never clean: the memory budget ends the search, best = first
+    assert len(seen) == 8 and info["ratio"] == 1.0 and not info["spread"]       # gaps of 2 + 4 + 8 + 16 + 32 + 32 + 32 GiB
+    assert info["held_gib"] * placement.GIB <= placement.MAX_HOLD_BYTES and max(made) == placement.MAX_SKIP_BYTES
+    seen, info = run([0.95] * 40)                         # never clean, never a plain conflict: the probe budget ends it
+    assert len(seen) == placement.MAX_PROBES and info["ratio"] == 0.95
     seen, info = run([1.0, 0.97, 0.9, 0.95, 0.99], max_probes=5)
     assert info["ratio"] == 0.9 and info["spread"] and len(seen) == 5
-    seen, info = run([1.0] * 40, max_hold_bytes=10 << 30)  # the memory budget: five blocks of 2 GiB
-    assert len(seen) == 4 and info["held_gib"] == 10.0
+    seen, info = run([1.0] * 40, max_hold_bytes=10 << 30)  # the memory budget: one gap fits, then blocks only
+    assert len(seen) == 3 and info["held_gib"] == 10.0
