@@ -55,6 +55,21 @@ HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; max shader clock (MI355X_MICROARCH.md)
 TOTAL_BOARDS = 1 << 20
 
+# The sub-records of an N = 1 run: name -> (boards, timed plies, MASK_ONLY, mode).  tests/test_gpu_bench_kernels.py compares
+# the kernel instantiation each one times with the oracle, at the same batch size and through the same entry point.
+CONFIG_RECORDS = {
+    "c2_4096": (4096, 256, False, "collect"), "c3_262144": (262144, 128, False, "collect"),
+    "c4_shard_131072": (131072, 256, False, "collect"), "large_4194304": (1 << 22, 32, False, "collect"),
+    "maskonly_1048576": (1 << 20, 64, True, "collect"),
+    # round 1's pipeline, one launch per ply (gbl_rollout, 234 algorithmic bytes per env-step)
+    "single_ply_1048576": (1 << 20, 200, False, "fused"), "single_ply_262144": (262144, 200, False, "fused"),
+    "single_ply_131072": (131072, 200, False, "fused"), "single_ply_4096": (4096, 200, False, "fused"),
+    "single_ply_maskonly_1048576": (1 << 20, 200, True, "fused"),
+    "single_ply_large_4194304": (1 << 22, 40, False, "fused"),
+    # externally supplied actions: gbl_sample + gbl_step, two launches per ply
+    "step_pipeline_1048576": (1 << 20, 200, False, "step"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -131,13 +146,15 @@ def cpu_baseline(boards, warmup, target_s):
 
 
 def auto_traj(boards, steps, requested=0):
-    """Plies per gbl_collect launch: the requested value, or by shard size (large shards: shorter launches, so that a
-    launch's tail -- its last generation of wavefronts draining -- stays small; chosen automatically they never get
-    more than half of a timed run); never more than the timed run."""
-    t = requested if requested > 0 else (8 if boards >= (1 << 19) else 16 if boards >= (1 << 18) else 32)
-    if boards >= (1 << 19) and requested <= 0:
-        t = min(t, max(1, steps // 2))
-    return max(1, min(t, steps))
+    """Plies per gbl_collect launch: the requested value; else a timed run of up to 32 plies is ONE launch (the driver's
+    20 plies: one kernel, no boundary inside the timed region); else by shard size (large shards: shorter launches, so
+    that a launch's tail -- its last generation of wavefronts draining -- stays small, and the trajectory arrays stay
+    a few GiB); never more than the timed run."""
+    if requested > 0:
+        return max(1, min(requested, steps))
+    if steps <= 32:
+        return max(1, steps)
+    return 8 if boards >= (1 << 19) else 16 if boards >= (1 << 18) else 32
 
 
 def kernel_source_hash():
@@ -252,8 +269,9 @@ class Pipeline:
         """kernel_s: summed duration of the dominant kernel over `launches` launches that played `plies_timed` plies."""
         total_bytes = sum(self.launch_bytes(pl) for _, pl in self.plan(plies_timed))
         achieved = total_bytes / kernel_s / 1e9
-        # (grids of up to 2048 tiles run the two-wavefronts-per-tile form of the kernel, k_collect2)
-        collect = "k_collect2" if -(-self.boards // 64) <= 2048 else "k_collect"
+        # which form of the kernel the library runs for this shape: asked of the library, not re-derived here
+        variant = self.lib.gbl_collect_variant(self.boards, self.T, 1, 0 if self.no_obs else 1)
+        collect = {0: "k_collect", 1: "k_collect (plain stores)", 2: "k_collect2"}.get(variant, "k_collect?")
         name = {"step": "k_step", "fused": "k_rollout (plies=1)", "collect": f"{collect} ({self.T} plies per launch)"}[self.mode]
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
@@ -262,6 +280,24 @@ class Pipeline:
                 "algorithmic_bytes_per_launch": total_bytes / launches,
                 "env_steps_per_launch": self.boards * plies_timed / launches,
                 "mean_launch_us": kernel_s / launches * 1e6, "launches_timed": launches, "timing": timing}
+
+
+def traffic_key(mode, no_obs, boards, plies_per_launch):
+    """The key of profiles/pmc_traffic.json for a pipeline (scripts/profile_round.sh takes the counters per key)."""
+    return f"{mode}{'-noobs' if no_obs else ''}:{boards}" + (f":T{plies_per_launch}" if mode == "collect" else "")
+
+
+def attach_traffic(roof, p, plies_per_launch):
+    """roofline.traffic of pipeline p: measured HBM bytes per launch of its dominant kernel (committed PMC passes of the
+    same launch shape), and their ratio to the algorithmic bytes of that launch; null (with the reason) when the
+    committed counters were taken on other kernel sources or there are none for this shape."""
+    key = traffic_key(p.mode if p.mode != "step" else "step", p.no_obs, p.boards, plies_per_launch)
+    roof["traffic"], roof["traffic_source"] = committed_counter(key, "hbm_bytes_per_launch")
+    if roof["traffic"] is not None:
+        roof["traffic_plies_per_launch"] = plies_per_launch
+        roof["traffic_algorithmic_bytes"] = p.launch_bytes(plies_per_launch)
+        roof["traffic_over_algorithmic"] = roof["traffic"] / roof["traffic_algorithmic_bytes"]
+    return roof
 
 
 def short_run(G, torch, dev, boards, K, W, no_obs=False, mode="collect", traj=32, placement="auto"):
@@ -282,8 +318,12 @@ def short_run(G, torch, dev, boards, K, W, no_obs=False, mode="collect", traj=32
                        f"{'MASK_ONLY' if no_obs else 'FULL'} outputs every ply, mode {mode}, {K} plies "
                        f"({launches} launches) as one hipGraph",
            "value": boards * K / s, "unit": "env-steps/s", "us_per_step": s / K * 1e6,
-           "roofline": p.kernel_roofline(s, K, launches,
-                                         "HIP events around the graph replay (includes kernel boundaries)")}
+           "roofline": attach_traffic(p.kernel_roofline(s, K, launches,
+                                                        "HIP events around the graph replay (includes kernel boundaries)"),
+                                      p, min(p.T, K) if mode == "collect" else 1)}
+    if mode == "step":
+        rec["roofline"]["note"] = ("two kernels per ply (k_sample 58 B + k_step 234 B algorithmic per board): the fraction is "
+                                   "the whole ply's time against k_step's 234 bytes")
     if p.traj is not None:
         rec["trajectory_placement"] = p.traj["_placement"]
     del g, p
@@ -328,16 +368,34 @@ def greedy_run(G, torch, dev, boards=65536, iters=50):
             "us_per_step": s * 1e6, "roofline": roof}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves -- torch.distributed.run as a
+    CHILD process, before this process has imported torch or touched the GPU (nothing is exec'ed after HIP is
+    initialised) -- and pass its exit code on.  Rank 0's JSON line is the child's stdout, i.e. ours."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:  # a free port for the rendezvous
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the pool's driver supports dmabuf IPC only (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): measuring {world}", file=sys.stderr)
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (there is no CPU fallback for the product path)")
@@ -411,7 +469,11 @@ def main():
         timing = "HIP event pair around each of %d eager gbl_step launches after the timed replay" % launches
     mean_kernel_s = kernel_s / launches
     per_rank_us = [mean_kernel_s * 1e6]
+    per_rank_placement = [p.traj["_placement"] if p.traj is not None else None]
     if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank_placement[0])  # (after the timed region: a few hundred bytes per rank)
+        per_rank_placement = gathered
         cpu = args.dist_backend != "nccl"
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if cpu else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -423,12 +485,8 @@ def main():
 
     if rank == 0:
         roof = p.kernel_roofline(kernel_s, plies_timed, launches, timing)
-        tkey = f"{args.mode}{'-noobs' if args.no_obs else ''}:{boards}" + (f":T{min(args.traj, K)}" if args.mode == "collect" else "")
-        roof["traffic"], roof["traffic_source"] = committed_counter(tkey, "hbm_bytes_per_launch")
-        if args.mode == "collect" and roof["traffic"] is not None:
-            # the counters were taken on launches of exactly T plies; the timed launches may end with a shorter one
-            roof["traffic_plies_per_launch"] = min(args.traj, K)
-            roof["traffic_algorithmic_bytes"] = p.launch_bytes(min(args.traj, K))
+        # (the counters were taken on launches of exactly T plies; the timed launches may end with a shorter one)
+        attach_traffic(roof, p, min(args.traj, K) if args.mode == "collect" else 1)
         variant = "MASK_ONLY" if args.no_obs else "FULL"
         out = {
             "metric": "env-steps/sec at 2^20 parallel boards, 1/2/4/8 MI355X; bit-exact mask/winner",
@@ -453,6 +511,10 @@ def main():
                        "launch": ("hipGraph replay of the K plies' launches (device-resident ply index; one untimed warm "
                                   "replay of the same graph = K more untimed plies before the timed one)") if graph is not None else "eager",
                        "kernel_us_per_rank": per_rank_us, "kernel_us_max": max(per_rank_us),
+                       # ranks that took part in the barriers / reductions, and the backend that carried them
+                       "rccl_ranks": world if (dist is not None and args.dist_backend == "nccl") else 0,
+                       "dist_backend": (args.dist_backend if dist is not None else None),
+                       "trajectory_placement_per_rank": per_rank_placement,
                        # where the observation / mask trajectory arrays lie (gobblet-rl_amd/placement.py): probe ratios
                        # both / (obs alone + mask alone), ~1.0 = same 96 GiB class of HBM, ~0.8 = different classes
                        "trajectory_placement": p.traj["_placement"] if p.traj is not None else None},
@@ -460,15 +522,7 @@ def main():
         }
         if world == 1 and not args.no_configs:
             cfg = {}
-            for name, n, k, noobs, mode in (
-                    ("c2_4096", 4096, 256, False, "collect"), ("c3_262144", 262144, 128, False, "collect"),
-                    ("c4_shard_131072", 131072, 256, False, "collect"), ("large_4194304", 1 << 22, 32, False, "collect"),
-                    ("maskonly_1048576", 1 << 20, 64, True, "collect"),
-                    # round 1's pipeline, one launch per ply (gbl_rollout, 234 algorithmic bytes per env-step)
-                    ("single_ply_1048576", 1 << 20, 200, False, "fused"), ("single_ply_262144", 262144, 200, False, "fused"),
-                    ("single_ply_131072", 131072, 200, False, "fused"), ("single_ply_4096", 4096, 200, False, "fused"),
-                    ("single_ply_maskonly_1048576", 1 << 20, 200, True, "fused"),
-                    ("single_ply_large_4194304", 1 << 22, 40, False, "fused")):
+            for name, (n, k, noobs, mode) in CONFIG_RECORDS.items():
                 cfg[name] = short_run(G, torch, dev, n, k, W, no_obs=noobs, mode=mode, traj=auto_traj(n, k),
                                       placement=args.placement)
             cfg["c5_greedy_65536"] = greedy_run(G, torch, dev)

@@ -67,6 +67,10 @@ SIGNATURES = {
     "gbl_counter_add": (_int, [_vp, _u32, _vp]),
     "gbl_collect": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u64, _u64, _u32, _vp, _u32,
                            _int, _vp, _vp, _vp]),
+    "gbl_collect_variant": (_int, [_i64, _u32, _int, _int]),
+    "gbl_block_alloc": (_int, [_i64, C.POINTER(_vp)]),
+    "gbl_block_free": (_int, [_vp]),
+    "gbl_device_memory": (_int, [C.POINTER(_i64), C.POINTER(_i64)]),
     "gbl_placement_probe": (_int, [_vp, _i64, _vp, _i64, _i64, _int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                    C.POINTER(C.c_float), _vp]),
 }

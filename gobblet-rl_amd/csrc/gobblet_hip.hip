@@ -74,6 +74,29 @@ inline int nt_policy(int64_t n)
 #endif
 constexpr int64_t kCollectCachedBytes = GBL_COLLECT_CACHED_BYTES;
 
+// Which kernel a gbl_collect call runs (also reported by gbl_collect_variant): GBL_COLLECT_PAIR = k_collect2 (grids of up
+// to kCollect2MaxTiles tiles that stream), GBL_COLLECT_STREAM / GBL_COLLECT_CACHED = k_collect with non-temporal / plain
+// stores.  A pure function of the call's shape (and of the -D macros of an A/B build).
+constexpr int64_t kCollect2MaxTiles = 2048;  // 8 workgroups per CU (110 VGPRs: 4 wavefronts per SIMD); 4096 tiles would need two batches: 7.45 -> 7.81 us per ply
+
+inline int collect_variant(int64_t n, uint32_t plies, bool with_mask, bool with_obs)
+{
+    // bytes of trajectory rows the launch writes, against what the Infinity Cache keeps (see k_collect)
+    const int64_t row_bytes = (int64_t)plies * n * ((with_mask ? kActions : 0) + (with_obs ? kObs : 0) + 9);
+#ifdef GBL_FORCE_COLLECT_NT
+    const bool nt = (GBL_FORCE_COLLECT_NT) != 0;
+    (void)row_bytes;
+#else
+    const bool nt = row_bytes > kCollectCachedBytes;
+#endif
+#ifdef GBL_FORCE_COLLECT_PAIR  // 0 / 1: A/B builds
+    const bool pair = (GBL_FORCE_COLLECT_PAIR) != 0;
+#else
+    const bool pair = (n + kTile - 1) / kTile <= kCollect2MaxTiles && nt && (with_mask || with_obs);
+#endif
+    return pair ? GBL_COLLECT_PAIR : nt ? GBL_COLLECT_STREAM : GBL_COLLECT_CACHED;
+}
+
 // LDS words for a tile image of ROWB-byte rows (+ slack for row_load's look-ahead dword)
 template <int ROWB>
 constexpr int image_words() { return kTile * ROWB / 4 + 4; }
@@ -623,8 +646,6 @@ __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__r
 // issues a trajectory store; wavefront 1 takes the finished images over into registers (after which wavefront 0
 // rebuilds them for the next ply; the observation image comes back zeroed) and does nothing but store.  Two barriers per ply: "images ready" and "images
 // taken".  Bit for bit the trajectories of k_collect.
-constexpr int64_t kCollect2MaxTiles = 2048;  // 8 workgroups per CU (110 VGPRs: 4 wavefronts per SIMD); 4096 tiles would need two batches: 7.45 -> 7.81 us per ply
-
 // (LDS traffic only: no vmcnt wait -- the storing wavefront's stores stay in flight across the barrier)
 __device__ __forceinline__ void pair_barrier()
 {
@@ -1233,6 +1254,37 @@ int gbl_pinned_free(void *host_ptr)
     return GBL_OK;
 }
 
+int gbl_block_alloc(int64_t bytes, void **dev_ptr)
+{
+    if (bytes <= 0 || !dev_ptr) return fail(GBL_ERR_ARG, "gbl_block_alloc: bytes > 0 and dev_ptr required");
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, (size_t)bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // (an out-of-memory answer must not linger as the thread's "last error")
+        return hip_fail(e, "gbl_block_alloc");
+    }
+    *dev_ptr = d;
+    return GBL_OK;
+}
+
+int gbl_block_free(void *dev_ptr)
+{
+    if (!dev_ptr) return GBL_OK;
+    hipError_t e = hipFree(dev_ptr);
+    if (e != hipSuccess) return hip_fail(e, "gbl_block_free");
+    return GBL_OK;
+}
+
+int gbl_device_memory(int64_t *free_bytes, int64_t *total_bytes)
+{
+    size_t f = 0, t = 0;
+    hipError_t e = hipMemGetInfo(&f, &t);
+    if (e != hipSuccess) return hip_fail(e, "gbl_device_memory");
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return GBL_OK;
+}
+
 int gbl_board_eval(int8_t *state, const int8_t *agent_index, const int32_t *actions, int8_t *record_out, int64_t n,
                    void *stream)
 {
@@ -1401,18 +1453,8 @@ int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_t
         return fail(GBL_ERR_ALIGN, "counters must be 128-byte aligned");
     Geometry g = geometry(n);
     hipStream_t s = (hipStream_t)stream;
-    // bytes of trajectory rows this launch writes, against what the Infinity Cache keeps (see k_collect)
-    const int64_t row_bytes = (int64_t)plies * n * ((mask_traj ? kActions : 0) + (obs_traj ? kObs : 0) + 9);
-#ifdef GBL_FORCE_COLLECT_NT
-    const bool nt = (GBL_FORCE_COLLECT_NT) != 0;
-#else
-    const bool nt = row_bytes > kCollectCachedBytes;
-#endif
-#ifdef GBL_FORCE_COLLECT_PAIR  // 0 / 1: A/B builds
-    const bool pair = (GBL_FORCE_COLLECT_PAIR) != 0;
-#else
-    const bool pair = g.ntiles <= kCollect2MaxTiles && nt && (mask_traj || obs_traj);
-#endif
+    const int variant = collect_variant(n, plies, mask_traj != nullptr, obs_traj != nullptr);
+    const bool pair = variant == GBL_COLLECT_PAIR, nt = variant != GBL_COLLECT_CACHED;
 #define GBL_COLLECT_K(M, O, D)                                  \
     if (pair) GBL_COLLECT_K2(M, O, D);                          \
     else if (nt) GBL_COLLECT_KN(M, O, D, true);                 \
@@ -1438,6 +1480,12 @@ int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_t
 #undef GBL_COLLECT_KN
 #undef GBL_COLLECT_K2
     GBL_LAUNCHED("gbl_collect");
+}
+
+int gbl_collect_variant(int64_t n, uint32_t plies, int with_mask, int with_obs)
+{
+    if (n < 0) return fail(GBL_ERR_ARG, "n < 0");
+    return collect_variant(n, plies, with_mask != 0, with_obs != 0);
 }
 
 int gbl_placement_probe(void *a, int64_t a_bytes, void *b, int64_t b_bytes, int64_t slot_boards, int plies, float *us_both,

@@ -10,6 +10,7 @@ with the same attributes are used (they are third-party to the reference too).
 from __future__ import annotations
 
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -156,8 +157,8 @@ class _HipBoardEngine:
         self._action = block[self._ACTION:self._ACTION + 4].view(np.int32)
         self._agent = block[self._AGENT:self._AGENT + 1]
         self._fields = {k: self._record[o:o + size] for k, (o, size) in nat.REC_FIELDS.items()}
-        self._stream = torch.cuda.current_stream(self.device)
         self._index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._lock = threading.Lock()  # one pinned block per device: environments stepped from several threads take turns
 
     def __del__(self):
         try:
@@ -168,25 +169,27 @@ class _HipBoardEngine:
     def evaluate(self, squares, agent_index=None, action=None) -> dict:
         """Everything the reference derives from ``squares`` (int8[27]) -- after Board.play_turn(agent_index,
         action) when a move is given -- as numpy arrays (copies)."""
-        self._state[:] = squares
-        base = self._dev
-        other = torch.cuda.current_device() != self._index  # (a launch goes to the CURRENT device)
-        if other:
-            prev = torch.cuda.current_device()
-            torch.cuda.set_device(self._index)
-        try:
-            if action is None:
-                rc = self._lib.gbl_board_eval(base + self._STATE, None, None, base, 1, self._stream.cuda_stream)
-            else:
-                self._action[0], self._agent[0] = action, agent_index
-                rc = self._lib.gbl_board_eval(base + self._STATE, base + self._AGENT, base + self._ACTION, base, 1,
-                                              self._stream.cuda_stream)
-        finally:
+        with self._lock:  # write the block, launch, wait, read the block: one caller at a time
+            self._state[:] = squares
+            base = self._dev
+            other = torch.cuda.current_device() != self._index  # (a launch goes to the CURRENT device)
             if other:
-                torch.cuda.set_device(prev)
-        nat.check(rc, "gbl_board_eval")
-        self._stream.synchronize()
-        return {k: v.copy() for k, v in self._fields.items()}
+                prev = torch.cuda.current_device()
+                torch.cuda.set_device(self._index)
+            try:
+                stream = torch.cuda.current_stream(self.device)  # the caller's stream of THIS call
+                if action is None:
+                    rc = self._lib.gbl_board_eval(base + self._STATE, None, None, base, 1, stream.cuda_stream)
+                else:
+                    self._action[0], self._agent[0] = action, agent_index
+                    rc = self._lib.gbl_board_eval(base + self._STATE, base + self._AGENT, base + self._ACTION, base, 1,
+                                                  stream.cuda_stream)
+            finally:
+                if other:
+                    torch.cuda.set_device(prev)
+            nat.check(rc, "gbl_board_eval")
+            stream.synchronize()
+            return {k: v.copy() for k, v in self._fields.items()}
 
 
 _ENGINES: dict = {}
@@ -373,6 +376,8 @@ class raw_env(_AECBase):  # noqa: N801  (reference spelling, gobblet.py:123)
         self.agent_selection = self._agent_selector.reset()
         self.render_mode = render_mode
         self.debug = args.debug if hasattr(args, "debug") else False
+        self.screen_width = args.screen_width if hasattr(args, "screen_width") else 640  # gobblet.py:165-166 (pygame window;
+        self.screen_height = self.screen_width                                           #  kept as attributes only)
         self.screen = None
 
     def observe(self, agent):  # gobblet.py:179-215
@@ -397,6 +402,13 @@ class raw_env(_AECBase):  # noqa: N801  (reference spelling, gobblet.py:123)
     def step(self, action):  # gobblet.py:231-273
         if self.terminations[self.agent_selection] or self.truncations[self.agent_selection]:
             return self._was_dead_step(action)
+        # gobblet.py:238-242.  The reference hands is_legal the agent NAME as agent_index, and Board.is_legal tests
+        # `agent_index == 0` (board.py:86): whoever moves, this debug test is player_2's.
+        if self.debug and not self.board.is_legal(action, self.agent_selection):
+            print("piece: ", self.board.get_piece_from_action(action))
+            print("piece_size: ", self.board.get_piece_size_from_action(action))
+            print("pos: ", self.board.get_pos_from_action(action))
+            print("--ERROR-- ILLEGAL MOVE")
         self.board.play_turn(self.agents.index(self.agent_selection), action)  # illegal: silent no-op
         next_agent = self._agent_selector.next()
         if self.board.check_game_over():

@@ -10,12 +10,23 @@ process usually come from the same class, which made the trajectory stream 20 % 
 A process cannot see physical addresses, so the class is measured: ``gbl_placement_probe`` replays the kernel's store
 pattern on two buffers (both, a alone, b alone; ratio both / (a + b) ~1.0 inside one class, ~0.80 across two, in between
 when an array itself straddles two classes).  ``spread_pair`` carves either array from the start of a BLOCK of its own
-(a power of two of at least 2 GiB, one ``hipMalloc``): small allocations of a process all come from one neighbourhood
-of physical memory whatever is allocated in between (twelve candidates behind 8 GiB spacers each: the same ratio twelve
-times), whereas blocks of 2 GiB and more come from all over the device and change class every few blocks.  It keeps a
-small pool of blocks for either array, probes a new one against the other array's first -- leaving a gap of 2, 4, 8 ...
-GiB in front of it after every plain conflict, because on a fresh device consecutive blocks can stay inside one 96 GiB
-class -- stops at the first clean pair and releases the other blocks and the gaps at the end."""
+(at least 2 GiB, one ``hipMalloc`` through the library's ``gbl_block_alloc`` -- outside torch's caching allocator, so
+that a rejected block goes straight back to the driver when it is dropped and nobody's cache is flushed): small
+allocations of a process all come from one neighbourhood of physical memory whatever is allocated in between (twelve
+candidates behind 8 GiB spacers each: the same ratio twelve times), whereas blocks of 2 GiB and more come from all over
+the device and change class every few blocks.  It keeps a small pool of blocks for either array, probes a new one
+against the other array's first -- leaving a gap of 2, 4, 8 ... GiB in front of it after every plain conflict, because
+on a fresh device consecutive blocks can stay inside one 96 GiB class -- stops at the first clean pair and frees the
+other blocks and the gaps at the end.
+
+What a caller that shares the device can rely on (round 3):
+  * the search never holds more than ``MAX_HOLD_BYTES`` (64 GiB) nor more than a quarter of the memory that was free
+    when it started (the two arrays' own blocks always count), and leaves ``RESERVE_BYTES`` untouched;
+  * an allocation the device refuses ENDS the search (the best pair seen so far is used); if not even the two arrays'
+    own blocks fit, ``PlacementUnavailable`` is raised and ``BatchedGobblet.trajectory_buffers`` falls back to plain
+    torch allocations, recording why;
+  * ``torch.cuda.empty_cache()`` is never called, and nothing is taken from or returned to torch's allocator.
+"""
 from __future__ import annotations
 
 import ctypes as C
@@ -31,10 +42,54 @@ ACCEPT_RATIO = 0.83        # stop searching at a pair this good (us_both / (us_a
 SPREAD_RATIO = 0.93        # reported as "spread" below this
 SAME_RATIO = 0.96          # above this the pair simply shares a class
 MIN_BLOCK_BYTES = 2 * GIB  # an array is carved from a block of its own of at least this size
-MAX_HOLD_BYTES = 144 * GIB # blocks and gaps held at most while searching (a class is 96 GiB)
+BLOCK_GRANULE = 2 << 20    # blocks are whole 2 MiB pages
+MAX_HOLD_BYTES = 64 * GIB  # blocks and gaps held at most while searching (a class is 96 GiB) ...
+FREE_FRACTION = 4          # ... and never more than 1 / FREE_FRACTION of the memory free at entry
 MAX_SKIP_BYTES = 32 * GIB  # the largest single gap
 MAX_PROBES = 16
 RESERVE_BYTES = 4 * GIB    # never take the device's last few GiB for the search
+
+
+class PlacementUnavailable(RuntimeError):
+    """The device cannot provide the two arrays' own blocks: the caller allocates as it otherwise would."""
+
+
+class DeviceBlock:
+    """One ``gbl_block_alloc`` block (a plain hipMalloc on `device`), handed to torch through
+    ``__cuda_array_interface__``: ``tensor()`` is a uint8 view of it, and the block is freed (``gbl_block_free``) when
+    the last tensor over it and this object are gone."""
+
+    def __init__(self, nbytes: int, device):
+        self.nbytes, self.device, self.ptr = int(nbytes), torch.device(device), None
+        p = C.c_void_p()
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().gbl_block_alloc(self.nbytes, C.byref(p)), "gbl_block_alloc")
+        self.ptr = p.value
+        self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False),
+                                         "version": 2, "strides": None}
+
+    def tensor(self) -> torch.Tensor:
+        return torch.as_tensor(self, device=self.device)
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            try:
+                nat.lib().gbl_block_free(self.ptr)
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
+            self.ptr = None
+
+
+def device_alloc(device):
+    """The allocator ``spread_pair`` uses on a GPU: nbytes -> uint8 tensor over a block of its own."""
+    return lambda nbytes: DeviceBlock(nbytes, device).tensor()
+
+
+def free_bytes(device) -> int:
+    f = C.c_int64()
+    with torch.cuda.device(device):
+        nat.check(nat.lib().gbl_device_memory(C.byref(f), None), "gbl_device_memory")
+    return f.value
 
 
 def probe(a: torch.Tensor, b: torch.Tensor, slot_boards: int = 0, plies: int = 0) -> tuple[float, float, float]:
@@ -50,22 +105,38 @@ def probe(a: torch.Tensor, b: torch.Tensor, slot_boards: int = 0, plies: int = 0
 
 
 def block_bytes(nbytes: int) -> int:
-    """The block an array of nbytes is carved from: a power of two, at least MIN_BLOCK_BYTES."""
-    return max(MIN_BLOCK_BYTES, 1 << max(0, int(nbytes) - 1).bit_length())
+    """The block an array of nbytes is carved from: whole 2 MiB pages, at least MIN_BLOCK_BYTES."""
+    return max(MIN_BLOCK_BYTES, -(-int(nbytes) // BLOCK_GRANULE) * BLOCK_GRANULE)
+
+
+_OOM = (torch.OutOfMemoryError, nat.GobbletHipError, MemoryError)
 
 
 def spread_pair(bytes_a: int, bytes_b: int, device, slot_boards: int = 0, plies: int = 0, max_probes: int = MAX_PROBES,
-                max_hold_bytes: int = MAX_HOLD_BYTES, alloc=None):
+                max_hold_bytes: int | None = None, alloc=None, free=None):
     """Two zero-filled uint8 tensors of bytes_a / bytes_b bytes on `device` (each the head of a block of its own, see the
-    module docstring), placed so that writes to them overlap.  Returns (a, b, info); info records every probe.  If no
-    pair is clean, the best one seen is returned.  alloc(nbytes): the allocator (tests script it)."""
+    module docstring), placed so that writes to them overlap.  Returns (a, b, info); info records every probe, what was
+    held and why the search ended.  If no pair is clean, the best one seen is returned.  alloc(nbytes) -> uint8 tensor
+    (raising on out-of-memory) and free() -> free bytes: the allocator and the memory gauge (tests script them)."""
     t0 = time.perf_counter()
     dev = torch.device(device)
-    alloc = alloc or (lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=dev))
+    alloc = alloc or device_alloc(dev)
+    free = free or (lambda: free_bytes(dev))
     size = {"a": int(bytes_a), "b": int(bytes_b)}
     block = {k: block_bytes(v) for k, v in size.items()}
-    pool = {"a": [alloc(block["a"])], "b": [alloc(block["b"])]}
-    held = block["a"] + block["b"]
+    own = block["a"] + block["b"]
+    free0 = free()
+    if free0 < own + RESERVE_BYTES:
+        raise PlacementUnavailable("%.1f GiB free, the arrays' own blocks need %.1f GiB + %d GiB reserve"
+                                   % (free0 / GIB, own / GIB, RESERVE_BYTES // GIB))
+    cap = min(MAX_HOLD_BYTES if max_hold_bytes is None else int(max_hold_bytes), free0 // FREE_FRACTION)
+    cap = max(cap, own)
+    try:
+        pool = {"a": [alloc(block["a"])]}
+        pool["b"] = [alloc(block["b"])]
+    except _OOM as e:
+        raise PlacementUnavailable("the device refused the arrays' own blocks: %s" % e) from None
+    held = own
     tried = []
     best = (None, 0, 0)  # ratio, index into pool a, index into pool b
 
@@ -80,19 +151,26 @@ def spread_pair(bytes_a: int, bytes_b: int, device, slot_boards: int = 0, plies:
     try_pair(0, 0)
     grow = "b"  # blocks are added alternately: one for the mask array first (the smaller one)
     skips, skip = [], MIN_BLOCK_BYTES
-    while best[0] > ACCEPT_RATIO and len(tried) < max_probes:
-        free = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else 1 << 62
-        if held + block[grow] > max_hold_bytes or free < block[grow] + RESERVE_BYTES:
+    ended = "clean pair"
+    while best[0] > ACCEPT_RATIO:
+        if len(tried) >= max_probes:
+            ended = "probe budget"
+            break
+        room = free()
+        if held + block[grow] > cap or room < block[grow] + RESERVE_BYTES:
+            ended = "memory budget (%.0f GiB: 1/%d of the %.0f GiB free at entry, at most %d)" % (
+                cap / GIB, FREE_FRACTION, free0 / GIB, MAX_HOLD_BYTES // GIB)
             break
         try:
             # On a fresh device consecutive blocks can stay inside one class for tens of GiB (a class is 96 GiB): after a
             # plain conflict leave a gap first, twice as large each time
-            if tried[-1] > SAME_RATIO and held + skip + block[grow] <= max_hold_bytes and free >= skip + block[grow] + RESERVE_BYTES:
+            if tried[-1] > SAME_RATIO and held + skip + block[grow] <= cap and room >= skip + block[grow] + RESERVE_BYTES:
                 skips.append(alloc(skip))
                 held += skip
                 skip = min(2 * skip, MAX_SKIP_BYTES)
             pool[grow].append(alloc(block[grow]))
-        except torch.OutOfMemoryError:
+        except _OOM:
+            ended = "the device refused a block"
             break
         held += block[grow]
         new, other = len(pool[grow]) - 1, "b" if grow == "a" else "a"
@@ -107,10 +185,9 @@ def spread_pair(bytes_a: int, bytes_b: int, device, slot_boards: int = 0, plies:
     a, b = pool["a"][ia][:size["a"]], pool["b"][ib][:size["b"]]
     a.zero_(); b.zero_()  # (a probe writes only zeros, but say so explicitly)
     released = len(pool["a"]) + len(pool["b"]) - 2 + len(skips)
-    pool.clear()
+    pool.clear()    # the rejected blocks and the gaps go back to the driver here (hipFree, no allocator cache involved)
     skips.clear()
-    if released and dev.type == "cuda":
-        torch.cuda.empty_cache()  # hand the rejected blocks back to the driver
     return a, b, {"spread": bool(ratio <= SPREAD_RATIO), "ratio": round(ratio, 3), "probes": tried,
-                  "block_gib": [block["a"] / GIB, block["b"] / GIB], "held_gib": round(held / GIB, 1),
+                  "block_gib": [round(block["a"] / GIB, 3), round(block["b"] / GIB, 3)], "held_gib": round(held / GIB, 1),
+                  "cap_gib": round(cap / GIB, 1), "released_blocks": released, "ended": ended,
                   "seconds": round(time.perf_counter() - t0, 3)}

@@ -211,10 +211,13 @@ class BatchedGobblet:
         placement "auto" (default): when the observation and the mask trajectory are large enough to be HBM streams
         (64 MiB each), the mask array is placed so that the two do not share one of the three 96 GiB classes of the
         device's memory, in which their writes would not overlap (``placement.py``: a probe kernel; either array is then
-        the head of a block of its own of at least 2 GiB, and a few more blocks are held while searching; 33 -> 27 us
-        per ply at 2^20 boards).  "spread" insists (raises if the arrays are too
-        small to probe), "any" takes the allocator's addresses as they come.  What happened is recorded under
-        ``_placement``.
+        the head of a hipMalloc block of its own of at least 2 GiB -- a 64 MiB mask array pins 2 GiB for its lifetime --
+        and a few more blocks are held while searching: at most 64 GiB and at most a quarter of what is free, all handed
+        straight back to the driver afterwards, torch's allocator and its cache are not involved; 33 -> 27 us per ply at
+        2^20 boards).  When the device cannot spare the blocks the arrays are plain torch allocations and ``_placement``
+        says why.  "spread" insists (raises if the arrays are too small to probe or the memory is not there), "any" takes
+        the allocator's addresses as they come.  The search synchronises the device and takes a few milliseconds: make
+        the buffers once and reuse them (``collect(out=...)``).  What happened is recorded under ``_placement``.
 
         layout "time" (default): every entry has shape (plies, N, ...) -- one slice per ply, a view of a
         (plies, slot_boards, ...) allocation; slot_boards = N rounded up to 128 boards (+ ``pad_boards``), so that
@@ -255,9 +258,16 @@ class BatchedGobblet:
         elif placement != "any" and probeable:
             geometry = dict(slot_boards=ply_stride, plies=T) if layout == "time" and ply_stride % 128 == 0 else {}
             cells = T * ply_stride if layout == "time" else tiles * T * 64
-            a, b, placed = _placement.spread_pair(cells * 117, cells * nat.ACTIONS, dev, **geometry)
-            full["observation"] = a.view(torch.int8).view(lead + (3, 3, 13))
-            full["action_mask"] = b.view(torch.int8).view(lead + (nat.ACTIONS,))
+            try:
+                a, b, placed = _placement.spread_pair(cells * 117, cells * nat.ACTIONS, dev, **geometry)
+                full["observation"] = a.view(torch.int8).view(lead + (3, 3, 13))
+                full["action_mask"] = b.view(torch.int8).view(lead + (nat.ACTIONS,))
+            except _placement.PlacementUnavailable as e:
+                # a device that is nearly full (a trainer's model and replay buffer): no search, the allocator's addresses
+                if placement == "spread":
+                    raise
+                full["observation"], full["action_mask"] = make_obs(), make_mask()
+                placed = {"spread": False, "why": "fell back to plain allocations: %s" % e}
         else:
             if self.observation is not None:
                 full["observation"] = make_obs()
@@ -291,12 +301,15 @@ class BatchedGobblet:
         position after the last ply; with ``refresh`` the ``action_mask`` / ``observation`` / ``actions`` / ``winner`` /
         ``rewards`` attributes are copied from the last ply (device copies of ~180 B per board: a pure collector that
         only reads the trajectory passes ``refresh=False`` and calls ``refresh()`` before it next steps by hand).
-        ``out``: a dict from ``trajectory_buffers(plies)`` to reuse (a replay buffer's staging area)."""
+        ``out``: a dict from ``trajectory_buffers(plies)`` to reuse (a replay buffer's staging area; placed for speed,
+        see there).  Without it every call allocates fresh, unplaced buffers."""
         if not self.auto_reset:
             raise ValueError("collect() plays with auto-reset; this environment was created with auto_reset=False")
         T = int(plies)
         if out is None:
-            out = self.trajectory_buffers(T, layout=layout)
+            # (fresh buffers on every call: no probe, no placement -- a loop that cares about the last 20 % makes its
+            # buffers once with trajectory_buffers() and passes them as `out`)
+            out = self.trajectory_buffers(T, layout=layout, placement="any")
         if out["_plies"] != T:
             raise ValueError("trajectory buffers were made for %d plies" % out["_plies"])
         f, n = out["_full"], self.num_envs

@@ -10,7 +10,13 @@
  *
  * Conventions
  *   - All pointers are DEVICE pointers owned by the caller (e.g. torch-ROCm
- *     tensors' data_ptr()); the library allocates nothing and keeps no state.
+ *     tensors' data_ptr()).  The library keeps no state between calls, and the
+ *     compute entry points allocate nothing and only enqueue on `stream`.  The
+ *     exceptions are helpers, none of them on the step path:
+ *     gbl_pinned_alloc / gbl_pinned_free and gbl_block_alloc / gbl_block_free
+ *     allocate and free memory the CALLER then owns (the library keeps no
+ *     reference), and gbl_placement_probe creates HIP events for its own
+ *     duration and BLOCKS the host until its measurement has run.
  *   - Every buffer that holds per-board ROWS (state, mask, obs, flat, cov)
  *     must be 16-byte aligned at board 0 (hipMalloc / torch allocations are).
  *   - `stream` is a hipStream_t (NULL = default stream).  Calls only enqueue.
@@ -258,6 +264,15 @@ int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_t
                 int64_t n, int64_t ply_stride, int64_t tile_stride, uint64_t seed, uint64_t env_base, uint32_t ply0,
                 const uint32_t *ply_dev, uint32_t plies, int illegal_mode, int64_t *counters, int32_t *turn,
                 void *stream);
+/* Which kernel a gbl_collect call of this shape runs (no launch; >= 0, or GBL_ERR_ARG): benchmarks and profiles label
+ * their records with it instead of re-deriving the library's dispatch rule.
+ *   GBL_COLLECT_STREAM  k_collect,  one wavefront per tile of 64 boards, trajectory rows stored non-temporally
+ *   GBL_COLLECT_CACHED  k_collect with plain stores (never chosen by the product build: A/B builds only)
+ *   GBL_COLLECT_PAIR    k_collect2, two wavefronts per tile (one plays, one stores): grids of up to 2048 tiles */
+#define GBL_COLLECT_STREAM 0
+#define GBL_COLLECT_CACHED 1
+#define GBL_COLLECT_PAIR 2
+int gbl_collect_variant(int64_t n, uint32_t plies, int with_mask, int with_obs);
 /* *counter += by, enqueued on the stream (device uint32). */
 int gbl_counter_add(uint32_t *counter, uint32_t by, void *stream);
 
@@ -277,6 +292,16 @@ int gbl_counter_add(uint32_t *counter, uint32_t by, void *stream);
  * a meaningful answer. */
 int gbl_placement_probe(void *a, int64_t a_bytes, void *b, int64_t b_bytes, int64_t slot_boards, int plies, float *us_both,
                         float *us_a, float *us_b, void *stream);
+
+/* Device memory blocks for the placement search (and for C callers without an allocator of their own): one hipMalloc
+ * / hipFree each, on the calling thread's current device, outside any caching allocator -- a block handed back is free
+ * for every other user of the device at once, with no process-wide cache flush.  The caller owns a block until it
+ * frees it.  gbl_block_alloc returns GBL_ERR_HIP (and leaves *dev_ptr alone) when the device cannot provide the block:
+ * the search then stops with what it has.  gbl_device_memory: hipMemGetInfo (either pointer may be NULL); the search
+ * caps what it holds by a fraction of the free bytes. */
+int gbl_block_alloc(int64_t bytes, void **dev_ptr);
+int gbl_block_free(void *dev_ptr);
+int gbl_device_memory(int64_t *free_bytes, int64_t *total_bytes);
 
 #ifdef __cplusplus
 }

@@ -57,7 +57,14 @@ while time.time() < t_end:
         if with_obs:
             assert np.array_equal(obs["observation"].cpu().numpy(), oo["obs"])
     # a collected trajectory (gbl_collect, time- or tile-major) and a one-launch board evaluation (gbl_board_eval)
-    if auto:
+    # (collect() plays with auto-reset whatever this round drew for the stepping above: boards the frozen-board steps
+    #  left finished are reset on both sides first, then the environment collects with auto_reset on)
+    if True:
+        if not auto:
+            fin = dn != 0
+            s[fin] = 0; tm[fin] = 0; dn[:] = 0
+            env.auto_reset = True
+            env.reset_where(t(fin))
         T = int(master.integers(1, 12))
         lay = str(master.choice(["time", "tile"]))
         ply = env.ply

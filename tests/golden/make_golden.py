@@ -399,6 +399,49 @@ def print_pieces_text(n_boards=48):
     print("print_pieces.json:", len(out["boards"]), "boards,", len(out["debug_frames"]), "debug frames")
 
 
+def debug_illegal_frames(n_games=12, seed=2024):
+    """stdout of raw_env.step with args.debug = True along games that CONTAIN illegal plies (gobblet.py:238-242: the four
+    lines "piece: / piece_size: / pos: / --ERROR-- ILLEGAL MOVE").  The legality test of that branch is handed the agent
+    NAME as agent_index (``self.board.is_legal(action, self.agent_selection)``), and Board.is_legal compares
+    ``agent_index == 0`` (board.py:86), so the test is ALWAYS player_2's: the lines also appear on legal moves of
+    player_1 that player_2 could not make, and are missing on illegal moves of player_1 that player_2 could.  Actions:
+    seeded; one ply in three is drawn from all 54 actions (often illegal: a silent no-op, the turn passes,
+    gobblet.py:244-246), the others from the mover's legal moves.  Also records the screen_width / screen_height
+    attributes (gobblet.py:165-166) for a default and an explicit args."""
+    import contextlib
+    import io
+    rng = np.random.default_rng(seed)
+    frames = []
+    env = raw_env(render_mode="text", args=types.SimpleNamespace(debug=True))
+    for game in range(n_games):
+        env.reset()
+        for ply in range(40):
+            agent = env.agent_selection
+            if env.terminations[agent]:
+                break
+            mask = env.observe(agent)["action_mask"]
+            legal = np.flatnonzero(mask)
+            action = int(rng.integers(0, 54)) if rng.random() < 1 / 3 else int(rng.choice(legal))
+            idx = env.agents.index(agent)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                env.step(action)
+            frames.append({"game": game, "ply": ply, "agent": idx, "action": action, "legal_for_mover": bool(mask[action]),
+                           "text": buf.getvalue(), "squares": env.board.squares.astype(int).tolist()})
+    n_err = sum("--ERROR-- ILLEGAL MOVE" in f["text"] for f in frames)
+    n_ill = sum(not f["legal_for_mover"] for f in frames)
+    quirk_a = sum(f["legal_for_mover"] and "--ERROR--" in f["text"] for f in frames)
+    quirk_b = sum((not f["legal_for_mover"]) and "--ERROR--" not in f["text"] for f in frames)
+    attrs = {}
+    for name, args in (("default", None), ("explicit", types.SimpleNamespace(screen_width=480))):
+        e = raw_env(render_mode=None, args=args)
+        attrs[name] = {"screen_width": int(e.screen_width), "screen_height": int(e.screen_height)}
+    with open(os.path.join(OUT, "debug_illegal.json"), "w") as f:
+        json.dump({"frames": frames, "attrs": attrs}, f, indent=0)
+    print("debug_illegal.json:", len(frames), "frames;", n_ill, "illegal plies;", n_err, "with the ERROR lines;",
+          quirk_a, "legal moves flagged (tested as player_2);", quirk_b, "illegal moves not flagged")
+
+
 def c1_thousand_games(n_games=1000):
     """the AEC loop of examples/example_basic.py:50-67 over the reference
     raw_env, masked-uniform actions drawn from numpy.random.default_rng(0); whole trajectories."""
@@ -506,6 +549,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "print_pieces":
         print_pieces_text()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "debug_illegal":
+        debug_illegal_frames()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "c1":
         c1_thousand_games()
         return
@@ -525,6 +571,7 @@ def main():
     greedy_vectors(games)
     render_text()
     print_pieces_text()
+    debug_illegal_frames()
     c1_thousand_games()
     greedy_restricted_masks()
     greedy_depth3()

@@ -254,22 +254,57 @@ def test_facade_has_no_public_backend_switch():
         G.gobblet_v1.parallel_env()
 
 
+def _check_debug_illegal_frames(G, capsys, golden_dir, **envkw):
+    """raw_env.step's debug branch (gobblet.py:238-242) frame by frame against stdout captured from the reference along
+    games WITH illegal plies -- including the quirk that the branch's legality test is always player_2's (the agent name
+    is passed as agent_index) -- and the board after every ply (illegal: unchanged, the turn passes)."""
+    import types
+    ref = json.load(open(os.path.join(golden_dir, "debug_illegal.json")))
+    frames = ref["frames"]
+    assert sum("--ERROR-- ILLEGAL MOVE" in f["text"] for f in frames) >= 20
+    assert any(f["legal_for_mover"] and "--ERROR--" in f["text"] for f in frames)          # a legal move flagged
+    assert any(not f["legal_for_mover"] and "--ERROR--" not in f["text"] for f in frames)  # an illegal move not flagged
+    e = G.gobblet_v1.raw_env(render_mode="text", args=types.SimpleNamespace(debug=True), **envkw)
+    for fr in frames:
+        if fr["ply"] == 0:
+            e.reset()
+        assert e.agents.index(e.agent_selection) == fr["agent"]
+        capsys.readouterr()
+        e.step(fr["action"])
+        assert _norm_np_repr(capsys.readouterr().out) == _norm_np_repr(fr["text"]), (fr["game"], fr["ply"])
+        assert np.array_equal(np.asarray(e.board.squares).astype(int), np.asarray(fr["squares"])), (fr["game"], fr["ply"])
+    for name, args in (("default", None), ("explicit", types.SimpleNamespace(screen_width=480))):  # gobblet.py:165-166
+        env = G.gobblet_v1.raw_env(render_mode=None, args=args, **envkw)
+        assert {"screen_width": env.screen_width, "screen_height": env.screen_height} == ref["attrs"][name]
+
+
+def test_debug_branch_with_illegal_plies_matches_reference(capsys, golden_dir):
+    _check_debug_illegal_frames(G, capsys, golden_dir)
+
+
 def test_placement_search_logic(monkeypatch):
-    """placement.spread_pair with a scripted probe and allocator (no GPU): either array is the head of a block of its
-    own; it stops at the first clean pair, otherwise takes the best pair it saw, alternates which array gets a new
-    block, honours the probe and memory budgets, probes a new block against one representative unless that pair is in
-    between, and returns zero-filled arrays of the sizes asked for."""
+    """placement.spread_pair with a scripted probe, allocator and memory gauge (no GPU): either array is the head of a
+    block of its own; it stops at the first clean pair, otherwise takes the best pair it saw, alternates which array gets
+    a new block, honours the probe budget and the memory cap (64 GiB, a quarter of what was free at entry), ends quietly
+    when the device refuses a block, refuses to start when not even the arrays' own blocks fit, probes a new block
+    against one representative unless that pair is in between, and returns zero-filled arrays of the sizes asked for."""
     import torch
     from gobblet_rl_amd import placement
+    GIB = placement.GIB
 
     made = []
+    state = {"free": 288 * GIB, "refuse_after": None}
 
     def alloc(nbytes):
+        if state["refuse_after"] is not None and len(made) >= state["refuse_after"]:
+            raise MemoryError("scripted out-of-memory")
         made.append(nbytes)
+        state["free"] -= nbytes
         return torch.full((4096,), len(made), dtype=torch.uint8)  # (a stand-in for the block; the value tells which)
 
-    def run(ratios, **kw):
+    def run(ratios, free=288 * GIB, refuse_after=None, **kw):
         made.clear()
+        state.update(free=free, refuse_after=refuse_after)
         script, seen = list(ratios), []
 
         def fake_probe(a, b, slot_boards=0, plies=0):
@@ -278,28 +313,47 @@ def test_placement_search_logic(monkeypatch):
             return 100.0 * r, 60.0, 40.0
 
         monkeypatch.setattr(placement, "probe", fake_probe)
-        a, b, info = placement.spread_pair(1000, 500, "cpu", alloc=alloc, **kw)
+        a, b, info = placement.spread_pair(1000, 500, "cpu", alloc=alloc, free=lambda: state["free"], **kw)
         assert a.numel() == 1000 and b.numel() == 500 and int(a.max()) == 0 and int(b.max()) == 0
-        assert all(m >= placement.MIN_BLOCK_BYTES and m & (m - 1) == 0 for m in made)   # (blocks and gaps: powers of two >= 2 GiB)
+        assert all(m >= placement.MIN_BLOCK_BYTES and m % placement.BLOCK_GRANULE == 0 for m in made)
+        assert info["held_gib"] <= info["cap_gib"] <= placement.MAX_HOLD_BYTES / GIB
         return seen, info
 
-    assert placement.block_bytes(1) == 2 << 30 and placement.block_bytes((2 << 30) + 1) == 4 << 30 and placement.block_bytes(4 << 30) == 4 << 30
+    assert placement.block_bytes(1) == 2 << 30 and placement.block_bytes((2 << 30) + 1) == (2 << 30) + (2 << 20)
+    assert placement.block_bytes(5 << 30) == 5 << 30
     seen, info = run([0.80])                              # clean at once: one probe, two blocks
     assert seen == [(1, 2, 0, 0)] and info["probes"] == [0.8] and info["held_gib"] == 4.0 and info["spread"]
+    assert info["ended"] == "clean pair" and info["released_blocks"] == 0
     seen, info = run([1.0, 0.99, 1.0, 0.81], slot_boards=1024, plies=8)
     # after every plain conflict a gap (allocations 3, 5, 7: 2, 4, 8 GiB), then a new mask block (4), a new observation
     # block (6), a new mask block (8): each against the other array's first block
     assert [s[:2] for s in seen] == [(1, 2), (1, 4), (6, 2), (1, 8)] and all(s[2:] == (1024, 8) for s in seen)
     assert [m >> 30 for m in made] == [2, 2, 2, 2, 4, 2, 8, 2]
     assert info["ratio"] == 0.81 and info["spread"] and len(info["probes"]) == 4 and info["held_gib"] == 24.0
+    assert info["released_blocks"] == 6
     seen, info = run([1.0, 0.94, 0.93])                   # in between: no gap, and the new block also meets the other blocks
     assert [s[:2] for s in seen][:4] == [(1, 2), (1, 4), (5, 2), (5, 4)]
-    seen, info = run([1.0] * 40)                          # never clean: the memory budget ends the search, best = first
-    assert len(seen) == 8 and info["ratio"] == 1.0 and not info["spread"]       # gaps of 2 + 4 + 8 + 16 + 32 + 32 + 32 GiB
-    assert info["held_gib"] * placement.GIB <= placement.MAX_HOLD_BYTES and max(made) == placement.MAX_SKIP_BYTES
+    seen, info = run([1.0] * 60, max_probes=60)           # never clean: the memory cap (64 GiB) ends the search, best = first
+    assert info["ratio"] == 1.0 and not info["spread"] and info["cap_gib"] == 64.0 and info["ended"].startswith("memory budget")
+    assert sum(made) <= placement.MAX_HOLD_BYTES and max(made) <= placement.MAX_SKIP_BYTES
     seen, info = run([0.95] * 40)                         # never clean, never a plain conflict: the probe budget ends it
-    assert len(seen) == placement.MAX_PROBES and info["ratio"] == 0.95
+    assert len(seen) == placement.MAX_PROBES and info["ratio"] == 0.95 and info["ended"] == "probe budget"
     seen, info = run([1.0, 0.97, 0.9, 0.95, 0.99], max_probes=5)
     assert info["ratio"] == 0.9 and info["spread"] and len(seen) == 5
-    seen, info = run([1.0] * 40, max_hold_bytes=10 << 30)  # the memory budget: one gap fits, then blocks only
+    seen, info = run([1.0] * 40, max_hold_bytes=10 << 30)  # an explicit cap: one gap fits, then blocks only
     assert len(seen) == 3 and info["held_gib"] == 10.0
+    # a device that is mostly taken: the cap is a quarter of what is free
+    seen, info = run([1.0] * 40, free=40 * GIB)
+    assert info["cap_gib"] == 10.0 and info["held_gib"] <= 10.0 and sum(made) <= 10 * GIB
+    # ... and the reserve stays untouched however small the blocks
+    seen, info = run([1.0] * 40, free=9 * GIB)
+    assert sum(made) <= 9 * GIB - placement.RESERVE_BYTES and info["cap_gib"] == 4.0   # (the arrays' own blocks always count)
+    # the device refuses a block in mid-search: the search ends with what it has
+    seen, info = run([1.0] * 40, refuse_after=4)
+    assert info["ended"] == "the device refused a block" and len(made) == 4 and info["ratio"] == 1.0
+    # not even the arrays' own blocks: the caller is told to allocate as it otherwise would
+    with pytest.raises(placement.PlacementUnavailable):
+        run([0.8], free=7 * GIB)
+    with pytest.raises(placement.PlacementUnavailable):
+        run([0.8], refuse_after=1)
+    assert made == [2 << 30]

@@ -1,0 +1,233 @@
+"""GPU parity tests (-m gpu): every kernel instantiation that ``bench.py`` times, compared DIRECTLY with the CPU oracle
+at the batch size (and through the dispatch branch) the benchmark record uses -- not transitively through another
+kernel.  One test case per ``configs`` key of bench.py's JSON line (and the headline); the table below names the
+instantiation each one reaches.  Bit-exact (integer / byte work).
+
+    bench record                  entry point (as bench.py calls it)        kernel instantiation
+    ----------------------------  ----------------------------------------  -------------------------------------------
+    headline (2^20, collect)      gbl_collect, ply index on the device      k_collect<mask, obs, DEV_PLY, NT>
+    c2_4096                       gbl_collect                               k_collect2<mask, obs, DEV_PLY>  (<= 2048 tiles)
+    c3_262144                     gbl_collect                               k_collect<mask, obs, DEV_PLY, NT>
+    c4_shard_131072               gbl_collect                               k_collect2<mask, obs, DEV_PLY>  (2048 tiles)
+    large_4194304                 gbl_collect                               k_collect<mask, obs, DEV_PLY, NT>, identity tile map
+    maskonly_1048576              gbl_collect, obs_traj = NULL              k_collect<mask, -, DEV_PLY, NT>
+    single_ply_{1048576,262144,   gbl_rollout_at(plies = 1)                 k_rollout<mask, obs, NT = 1, DEV_PLY, ONE_PLY>
+      131072,4096}
+    single_ply_large_4194304      gbl_rollout_at(plies = 1)                 k_rollout<mask, obs, NT = 3, DEV_PLY, ONE_PLY>
+    single_ply_maskonly_1048576   gbl_rollout_at(plies = 1), obs_out = NULL k_rollout<mask, -, NT = 1, DEV_PLY, ONE_PLY>
+    --mode step                   gbl_sample_at + gbl_step                  k_sample, k_step<mask, obs, NT, false>
+    c5_greedy_65536               gbl_greedy                                k_greedy<4>  (test_gpu_parity.py::test_greedy_config5_full_size)
+    greedy_collect_65536          gbl_collect_policy                        k_collect_policy<W> (test_gpu_policy_collect.py)
+The oracle functions follow gobblet.py:179-271 (observe / step / reset) and board.py:82-220; see oracle/gobblet_oracle.c.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+THREADS = 16
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gobblet_rl_amd as g
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    g._native.lib()
+    return g
+
+
+def npy(x):
+    return x.cpu().numpy()
+
+
+def warm_pair(G, n, seed, base, warm, **kw):
+    """An environment and the oracle's arrays after `warm` masked-random plies from reset (the benchmark's workload)."""
+    env = G.BatchedGobblet(n, DEV, auto_reset=True, seed=seed, env_base=base, **kw)
+    s, tm, dn = oracle.batch_reset(n)
+    if warm:
+        env.rollout(warm)
+        oracle.batch_rollout(s, tm, dn, seed, base, 0, warm, threads=THREADS, want_obs=False, want_mask=False)
+    return env, s, tm, dn
+
+
+def slot(tr, key, t_, n):
+    """Ply t_ of trajectory entry `key` as an (n, ...) tensor, whichever the layout."""
+    if tr["_layout"] == "time":
+        return tr[key][t_]
+    v = tr[key][:, t_]
+    return v.reshape((v.shape[0] * 64,) + tuple(v.shape[2:]))[:n]
+
+
+def check_trajectory(env, tr, T, ply0, s, tm, dn, illegal, with_obs=True, with_mask=True):
+    """Every slot of a collected trajectory against the oracle's fused ply (sample -> step -> auto-reset -> observe)."""
+    n, ended = env.num_envs, 0
+    for t_ in range(T):
+        o = oracle.batch_rollout(s, tm, dn, env.seed, env.env_base, ply0 + t_, 1, illegal_mode=illegal, threads=THREADS,
+                                 want_obs=with_obs)
+        assert np.array_equal(npy(slot(tr, "actions", t_, n)), o["actions"]), ("actions", t_)
+        assert np.array_equal(npy(slot(tr, "winner", t_, n)), o["winner"]), ("winner", t_)
+        assert np.array_equal(npy(slot(tr, "rewards", t_, n)), o["reward"]), ("rewards", t_)
+        assert np.array_equal(npy(slot(tr, "done", t_, n)), dn), ("done", t_)
+        assert np.array_equal(npy(slot(tr, "to_move", t_, n)), tm), ("to_move", t_)
+        if with_mask:
+            assert np.array_equal(npy(slot(tr, "action_mask", t_, n)), o["mask"]), ("action_mask", t_)
+        if with_obs:
+            assert np.array_equal(npy(slot(tr, "observation", t_, n)), o["obs"]), ("observation", t_)
+        ended += int(dn.sum())
+    assert np.array_equal(npy(env.squares), s) and np.array_equal(npy(env.to_move), tm) and np.array_equal(npy(env.done), dn)
+    return ended
+
+
+# bench record -> (boards, plies per launch as bench.py's auto_traj picks them (cut where the oracle needs the time), obs)
+COLLECT_RECORDS = {
+    "headline_1048576": (1 << 20, 8, True),
+    "c2_4096": (4096, 32, True),
+    "c3_262144": (262144, 16, True),
+    "c4_shard_131072": (131072, 32, True),
+    "large_4194304": (1 << 22, 3, True),
+    "maskonly_1048576": (1 << 20, 8, False),
+}
+
+
+@pytest.mark.parametrize("record", list(COLLECT_RECORDS))
+def test_bench_collect_record_vs_oracle(G, record):
+    """gbl_collect exactly as bench.py's Pipeline launches it for this record (ply index in device memory, time-major
+    slots, the record's batch size and so its dispatch branch), every slot against the oracle."""
+    n, T, with_obs = COLLECT_RECORDS[record]
+    seed, base, warm = 0, 0, 12
+    env, s, tm, dn = warm_pair(G, n, seed, base, warm, with_observation=with_obs)
+    env.device_ply()                                  # DEV_PLY instantiation: what the hipGraph replay needs
+    tr = env.trajectory_buffers(T, placement="any")
+    env.collect(T, out=tr, refresh=False)
+    env.advance_ply()
+    torch.cuda.synchronize()
+    ended = check_trajectory(env, tr, T, warm, s, tm, dn, 0, with_obs=with_obs)
+    assert ended > 0                                  # games ended (and restarted) inside the trajectory
+    assert env.ply == warm + T
+
+
+@pytest.mark.parametrize("n,with_obs,layout,illegal,device_ply", [
+    # one board more than the two-wavefronts-per-tile kernel takes: the first grid of the one-wavefront k_collect
+    (131073, True, "time", "noop", False), (131073, False, "time", "terminate", True),
+    (131073, True, "tile", "terminate", True), (131073, False, "tile", "noop", False),
+    # 2^20 boards x 4 plies, MASK_ONLY and FULL, both illegal modes
+    (1 << 20, False, "time", "terminate", False), (1 << 20, True, "tile", "noop", False)])
+def test_collect_one_wavefront_kernel_vs_oracle(G, n, with_obs, layout, illegal, device_ply):
+    """k_collect (one wavefront per tile: grids above 2 048 tiles) directly against the oracle, FULL and MASK_ONLY, both
+    layouts, both illegal modes, ply index by value and on the device; a ragged last tile at 131 073 boards."""
+    T, seed, base, warm = 4, 17, 5_000_000_000, 9
+    env, s, tm, dn = warm_pair(G, n, seed, base, warm, with_observation=with_obs, illegal_mode=illegal)
+    if device_ply:
+        env.device_ply()
+    tr = env.trajectory_buffers(T, layout=layout, placement="any")
+    env.collect(T, out=tr, refresh=False)
+    env.advance_ply()
+    torch.cuda.synchronize()
+    check_trajectory(env, tr, T, warm, s, tm, dn, 0 if illegal == "noop" else 1, with_obs=with_obs)
+
+
+@pytest.mark.parametrize("n", [3000, 131073])
+@pytest.mark.parametrize("null", ["mask", "obs", "both", "scalars"])
+def test_collect_c_abi_null_outputs(G, n, null):
+    """gbl_collect called through the C-ABI with mask_traj / obs_traj / both / every scalar array NULL (k_collect and
+    k_collect2 <false, *> and <*, false>): what IS written equals the oracle, the state after the launch too."""
+    nat, L = G._native, G._native.lib()
+    T, seed, base, warm = 5, 23, 77, 7
+    env, s, tm, dn = warm_pair(G, n, seed, base, warm)
+    slot_boards = -(-n // 128) * 128
+    dev = torch.device(DEV)
+    z = lambda *shape, dtype=torch.int8: torch.zeros(shape, dtype=dtype, device=dev)  # noqa: E731
+    act, win, rew = z(T, slot_boards, dtype=torch.int32), z(T, slot_boards), z(T, slot_boards, 2)
+    don, tmv = z(T, slot_boards), z(T, slot_boards)
+    mask, obs = z(T, slot_boards, 54), z(T, slot_boards, 3, 3, 13)
+    want_mask, want_obs, want_scalars = null not in ("mask", "both"), null not in ("obs", "both"), null != "scalars"
+    p = lambda x, on: x.data_ptr() if on else None  # noqa: E731
+    nat.check(L.gbl_collect(env.squares.data_ptr(), env.to_move.data_ptr(), env.done.data_ptr(), p(act, want_scalars),
+                            p(win, want_scalars), p(rew, want_scalars), p(don, want_scalars), p(tmv, want_scalars),
+                            p(mask, want_mask), p(obs, want_obs), n, slot_boards, 64, seed, base, warm, None, T, 0, None, None,
+                            nat.current_stream(dev)), "gbl_collect")
+    torch.cuda.synchronize()
+    for t_ in range(T):
+        o = oracle.batch_rollout(s, tm, dn, seed, base, warm + t_, 1, threads=THREADS)
+        if want_scalars:
+            assert np.array_equal(npy(act[t_, :n]), o["actions"]) and np.array_equal(npy(win[t_, :n]), o["winner"])
+            assert np.array_equal(npy(rew[t_, :n]), o["reward"]) and np.array_equal(npy(don[t_, :n]), dn)
+            assert np.array_equal(npy(tmv[t_, :n]), tm)
+        if want_mask:
+            assert np.array_equal(npy(mask[t_, :n]), o["mask"]), t_
+        if want_obs:
+            assert np.array_equal(npy(obs[t_, :n]), o["obs"]), t_
+    assert np.array_equal(npy(env.squares), s) and np.array_equal(npy(env.to_move), tm)
+    # the arrays handed over as NULL were not touched (they are separate allocations: nothing else could have been)
+    if not want_mask:
+        assert int(mask.abs().sum()) == 0
+    if not want_obs:
+        assert int(obs.abs().sum()) == 0
+    if not want_scalars:
+        assert int(act.abs().sum()) == 0 and int(don.abs().sum()) == 0
+
+
+# bench record -> (boards, observation?)
+SINGLE_PLY_RECORDS = {
+    "single_ply_1048576": (1 << 20, True), "single_ply_262144": (262144, True), "single_ply_131072": (131072, True),
+    "single_ply_4096": (4096, True), "single_ply_maskonly_1048576": (1 << 20, False),
+    "single_ply_large_4194304": (1 << 22, True),
+}
+
+
+@pytest.mark.parametrize("record", list(SINGLE_PLY_RECORDS))
+def test_bench_single_ply_record_vs_oracle(G, record):
+    """gbl_rollout_at(plies = 1) -- the fused sample + step ply of bench.py's `fused` mode, ply index on the device --
+    at the record's batch size (so with its non-temporal store policy: the mask stream too from 2^21 boards), three
+    consecutive plies, every output against the oracle.  MASK_ONLY at 2^20 boards included."""
+    n, with_obs = SINGLE_PLY_RECORDS[record]
+    seed, base, warm = 3, 1 << 33, 10
+    env, s, tm, dn = warm_pair(G, n, seed, base, warm, with_observation=with_obs)
+    env.device_ply()
+    for k in range(3):
+        obs, rew, done, win = env.rollout(1)
+        env.advance_ply()
+        o = oracle.batch_rollout(s, tm, dn, seed, base, warm + k, 1, threads=THREADS, want_obs=with_obs)
+        assert np.array_equal(npy(env.squares), s) and np.array_equal(npy(env.to_move), tm) and np.array_equal(npy(done), dn)
+        assert np.array_equal(npy(env.actions), o["actions"]) and np.array_equal(npy(win), o["winner"])
+        assert np.array_equal(npy(rew), o["reward"]) and np.array_equal(npy(obs["action_mask"]), o["mask"])
+        if with_obs:
+            assert np.array_equal(npy(obs["observation"]), o["obs"])
+    assert env.ply == warm + 3
+
+
+def test_bench_step_mode_vs_oracle(G):
+    """bench.py --mode step at 2^20 boards: gbl_sample_at (ply index on the device) + gbl_step with auto-reset, two
+    plies, every output against the oracle (k_sample, k_step<mask, obs, NT = 1, false>); then MASK_ONLY."""
+    n, seed, base, warm = 1 << 20, 4, 99, 11
+    for with_obs in (True, False):
+        env, s, tm, dn = warm_pair(G, n, seed, base, warm, with_observation=with_obs)
+        env.device_ply()
+        for k in range(2):
+            a = env.sample_actions()
+            exp_a = oracle.batch_sample(oracle.batch_legal_mask(s, tm), seed, base, warm + k)
+            assert np.array_equal(npy(a), exp_a)
+            obs, rew, done, win = env.step(a)
+            env.advance_ply()
+            o = oracle.batch_step(s, tm, dn, exp_a, auto_reset=True, threads=THREADS, want_obs=with_obs)
+            assert np.array_equal(npy(env.squares), s) and np.array_equal(npy(done), dn) and np.array_equal(npy(win), o["winner"])
+            assert np.array_equal(npy(rew), o["reward"]) and np.array_equal(npy(obs["action_mask"]), o["mask"])
+            if with_obs:
+                assert np.array_equal(npy(obs["observation"]), o["obs"])
+
+
+def test_bench_config_keys_are_all_covered(G):
+    """Every sub-record bench.py emits has a test above (or the named one elsewhere) that compares its kernel with the
+    oracle: the key lists are read from bench.py itself, so a new record without a test fails here."""
+    import bench
+    keys = set(bench.CONFIG_RECORDS)
+    covered = set(COLLECT_RECORDS) | set(SINGLE_PLY_RECORDS) | {"c5_greedy_65536", "greedy_collect_65536", "step_pipeline_1048576",
+                                                                "two_stream_single_ply_131072", "two_stream_single_ply_262144",
+                                                                "step_into_sampler_131072"}
+    assert keys <= covered, keys - covered

@@ -658,9 +658,11 @@ def test_c_abi_without_python(G, tmp_path):
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-I", os.path.join(root, "include"),
                            os.path.join(root, "examples", "c_abi_example.cpp"), "-L", csrc, "-lgobblet_hip",
                            f"-Wl,-rpath,{csrc}", "-o", exe])
-    out = subprocess.run([exe, "50000", "30"], capture_output=True, text=True, timeout=120)
+    out = subprocess.run([exe, "131072", "30"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "misaligned pointer refused" in out.stdout
+    # the example's own copy of the placement search (gbl_block_alloc / gbl_placement_probe / gbl_block_free) found a pair
+    assert "trajectory arrays placed: probe ratio" in out.stdout and "kernel variant 2" in out.stdout
 
 
 def test_example_scripts_run(G):
@@ -826,6 +828,13 @@ def test_text_render_and_debug_printers_on_gpu(G, golden_dir, capsys):
         assert _norm_np_repr(capsys.readouterr().out) == _norm_np_repr(fr["text"]), i
 
 
+def test_debug_branch_with_illegal_plies_on_gpu(G, golden_dir, capsys):
+    """raw_env.step's `--ERROR-- ILLEGAL MOVE` branch (gobblet.py:238-242, agent-name quirk included) on the GPU-backed
+    facade against the reference's captured stdout: the same check the CPU suite runs on the stand-in engine."""
+    from tests.test_abi_and_host import _check_debug_illegal_frames
+    _check_debug_illegal_frames(G, capsys, golden_dir, device=DEV)
+
+
 def test_load_state_dict_twice_and_graph_after_load(G):
     """load_state_dict copies into the environment's own tensors: the checkpoint is not aliased (loading it again
     rewinds to the same state), tensor addresses survive (a hipGraph captured before the load keeps working), and
@@ -979,14 +988,21 @@ def test_bench_script_two_ranks_rehearsal(G):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
            "--boards", "32768", "--dist-backend", "gloo", "--share-device"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1  # rank 0 only
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_boards"] == 32768
-    assert d["config"]["boards_per_gpu"] == 16384 and len(d["config"]["kernel_us_per_rank"]) == 2
-    assert "configs" not in d and "cpu_baseline" not in d  # N = 1 only
+    bare = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+            "--boards", "32768", "--dist-backend", "gloo", "--share-device"]
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    # under the launcher (the driver's form), and bare: bench.py then starts its two ranks itself
+    for command, environ in ((cmd, env), (bare, clean)):
+        out = subprocess.run(command, capture_output=True, text=True, timeout=600, cwd=root, env=environ)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1  # rank 0 only
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_boards"] == 32768
+        assert d["config"]["boards_per_gpu"] == 16384 and len(d["config"]["kernel_us_per_rank"]) == 2
+        assert len(d["config"]["trajectory_placement_per_rank"]) == 2 and d["config"]["dist_backend"] == "gloo"
+        assert d["config"]["rccl_ranks"] == 0                   # (gloo rehearsal; under RCCL this is the world size)
+        assert "configs" not in d and "cpu_baseline" not in d  # N = 1 only
 
 
 def test_collect_beyond_4gib(G):
@@ -1047,8 +1063,9 @@ def test_placement_probe_and_spread_buffers(G):
     free0, _ = torch.cuda.mem_get_info()
     spread = e1.trajectory_buffers(T)  # placement="auto"
     info = spread["_placement"]
-    assert set(info) >= {"spread", "ratio", "probes", "block_gib", "held_gib", "seconds"} and 1 <= len(info["probes"]) <= placement.MAX_PROBES
-    assert 0.5 < info["ratio"] < 1.2 and info["held_gib"] * placement.GIB <= placement.MAX_HOLD_BYTES
+    assert set(info) >= {"spread", "ratio", "probes", "block_gib", "held_gib", "cap_gib", "ended", "seconds"} and 1 <= len(info["probes"]) <= placement.MAX_PROBES
+    assert 0.5 < info["ratio"] < 1.2 and info["held_gib"] <= info["cap_gib"] <= placement.MAX_HOLD_BYTES / placement.GIB
+    assert info["cap_gib"] * placement.GIB <= free0 / placement.FREE_FRACTION + 1 << 30
     assert spread["observation"].shape == (T, n, 3, 3, 13) and spread["action_mask"].shape == (T, n, 54)
     assert int(spread["_full"]["observation"].abs().max()) == 0 and int(spread["_full"]["action_mask"].abs().max()) == 0
     free1, _ = torch.cuda.mem_get_info()
@@ -1067,7 +1084,7 @@ def test_placement_probe_and_spread_buffers(G):
     with torch.cuda.stream(side):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            tr = e3.collect(T, refresh=False)
+            tr = e3.collect(T, out=e3.trajectory_buffers(T), refresh=False)
             e3.advance_ply()
         g.replay()
     torch.cuda.current_stream().wait_stream(side)
@@ -1077,6 +1094,49 @@ def test_placement_probe_and_spread_buffers(G):
         G.BatchedGobblet(64, DEV, auto_reset=True).trajectory_buffers(4, placement="spread")  # too small to probe
     small = G.BatchedGobblet(64, DEV, auto_reset=True).trajectory_buffers(4)
     assert small["_placement"]["spread"] is False and "too small" in small["_placement"]["why"]
+    assert G.BatchedGobblet(64, DEV, auto_reset=True).collect(4)["_placement"]["why"] == "placement='any'"  # implicit buffers: no probe
+
+
+def test_placement_on_a_nearly_full_device(G):
+    """A caller that has filled HBM already (a trainer's model and replay buffer): the search is capped by a quarter of
+    what is free, never flushes torch's allocator cache, frees what it only held, and when not even the arrays' own
+    blocks fit the buffers are plain torch allocations with the reason recorded -- the trajectories are the same."""
+    from gobblet_rl_amd import placement
+    GIB = placement.GIB
+    n, T, seed = 65536, 24, 5
+    kw = dict(auto_reset=True, seed=seed)
+    ref = G.BatchedGobblet(n, DEV, **kw)
+    plain = ref.trajectory_buffers(T, placement="any")
+    ref.collect(T, out=plain)
+    cached = torch.empty(1 << 30, dtype=torch.uint8, device=DEV)   # a block that sits in torch's cache during the search
+    del cached
+    reserved0 = torch.cuda.memory_reserved()
+    assert reserved0 >= 1 << 30
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(free - 30 * GIB, dtype=torch.uint8, device=DEV)   # leave ~30 GiB: the cap becomes ~7.5 GiB
+    e1 = G.BatchedGobblet(n, DEV, **kw)
+    tr = e1.trajectory_buffers(T)
+    info = tr["_placement"]
+    assert "probes" in info and info["cap_gib"] <= 30 / placement.FREE_FRACTION + 0.5 and info["held_gib"] <= info["cap_gib"]
+    assert torch.cuda.memory_reserved() >= reserved0 + hog.numel()      # torch's cache was not flushed
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 >= 30 * GIB - 5 * GIB                                   # the rejected blocks and gaps went back to the driver
+    e1.collect(T, out=tr)
+    for key in ("actions", "winner", "action_mask", "observation"):
+        assert torch.equal(tr[key], plain[key]), key
+    del tr, e1
+    free2, _ = torch.cuda.mem_get_info()
+    hog2 = torch.empty(max(free2 - 6 * GIB, 1), dtype=torch.uint8, device=DEV)   # ~6 GiB left: < 2 + 2 + 4 GiB reserve
+    e2 = G.BatchedGobblet(n, DEV, **kw)
+    tr = e2.trajectory_buffers(T)
+    assert tr["_placement"]["spread"] is False and "fell back to plain allocations" in tr["_placement"]["why"]
+    with pytest.raises(placement.PlacementUnavailable):
+        e2.trajectory_buffers(T, placement="spread")
+    e2.collect(T, out=tr)
+    for key in ("actions", "winner", "action_mask", "observation"):
+        assert torch.equal(tr[key], plain[key]), key
+    del hog, hog2, tr
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("n,illegal,auto_reset", [(4099, "noop", True), (300, "terminate", False)])
