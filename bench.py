@@ -69,6 +69,9 @@ CONFIG_RECORDS = {
     # externally supplied actions: gbl_sample + gbl_step, two launches per ply
     "step_pipeline_1048576": (1 << 20, 200, False, "step"),
 }
+# ... plus two records with their own drivers: c5_greedy_65536 (greedy_run) and greedy_collect_65536 (greedy_collect_run)
+EXTRA_RECORDS = ("c5_greedy_65536", "greedy_collect_65536", "two_stream_single_ply_131072", "two_stream_single_ply_262144",
+                 "step_reply_131072", "step_reply_262144")
 
 
 def parse():
@@ -140,9 +143,19 @@ def cpu_baseline(boards, warmup, target_s):
         oracle.batch_sample_step(s1, tm1, dn1, a[:n1].copy(), w[:n1].copy(), r[:n1].copy(), m1, obs[:n1].copy(), 0, 0,
                                  999 + k, threads=1)
     d1 = time.perf_counter() - t0
+    # config 5's baseline: depth-2 greedy decisions on 2048 positions of the same stationary mix, one core, with the
+    # reference's work per decision counted (legality tests / leaf evaluations of greedy_policy.py:84-157)
+    k = 2048
+    oracle.greedy_work(reset=True)
+    t0 = time.perf_counter()
+    oracle.batch_greedy(s[:k].copy(), tm[:k].copy(), depth=2)
+    dg = time.perf_counter() - t0
+    tests, leaves = oracle.greedy_work()
     return {"value": n * plies / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{n} boards x {plies} plies (sample+step+mask+obs, auto-reset), C oracle, {cores} threads",
-            "value_1core": n1 * 4 / d1}
+            "value_1core": n1 * 4 / d1,
+            "greedy_depth2": {"decisions_per_s_1core": k / dg, "sample": f"{k} positions, 1 thread",
+                              "legality_tests_per_decision": tests / k, "leaf_evaluations_per_decision": leaves / k}}
 
 
 def auto_traj(boards, steps, requested=0):
@@ -330,6 +343,102 @@ def short_run(G, torch, dev, boards, K, W, no_obs=False, mode="collect", traj=32
     return rec
 
 
+def two_stream_run(G, torch, dev, boards, K, W):
+    """One ply per launch (gbl_rollout, the external-consumer pipeline) with the batch cut in two halves that run on two
+    streams inside one hipGraph: a half's launch ramp (XCD start stagger + first wave's life) overlaps the
+    other half's store phase.  Candidate (a) of the one-ply pipelines at C3 / C4-shard sizes."""
+    half = boards // 2
+    pa = Pipeline(G, torch, half, 0, dev, mode="fused")
+    pb = Pipeline(G, torch, boards - half, half, dev, mode="fused")
+    pa.eager(W); pb.eager(W)
+    torch.cuda.synchronize(dev)
+    g, s2 = torch.cuda.CUDAGraph(), torch.cuda.Stream(dev)
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        s1 = torch.cuda.current_stream(dev)
+        s2.wait_stream(s1)
+        for i in range(K):
+            pa.enqueue(i, 1, s1.cuda_stream)
+            pb.enqueue(i, 1, s2.cuda_stream)
+        pa.advance(K, s1.cuda_stream); pb.advance(K, s2.cuda_stream)
+        s1.wait_stream(s2)
+    g.replay()
+    torch.cuda.synchronize(dev)
+    a, b = pa.events(1)[0]
+    a.record(); g.replay(); b.record()
+    torch.cuda.synchronize(dev)
+    sec = a.elapsed_time(b) / 1e3
+    total = ALGO_BYTES_FULL * boards * K
+    return {"workload": f"{boards} boards x 1 GPU as two half batches on two streams in one hipGraph, one ply per launch "
+                        f"(gbl_rollout), FULL outputs every ply, {K} plies",
+            "value": boards * K / sec, "unit": "env-steps/s", "us_per_step": sec / K * 1e6,
+            "roofline": {"bound": "hbm", "achieved": total / sec / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": total / sec / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "2 x k_rollout (plies=1)<mask,obs> on two streams", "algorithmic_bytes_per_env_step": ALGO_BYTES_FULL,
+                         "timing": "HIP events around the graph replay (two streams forked and joined inside the graph)"}}
+
+
+def step_reply_run(G, torch, dev, boards, K, W):
+    """Candidate (b): an external policy's ply and the masked-random reply in ONE launch (gbl_collect_from, 2 plies per
+    launch, both materialised in trajectory slots).  The stand-in for the external policy is the library's sampler on
+    the previous launch's last mask slot (its launch is part of the timed loop; the env-only time is taken separately with
+    an event pair around every gbl_collect_from launch of an eager run)."""
+    nat, L = G._native, G._native.lib()
+    env = G.BatchedGobblet(boards, dev, auto_reset=True, seed=0)
+    env.rollout(W)
+    buf = env.trajectory_buffers(2)
+    f = buf["_full"]
+    ctr = torch.zeros(1, dtype=torch.int32, device=dev)
+    env.refresh()
+    f["action_mask"][1, :boards].copy_(env.action_mask)
+    acts = torch.zeros(boards, dtype=torch.int32, device=dev)
+    mask1 = f["action_mask"][1]
+
+    def decision(off, stream, ev=None):
+        nat.check(L.gbl_sample_at(mask1.data_ptr(), acts.data_ptr(), boards, 12345, 0, off, ctr.data_ptr(), stream), "gbl_sample_at")
+        if ev:
+            ev[0].record()
+        nat.check(L.gbl_collect_from(env.squares.data_ptr(), env.to_move.data_ptr(), env.done.data_ptr(), acts.data_ptr(),
+                                     f["actions"].data_ptr(), f["winner"].data_ptr(), f["rewards"].data_ptr(),
+                                     f["done"].data_ptr(), f["to_move"].data_ptr(), f["action_mask"].data_ptr(),
+                                     f["observation"].data_ptr(), boards, buf["_ply_stride"], buf["_tile_stride"], 0, 0, off,
+                                     ctr.data_ptr(), 2, 0, None, None, stream), "gbl_collect_from")
+        if ev:
+            ev[1].record()
+    D = K // 2
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        cs = nat.current_stream(dev)
+        for i in range(D):
+            decision(2 * i, cs)
+        nat.check(L.gbl_counter_add(ctr.data_ptr(), 2 * D, cs), "gbl_counter_add")
+    g.replay()
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); g.replay(); b.record()
+    torch.cuda.synchronize(dev)
+    sec = a.elapsed_time(b) / 1e3
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(32)]
+    for i, ev in enumerate(evs):
+        decision(2 * i, nat.current_stream(dev), ev)
+    torch.cuda.synchronize(dev)
+    kern = sum(x.elapsed_time(y) for x, y in evs) / 1e3 / len(evs)
+    per_launch = (2 * ALGO_BYTES_COLLECT_PLY + ALGO_BYTES_COLLECT_LAUNCH + 4) * boards
+    variant = {0: "k_collect", 1: "k_collect (plain stores)", 2: "k_collect2"}[L.gbl_collect_variant(boards, 2, 1, 1)]
+    return {"workload": f"{boards} boards x 1 GPU, an external policy's ply (stand-in: gbl_sample on the last mask slot) + the "
+                        f"masked-random reply per launch (gbl_collect_from, 2 plies per launch), auto-reset, FULL outputs every ply, "
+                        f"{2 * D} plies as one hipGraph",
+            "value": boards * 2 * D / sec, "unit": "env-steps/s", "us_per_step": sec / (2 * D) * 1e6,
+            "us_per_step_env_only": kern / 2 * 1e6,
+            "roofline": {"bound": "hbm", "achieved": per_launch / kern / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": per_launch / kern / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": f"{variant} (2 plies per launch, first ply given)<mask,obs>",
+                         "algorithmic_bytes_per_env_step": per_launch / boards / 2, "algorithmic_bytes_per_launch": per_launch,
+                         "mean_launch_us": kern * 1e6, "launches_timed": len(evs),
+                         "timing": "HIP event pair around every gbl_collect_from launch of an eager run (the policy stand-in's "
+                                   "launch excluded); value / us_per_step include it"},
+            "trajectory_placement": buf["_placement"]}
+
+
 def greedy_run(G, torch, dev, boards=65536, iters=50):
     """BASELINE config 5: `boards` positions of the stationary masked-random mix x depth-2 greedy lookahead,
     one gbl_greedy launch per call.  Bound: integer VALU issue, not HBM (144 B of I/O per decision)."""
@@ -353,19 +462,65 @@ def greedy_run(G, torch, dev, boards=65536, iters=50):
     b.record()
     torch.cuda.synchronize(dev)
     s = a.elapsed_time(b) / 1e3 / iters
-    insts, src = committed_counter(f"greedy:{boards}", "SQ_INSTS_VALU")
-    roof = {"bound": "valu", "unit": "wave64 VALU instructions/s", "peak": SIMDS * CLOCK_GHZ * 1e9 / 4,
-            "achieved": None, "frac": None, "kernel": "k_greedy (depth 2)", "mean_launch_us": s * 1e6,
-            "launches_timed": iters, "timing": "HIP events around back-to-back eager launches / count",
-            "valu_instructions_per_launch": insts, "valu_instructions_source": src,
-            "note": "frac = VALU-busy share of the SIMDs: executed VALU instructions (rocprofv3 SQ_INSTS_VALU, committed "
-                    "profile) x 4 cycles / (1024 SIMDs x launch time x 2.4 GHz); HBM traffic is ~144 B per decision"}
-    if insts:
-        roof["achieved"] = insts / s
-        roof["frac"] = roof["achieved"] / roof["peak"]
     return {"workload": f"{boards} boards (stationary masked-random mix, both movers, empty history) x depth-2 greedy "
                         f"lookahead, one launch per call", "value": boards / s, "unit": "decisions/s",
-            "us_per_step": s * 1e6, "roofline": roof}
+            "us_per_step": s * 1e6,
+            "roofline": valu_roofline(f"greedy:{boards}", "k_greedy (depth 2)", s, iters,
+                                      "HIP events around back-to-back eager launches / count")}
+
+
+VALU_CYCLES_NOMINAL, VALU_CYCLES_MIX = 4.0, 2.9  # SIMD cycles per wave64 VALU instruction: the architectural figure, and
+# what the instructions these kernels are made of (v_bfe, v_lshlrev, v_bcnt, 3-operand logic, v_cmp + v_cndmask, SGPR
+# operands) measure at full occupancy (scripts/microbench/valu_rates.hip, profiles/r02/valu_rates.txt)
+
+
+def valu_roofline(counter_key, kernel, launch_s, launches, timing):
+    """Roofline of an integer-VALU-bound kernel: executed wave64 VALU instructions per launch (rocprofv3 SQ_INSTS_VALU of a
+    committed profile of the same launch) against what 1024 SIMDs can issue in the launch's time -- by two yardsticks."""
+    insts, src = committed_counter(counter_key, "SQ_INSTS_VALU")
+    peak = SIMDS * CLOCK_GHZ * 1e9 / VALU_CYCLES_NOMINAL
+    roof = {"bound": "valu", "unit": "wave64 VALU instructions/s", "peak": peak, "achieved": None, "frac": None,
+            "frac_of_measured_issue_rate": None, "kernel": kernel, "mean_launch_us": launch_s * 1e6,
+            "launches_timed": launches, "timing": timing, "valu_instructions_per_launch": insts,
+            "valu_instructions_source": src,
+            "note": "frac = executed VALU instructions x 4 cycles / (1024 SIMDs x launch time x 2.4 GHz); "
+                    "frac_of_measured_issue_rate = the same with 2.9 cycles per instruction, the rate this instruction mix "
+                    "issues at with every SIMD full (valu_rates.txt); HBM traffic is ~150-330 B per decision: irrelevant"}
+    if insts:
+        roof["achieved"] = insts / launch_s
+        roof["frac"] = roof["achieved"] / peak
+        roof["frac_of_measured_issue_rate"] = roof["achieved"] / (SIMDS * CLOCK_GHZ * 1e9 / VALU_CYCLES_MIX)
+    return roof
+
+
+def greedy_collect_run(G, torch, dev, boards=65536, T=16, launches=8, policies=("greedy", "greedy")):
+    """Whole games with the reference's greedy policy on both sides (tutorials/GreedyAgent/tutorial_greedy.py), T plies per
+    launch with every ply materialised: gbl_collect_policy.  One env-step = one decision + raw_env.step + observe."""
+    env = G.BatchedGobblet(boards, dev, auto_reset=True, seed=0)
+    env.rollout(64)
+    env.device_ply()
+    buf = env.trajectory_buffers(T, policy_outputs=True)
+    for _ in range(2):
+        env.collect(T, out=buf, policies=policies, refresh=False)
+        env.advance_ply()
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(launches):
+        env.collect(T, out=buf, policies=policies, refresh=False)
+        env.advance_ply()
+    b.record()
+    torch.cuda.synchronize(dev)
+    s = a.elapsed_time(b) / 1e3 / launches
+    greedy_share = float((buf["how"] != 0).float().mean())
+    rec = {"workload": f"{boards} boards x 1 GPU, {policies[0]} vs {policies[1]} (device-side GreedyGobbletPolicy, depth 2, "
+                       f"fallback draws and histories included), auto-reset, FULL outputs every ply, {T} plies per launch",
+           "value": boards * T / s, "unit": "env-steps/s", "us_per_step": s / T * 1e6,
+           "greedy_decisions_per_s": boards * T * greedy_share / s, "share_of_plies_decided_by_greedy": greedy_share,
+           "roofline": valu_roofline(f"policy-collect:{boards}:T{T}", f"k_collect_policy ({T} plies per launch)", s, launches,
+                                     "HIP events around back-to-back eager launches / count"),
+           "trajectory_placement": buf["_placement"]}
+    return rec
 
 
 def spawn_ranks(n):
@@ -525,10 +680,24 @@ def main():
             for name, (n, k, noobs, mode) in CONFIG_RECORDS.items():
                 cfg[name] = short_run(G, torch, dev, n, k, W, no_obs=noobs, mode=mode, traj=auto_traj(n, k),
                                       placement=args.placement)
+            # the external-policy pipelines at the C3 / C4-shard sizes: two candidates against single_ply_* above
+            for n in (131072, 262144):
+                cfg[f"two_stream_single_ply_{n}"] = two_stream_run(G, torch, dev, n, 200, W)
+                cfg[f"step_reply_{n}"] = step_reply_run(G, torch, dev, n, 200, W)
             cfg["c5_greedy_65536"] = greedy_run(G, torch, dev)
+            cfg["greedy_collect_65536"] = greedy_collect_run(G, torch, dev)
             out["configs"] = cfg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(boards, W, args.cpu_seconds)
+            ref = out["cpu_baseline"].get("greedy_depth2")
+            if ref and "configs" in out:
+                # the reference's work per decision (counted by the CPU restatement on the same
+                # stationary mix) x the measured decisions/s
+                c5 = out["configs"]["c5_greedy_65536"]
+                c5["reference_work_per_decision"] = {k: ref[k] for k in ("legality_tests_per_decision", "leaf_evaluations_per_decision")}
+                c5["legality_tests_per_s_equivalent"] = c5["value"] * ref["legality_tests_per_decision"]
+                c5["leaf_evaluations_per_s_equivalent"] = c5["value"] * ref["leaf_evaluations_per_decision"]
+                c5["cpu_port_decisions_per_s_1core"] = ref["decisions_per_s_1core"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

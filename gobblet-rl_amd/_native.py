@@ -30,6 +30,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 
 OK, ERR_ARG, ERR_ALIGN, ERR_HIP = 0, -1, -2, -3
 ILLEGAL_NOOP, ILLEGAL_TERMINATE = 0, 1
+POLICY_RANDOM, POLICY_GREEDY1, POLICY_GREEDY2, POLICY_GREEDY3 = 0, 1, 2, 3  # gbl_collect_policy
+HOW_RANDOM, HOW_GREEDY, HOW_FALLBACK = 0, 1, 2
 CELLS, ACTIONS, OBS_BYTES = 27, 54, 117
 COUNTER_STRIPES, COUNTER_STRIDE = 64, 16
 # gbl_board_eval record (include/gobblet_hip.h GBL_REC_*): field -> (byte offset, bytes)
@@ -67,6 +69,9 @@ SIGNATURES = {
     "gbl_counter_add": (_int, [_vp, _u32, _vp]),
     "gbl_collect": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u64, _u64, _u32, _vp, _u32,
                            _int, _vp, _vp, _vp]),
+    "gbl_collect_from": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u64, _u64, _u32, _vp, _u32,
+                                _int, _vp, _vp, _vp]),
+    "gbl_collect_policy": (_int, [_vp] * 14 + [_i64, _i64, _i64, _u64, _u64, _u32, _vp, _u32, _int, _int, _int, _int, _vp, _vp, _vp]),
     "gbl_collect_variant": (_int, [_i64, _u32, _int, _int]),
     "gbl_block_alloc": (_int, [_i64, C.POINTER(_vp)]),
     "gbl_block_free": (_int, [_vp]),

@@ -190,6 +190,45 @@ __device__ __forceinline__ void tile_out(int8_t *__restrict__ g, const uint32_t 
     }
 }
 
+// tile_out for kernels that are NOT bound by their stores (gbl_collect_policy: the greedy decision dominates): at most
+// CHUNK vectors per lane in registers at a time instead of the whole tile (the observation tile alone is 8 vectors = 32
+// VGPRs, which there would cost a wavefront of occupancy).  Same bytes, same store policy.
+template <int ROWB, int NT, int CHUNK>
+__device__ __forceinline__ void tile_out_narrow(int8_t *__restrict__ g, const uint32_t *lds, int lane, int rows)
+{
+    constexpr int NV = kTile * ROWB / 16;
+    if (rows != kTile) {
+        tile_out<ROWB, NT>(g, lds, lane, rows);  // (ragged last tile: byte granular)
+        return;
+    }
+    const uint4 *lv = reinterpret_cast<const uint4 *>(lds);
+#ifndef GBL_HOST_EMU
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g, 0, kTile * ROWB, 0x00020000);
+#endif
+#pragma unroll
+    for (int i0 = 0; i0 < NV; i0 += 64 * CHUNK) {
+        uint4 v[CHUNK];
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) {
+            const int i = i0 + 64 * u + lane;
+            v[u] = lv[i < NV ? i : NV - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) {
+            const int i = i0 + 64 * u + lane;
+            if (i0 + 64 * u < NV && i < NV) {
+#ifndef GBL_HOST_EMU
+                if constexpr (NT == kStoreStreamDrop) {
+                    vec4u t = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    __builtin_amdgcn_raw_buffer_store_b128(t, rs, i * 16, 0, 2 | 16);
+                } else
+#endif
+                    store16<NT == kStoreStreamDrop ? kStoreStream : NT>(reinterpret_cast<uint4 *>(g) + i, v[u]);
+            }
+        }
+    }
+}
+
 // tile_out in two halves, for a wavefront that takes a FULL tile's image over from another one: tile_fetch copies
 // the image into registers (after which the image may be rebuilt), tile_store sends them out.
 template <int ROWB>
@@ -237,6 +276,16 @@ __device__ __forceinline__ void wave_lds_fence()
 #ifndef GBL_HOST_EMU
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#endif
+}
+
+// Workgroup barrier for kernels whose wavefronts share LDS only: waits for the caller's LDS traffic (lgkmcnt) but NOT for
+// its outstanding global stores (vmcnt), which __syncthreads() would -- a wavefront's trajectory stores stay in flight
+// across the rendezvous.
+__device__ __forceinline__ void pair_barrier()
+{
+#ifndef GBL_HOST_EMU
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 }
 

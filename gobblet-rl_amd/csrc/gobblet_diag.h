@@ -3,6 +3,9 @@
 // reads (scripts/microbench/phase_stamps.py, greedy_stamps.py).  In the product build every macro below expands to
 // nothing and no symbol is added.
 #pragma once
+struct TileStamps {
+    unsigned long long t[3];  // phase stamps taken inside greedy_tile (diagnostic builds only; unused otherwise)
+};
 #ifdef GBL_STAMPS
 __device__ unsigned long long g_stamps[1 << 17][12];
 #define GBL_STAMP(i) unsigned long long st_##i = __builtin_amdgcn_s_memtime()
@@ -12,6 +15,8 @@ __device__ unsigned long long g_stamps[1 << 17][12];
 #define GBL_STAMP_DEP(i, v)                                  \
     asm volatile("" ::"v"(v));                               \
     unsigned long long st_##i = __builtin_amdgcn_s_memtime()
+#define GBL_STAMP_VAL(i, v) unsigned long long st_##i = (v)
+#define GBL_TILE_STAMP(ts, i) (ts).t[i] = __builtin_amdgcn_s_memtime()
 #define GBL_STAMP_DRAIN(i)                                   \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         \
     unsigned long long st_##i = __builtin_amdgcn_s_memtime()
@@ -29,6 +34,8 @@ __device__ unsigned long long g_stamps[1 << 17][12];
 #define GBL_STAMP_DECL(i)
 #define GBL_STAMP_SET(i)
 #define GBL_STAMP_DEP(i, v)
+#define GBL_STAMP_VAL(i, v)
+#define GBL_TILE_STAMP(ts, i)
 #define GBL_STAMP_DRAIN(i)
 #define GBL_STAMP_FLUSH(tile)
 #endif

@@ -557,7 +557,8 @@ __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__r
                                                 int8_t *__restrict__ reward_t, int8_t *__restrict__ done_t,
                                                 int8_t *__restrict__ to_move_t, int8_t *__restrict__ mask_t,
                                                 int8_t *__restrict__ obs_t, int illegal_mode,
-                                                int64_t *__restrict__ counters, int32_t *__restrict__ turn)
+                                                int64_t *__restrict__ counters, int32_t *__restrict__ turn,
+                                                const int32_t *__restrict__ first_actions)
 {
     __shared__ uint32_t s_state[image_words<kCells>()];
     __shared__ uint32_t s_out[out_image_words<true, WITH_OBS>()];
@@ -573,6 +574,8 @@ __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__r
     if (!lane_setup<1, false>(L, n, ntiles)) return;
 #endif
     int mover = to_move[L.valid ? L.b : n - 1];
+    // gbl_collect_from: the first ply plays the caller's actions (an external policy), the others are sampled
+    int given = first_actions ? first_actions[L.valid ? L.b : n - 1] : 0;
     uint32_t r[7];
     Draw4 block{{0u, 0u, 0u, 0u}};
     load_state(state, s_state, L, r, [&] { block = draw_block(seed, env_base + (uint64_t)L.b, ply0); });
@@ -586,7 +589,8 @@ __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__r
     uint64_t legal = legal54(p, mover);
     for (uint32_t t = 0; t < plies; ++t) {
         const uint32_t ply = ply0 + t;
-        const int action = pick54(legal, draw_word(block, ply));
+        int action = pick54(legal, draw_word(block, ply));
+        if (first_actions && t == 0) action = given;
         if (t + 1 < plies && ((ply + 1) & 3u) == 0) block = draw_block(seed, env_base + (uint64_t)L.b, ply + 1);
         {  // step_lane with the mover's mask at hand
             y = play_ply(p, row, mover, legal, action, illegal_mode);
@@ -646,14 +650,6 @@ __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__r
 // issues a trajectory store; wavefront 1 takes the finished images over into registers (after which wavefront 0
 // rebuilds them for the next ply; the observation image comes back zeroed) and does nothing but store.  Two barriers per ply: "images ready" and "images
 // taken".  Bit for bit the trajectories of k_collect.
-// (LDS traffic only: no vmcnt wait -- the storing wavefront's stores stay in flight across the barrier)
-__device__ __forceinline__ void pair_barrier()
-{
-#ifndef GBL_HOST_EMU
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-}
-
 template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY>
 __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n,
                                                  int64_t ntiles, uint64_t seed, uint64_t env_base,
@@ -663,7 +659,8 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
                                                  int8_t *__restrict__ reward_t, int8_t *__restrict__ done_t,
                                                  int8_t *__restrict__ to_move_t, int8_t *__restrict__ mask_t,
                                                  int8_t *__restrict__ obs_t, int illegal_mode,
-                                                 int64_t *__restrict__ counters, int32_t *__restrict__ turn)
+                                                 int64_t *__restrict__ counters, int32_t *__restrict__ turn,
+                                                 const int32_t *__restrict__ first_actions)
 {
     __shared__ uint32_t s_state[image_words<kCells>()];
     __shared__ uint32_t s_obs[WITH_OBS ? image_words<kObs>() : 4];
@@ -716,6 +713,7 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
     }
     // ---- the playing wavefront (k_collect's loop without its trajectory stores) -------------------------------------
     int mover = to_move[L.valid ? L.b : n - 1];
+    int given = first_actions ? first_actions[L.valid ? L.b : n - 1] : 0;  // (gbl_collect_from, see k_collect)
     uint32_t r[7];
     Draw4 block{{0u, 0u, 0u, 0u}};
     load_state(state, s_state, L, r, [&] { block = draw_block(seed, env_base + (uint64_t)L.b, ply0); });
@@ -733,7 +731,8 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
     }
     for (uint32_t t = 0; t < plies; ++t) {
         const uint32_t ply = ply0 + t;
-        const int action = pick54(legal, draw_word(block, ply));
+        int action = pick54(legal, draw_word(block, ply));
+        if (first_actions && t == 0) action = given;
         if (t + 1 < plies && ((ply + 1) & 3u) == 0) block = draw_block(seed, env_base + (uint64_t)L.b, ply + 1);
         y = play_ply(p, row, mover, legal, action, illegal_mode);
         dn = y.terminal ? 1 : 0;
@@ -863,13 +862,197 @@ __global__ __launch_bounds__(64) void k_validate(const int8_t *__restrict__ stat
 // W wavefronts per workgroup share one tile: wavefront 0 owns the boards (loads, depth-1 walk, replay,
 // outputs), all W evaluate pairs, so a tile's serial chain shrinks and every SIMD holds wavefronts in
 // different phases.  W = 1 needs no barrier (depth 1 has no pairs and uses it).
+// Orders the workgroup's LDS accesses (the only thing the wavefronts of a tile share).  Not __syncthreads(): that also
+// waits for the caller's outstanding global stores (vmcnt), which in gbl_collect_policy would put the drain of a ply's
+// trajectory stores on the path of the next decision.
 template <int W>
 __device__ __forceinline__ void pool_fence()
 {
     if (W > 1)
-        __syncthreads();
+        pair_barrier();
     else
         wave_lds_fence();
+}
+
+// The LDS a tile's decision works in (one per workgroup).
+template <int W>
+struct GreedyLds {
+    // (board << 8) | candidate of every depth-2 evaluation, in kSegs segments: segment g lists candidates
+    // [g * kSeg, (g + 1) * kSeg) of all 64 boards and is built by wavefront g mod W
+    static constexpr int kSegs = W >= 2 ? W : 2, kSeg = (kActions + kSegs - 1) / kSegs, kSegCap = kTile * kSeg;
+    static_assert(kSeg <= 32, "a segment's candidates fit one 32-bit word");
+    alignas(16) uint16_t pair[kSegs * kSegCap];
+    uint16_t again[kTile * kActions];    // pairs that need the exact evaluation (greedy_reply<true>)
+    uint32_t board[kTile][4];            // planes nz, neg, odd; bit 0: the agent to move, bit 1: the board wants depth 2
+    uint64_t legal[kTile];               // its legal moves on the root position
+    unsigned long long work[kTile];      // the candidates of a board that get an evaluation of their own
+    int count[kSegs];
+    uint16_t reply[kTile][kActions];     // greedy_reply() of (board, candidate), where bit 0 is set
+    unsigned long long threat[kTile];    // candidates whose summary has bit 0 / bit 15 / bit 7 / bit 8,
+    unsigned long long allwin[kTile];    // and those whose first winning reply is a legal move of ours
+    unsigned long long second[kTile];    // (the sets greedy_replay_closed works on)
+    unsigned long long block[kTile];
+    unsigned long long flegal[kTile];
+    int deferred;
+    unsigned long long defer[kTile];     // the set-aside pairs as per-board candidate sets (first round)
+    uint32_t quiet[kTile];               // per board: bit 0 quiet root, bits 1-9 risky squares (greedy_quiet_root)
+    // The two pair lists are dead between two decisions (written after the first barriers of greedy_tile, read before
+    // its last): a kernel that decides in a loop stages its output rows through them in between.
+    static constexpr int kScratchBytes = (int)(sizeof(uint16_t) * (kSegs * kSegCap + kTile * kActions));
+    __device__ __forceinline__ uint32_t *scratch() { return reinterpret_cast<uint32_t *>(pair); }
+};
+
+// One decision per board of a tile, by ALL 64 W threads of the workgroup (slot = 0 .. 64 W - 1; every thread calls, the
+// barriers are inside).  The owners (slot < 64, lane = board) pass their board, the agent to move, the legal mask
+// handed to the policy (0: nothing to decide on this board -- an invalid lane, or in gbl_collect_policy a board whose
+// mover plays at random), the board's depth (1, 2; 3 decides like 2) and the agent's last three actions; the other
+// threads' arguments are ignored and they get an empty result.  deep: some board of SOME tile of the launch may want
+// depth 2 (workgroup-uniform: it decides whether the pooled rounds and their barriers exist at all).
+// Safe to call in a loop: what the owners read last (replay) and write first (heads) is their own wavefront's business,
+// and everybody else's reads of an iteration lie before its last barrier.
+template <int W>
+__device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<W> &S, int slot, const Planes &p, int me, uint64_t mask,
+                                                    int depth, bool deep, uint32_t prev3, TileStamps &ts)
+{
+    constexpr int kSegs = GreedyLds<W>::kSegs, kSeg = GreedyLds<W>::kSeg, kSegCap = GreedyLds<W>::kSegCap;
+    const int lane = slot & (kTile - 1);
+    const bool owner = slot < kTile;
+    GreedyHead h{0ull, 0ull, 0ull, 0ull, 0, -1};
+    GreedyPlan plan{GreedyDom{0ull, {63u, 63u, 63u}, {0u, 0u, 0u}}, 0ull};
+    int total = 0;
+    const bool two = owner && depth > 1 && mask != 0;  // this board takes part in the depth-2 rounds
+    if (owner && deep) {
+        S.board[lane][0] = p.nz;
+        S.board[lane][1] = p.neg;
+        S.board[lane][2] = p.odd;
+        S.board[lane][3] = (uint32_t)me | (two ? 2u : 0u);
+    }
+    // While the owners walk depth 1, the second wavefront finds out for every board whether the OPPONENT could win on
+    // the root at once (greedy_quiet_root: as expensive as the depth-1 walk itself, and off the owners' serial path).
+    if (deep && W > 1) {
+        pool_fence<W>();
+        if ((slot >> 6) == 1 && (S.board[lane][3] & 2u)) {
+            const Planes q{S.board[lane][0], S.board[lane][1], S.board[lane][2]};
+            const GreedyQuiet g = greedy_quiet_root(q, (int)(S.board[lane][3] & 1u));
+            S.quiet[lane] = (g.quiet ? 1u : 0u) | (g.risky << 1);
+        }
+    }
+    if (owner) {
+        h = greedy_head(p, me, mask, depth);  // empty mask: nothing to do
+        if (deep) {
+            S.legal[lane] = h.legal_me;
+            S.threat[lane] = 0ull;
+            S.allwin[lane] = 0ull;
+            S.second[lane] = 0ull;
+            S.block[lane] = 0ull;
+            S.flegal[lane] = 0ull;
+            S.defer[lane] = 0ull;
+            if (lane == 0) S.deferred = 0;
+        }
+    }
+    if (deep) {
+        if (W > 1) pool_fence<W>();  // the second wavefront's verdicts are in
+        if (owner) {
+            // twin placements are not evaluated a second time; placements from hand not at all on a root where the
+            // opponent has no winning move (greedy_quiet_root), else behind a smaller one on the same square only
+            // if that one turns out not to be calm (greedy_dominance)
+            if (two) {
+                GreedyQuiet g;
+                if (W > 1) {
+                    const uint32_t v = S.quiet[lane];
+                    g = GreedyQuiet{(v & 1u) != 0, v >> 1, greedy_from_hand(p, me)};
+                } else {
+                    g = greedy_quiet_root(p, me);
+                }
+                plan = greedy_plan(h, p, me, g);
+            }
+            S.work[lane] = plan.dom.first;
+        }
+    }
+    GBL_TILE_STAMP(ts, 0);
+    if (deep) {
+        auto record = [&](uint32_t o, uint32_t a, uint32_t sum) {
+            if (sum & 1u) {
+                S.reply[o][a] = (uint16_t)sum;
+                atomicOr(&S.threat[o], 1ull << a);
+                if (sum & (1u << 7)) atomicOr(&S.second[o], 1ull << a);
+                if (sum & (1u << 8)) atomicOr(&S.block[o], 1ull << a);
+                if ((S.legal[o] >> ((sum >> 1) & 63u)) & 1ull) atomicOr(&S.flegal[o], 1ull << a);
+            }
+            if (sum >> 15) atomicOr(&S.allwin[o], 1ull << a);
+        };
+        pool_fence<W>();
+        // The pair lists, by all W wavefronts: lane = board.  One ballot per candidate compacts the boards that have
+        // it (no per-lane loop, no divergence); the order of a list is irrelevant, results land in per-board sets.
+        for (int sg = slot >> 6; sg < kSegs; sg += W) {
+            const uint32_t wk = (uint32_t)(S.work[lane] >> (sg * kSeg)) & (uint32_t)((1ull << kSeg) - 1ull);
+            const uint32_t tag = ((uint32_t)lane << 8) + (uint32_t)(sg * kSeg);
+            uint16_t *seg = S.pair + sg * kSegCap;
+            uint32_t cnt = 0;  // wave-uniform
+#pragma unroll
+            for (int j = 0; j < kSeg; ++j) {
+                const bool has = (wk >> j) & 1u;
+                const unsigned long long m = __ballot(has);
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, cnt));
+                if (has) seg[at] = (uint16_t)(tag + j);
+                cnt += (uint32_t)__popcll(m);
+            }
+            if (lane == 0) S.count[sg] = (int)cnt;
+        }
+        pool_fence<W>();
+        int seg_end[kSegs];  // cumulative list lengths
+        total = 0;
+#pragma unroll
+        for (int w = 0; w < kSegs; ++w) seg_end[w] = (total += S.count[w]);
+        auto pair_at = [&](int g) -> uint32_t {
+            int w = 0, start = 0;
+#pragma unroll
+            for (int k = 0; k + 1 < kSegs; ++k) {
+                w += g >= seg_end[k] ? 1 : 0;
+                start = g >= seg_end[k] ? seg_end[k] : start;
+            }
+            return S.pair[w * kSegCap + (g - start)];
+        };
+        // first round: the cheap evaluation; the few pairs where a lift could hand us a line are set aside
+        for (int g = slot; g < total; g += kTile * W) {
+            const uint32_t pair = pair_at(g), o = pair >> 8, a = pair & 0xFFu;
+            const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
+            const uint32_t sum = greedy_reply<false>(q, (int)(S.board[o][3] & 1u), S.legal[o], a);
+            if (sum == kGreedyDefer) {
+                S.again[atomicAdd(&S.deferred, 1)] = (uint16_t)pair;
+                atomicOr(&S.defer[o], 1ull << a);
+            } else {
+                record(o, a, sum);
+            }
+        }
+        pool_fence<W>();
+        // the placements held back behind a smaller one on the same square whose stand-in was not calm join the exact
+        // round (a couple per board: they fit the round the set-aside pairs need anyway)
+        if (owner)
+            for (uint64_t it = greedy_second_round(plan.dom, S.threat[lane] | S.defer[lane]) | plan.exact; it; it &= it - 1)
+                S.again[atomicAdd(&S.deferred, 1)] = (uint16_t)(((uint32_t)lane << 8) | (uint32_t)__builtin_ctzll(it));
+        pool_fence<W>();
+        GBL_TILE_STAMP(ts, 1);
+        const int again = S.deferred;
+        for (int g = slot; g < again; g += kTile * W) {
+            const uint32_t pair = S.again[g], o = pair >> 8, a = pair & 0xFFu;
+            const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
+            record(o, a, greedy_reply<true>(q, (int)(S.board[o][3] & 1u), S.legal[o], a));
+        }
+        pool_fence<W>();
+    }
+    GBL_TILE_STAMP(ts, 2);
+    if (!owner) return GreedyResult{-1, 0ull, false};
+    if (two)  // :103-157 on the owner's lane, in closed form over the candidate sets
+        greedy_replay_closed(h, ReplySets{S.threat[lane], S.allwin[lane], S.second[lane], S.block[lane], S.flegal[lane]},
+                             [&](int a) { return (uint32_t)S.reply[lane][((h.dup >> a) & 1ull) ? a - 9 : a]; });
+    return greedy_finish(h, prev3);
+}
+
+// the agent's last three actions (one per byte, 0xFF = none) from the 6 history bytes of a board, read as three 16-bit words
+__device__ __forceinline__ uint32_t hist_prev3(uint32_t h0, uint32_t h1, uint32_t h2, int me)
+{
+    return me ? ((h1 >> 8) | (h2 << 8)) & 0x00FFFFFFu : (h0 | (h1 << 16)) & 0x00FFFFFFu;
 }
 
 template <int W>
@@ -889,25 +1072,7 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
     if (hist_rw) hist = hist_rw;
     __shared__ uint32_t s_state[image_words<kCells>()];
     __shared__ uint32_t s_mask[image_words<kActions>()];
-    __shared__ uint32_t s_board[kTile][4];          // planes nz, neg, odd and the agent to move
-    __shared__ uint64_t s_legal[kTile];             // its legal moves on the root position
-    // (board << 8) | candidate of every depth-2 evaluation, in kSegs segments: segment g lists candidates
-    // [g * kSeg, (g + 1) * kSeg) of all 64 boards and is built by wavefront g mod W
-    constexpr int kSegs = W >= 2 ? W : 2, kSeg = (kActions + kSegs - 1) / kSegs, kSegCap = kTile * kSeg;
-    static_assert(kSeg <= 32, "a segment's candidates fit one 32-bit word");
-    __shared__ uint16_t s_pair[kSegs * kSegCap];
-    __shared__ unsigned long long s_work[kTile];    // the candidates of a board that get an evaluation of their own
-    __shared__ int s_count[kSegs];
-    __shared__ uint16_t s_reply[kTile][kActions];   // greedy_reply() of (board, candidate), where bit 0 is set
-    __shared__ unsigned long long s_threat[kTile];  // candidates whose summary has bit 0 / bit 15 / bit 7 / bit 8,
-    __shared__ unsigned long long s_allwin[kTile];  // and those whose first winning reply is a legal move of ours
-    __shared__ unsigned long long s_second[kTile];  // (the sets greedy_replay_closed works on)
-    __shared__ unsigned long long s_block[kTile];
-    __shared__ unsigned long long s_flegal[kTile];
-    __shared__ int s_deferred;
-    __shared__ uint16_t s_again[kTile * kActions];  // pairs that need the exact evaluation (greedy_reply<true>)
-    __shared__ unsigned long long s_defer[kTile];   // ... as per-board candidate sets (first round)
-    __shared__ uint32_t s_quiet[kTile];             // per board: bit 0 quiet root, bits 1-9 risky squares (greedy_quiet_root)
+    __shared__ GreedyLds<W> S;
     GBL_STAMP(0);
     GBL_STAMP_REAL(0);
     Lane L;
@@ -919,11 +1084,10 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
         L.valid = L.lane < L.rows;
         L.b = L.tile * kTile + L.lane;
     }
-    GreedyHead h{0ull, 0ull, 0ull, 0ull, 0, -1};
-    GreedyPlan plan{GreedyDom{0ull, {63u, 63u, 63u}, {0u, 0u, 0u}}, 0ull};
     Planes p{0u, 0u, 0u};
     uint32_t prev3 = 0x00FFFFFFu, h0 = 0xFFFFu, h1 = 0xFFFFu, h2 = 0xFFFFu;
-    int total = 0, me = 0;
+    int me = 0;
+    uint64_t mask = 0;
     if (owner) {
         // per-board scalars first, branch-free from a clamped index: in flight together with the tile (see k_step);
         // the history of BOTH agents (6 bytes, 2-byte aligned), the mover picks its three below
@@ -937,25 +1101,6 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
         load_state(state, s_state, L, r);
         p = planes_of(L, r);
         me = L.valid ? (tm != 0) : 0;
-        if (depth > 1) {
-            s_board[L.lane][0] = p.nz;
-            s_board[L.lane][1] = p.neg;
-            s_board[L.lane][2] = p.odd;
-            s_board[L.lane][3] = (uint32_t)me;
-        }
-    }
-    // While the owners walk depth 1, the second wavefront finds out for every board whether the OPPONENT could win on
-    // the root at once (greedy_quiet_root: as expensive as the depth-1 walk itself, and off the owners' serial path).
-    if (depth > 1 && W > 1) {
-        pool_fence<W>();
-        if ((slot >> 6) == 1) {
-            const Planes q{s_board[L.lane][0], s_board[L.lane][1], s_board[L.lane][2]};
-            const GreedyQuiet g = greedy_quiet_root(q, (int)s_board[L.lane][3]);
-            s_quiet[L.lane] = (g.quiet ? 1u : 0u) | (g.risky << 1);
-        }
-    }
-    if (owner) {
-        uint64_t mask;
         if (mask_in) {
             tile_in<kActions>(mask_in + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
             wave_lds_fence();
@@ -968,116 +1113,14 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
         }
         if (!L.valid) mask = 0;
         if (hist && L.valid)  // bytes 0-2: player_1's last three actions, bytes 3-5: player_2's
-            prev3 = me ? ((h1 >> 8) | (h2 << 8)) & 0x00FFFFFFu : (h0 | (h1 << 16)) & 0x00FFFFFFu;
-        h = greedy_head(p, me, mask, depth);  // invalid lanes: empty mask, nothing to do
-        if (depth > 1) {
-            s_legal[L.lane] = h.legal_me;
-            s_threat[L.lane] = 0ull;
-            s_allwin[L.lane] = 0ull;
-            s_second[L.lane] = 0ull;
-            s_block[L.lane] = 0ull;
-            s_flegal[L.lane] = 0ull;
-            s_defer[L.lane] = 0ull;
-            if (L.lane == 0) s_deferred = 0;
-        }
+            prev3 = hist_prev3(h0, h1, h2, me);
     }
-    if (depth > 1) {
-        if (W > 1) pool_fence<W>();  // the second wavefront's verdicts are in
-        if (owner) {
-            // twin placements are not evaluated a second time; placements from hand not at all on a root where the
-            // opponent has no winning move (greedy_quiet_root), else behind a smaller one on the same square only
-            // if that one turns out not to be calm (greedy_dominance)
-            GreedyQuiet g;
-            if (W > 1) {
-                const uint32_t v = s_quiet[L.lane];
-                g = GreedyQuiet{(v & 1u) != 0, v >> 1, greedy_from_hand(p, me)};
-            } else {
-                g = greedy_quiet_root(p, me);
-            }
-            plan = greedy_plan(h, p, me, g);
-            s_work[L.lane] = plan.dom.first;
-        }
-    }
-    GBL_STAMP(1);
-    GBL_STAMP_DECL(2);
-    if (depth > 1) {
-        auto record = [&](uint32_t o, uint32_t a, uint32_t sum) {
-            if (sum & 1u) {
-                s_reply[o][a] = (uint16_t)sum;
-                atomicOr(&s_threat[o], 1ull << a);
-                if (sum & (1u << 7)) atomicOr(&s_second[o], 1ull << a);
-                if (sum & (1u << 8)) atomicOr(&s_block[o], 1ull << a);
-                if ((s_legal[o] >> ((sum >> 1) & 63u)) & 1ull) atomicOr(&s_flegal[o], 1ull << a);
-            }
-            if (sum >> 15) atomicOr(&s_allwin[o], 1ull << a);
-        };
-        pool_fence<W>();
-        // The pair lists, by all W wavefronts: lane = board.  One ballot per candidate compacts the boards that have
-        // it (no per-lane loop, no divergence); the order of a list is irrelevant, results land in per-board sets.
-        for (int sg = slot >> 6; sg < kSegs; sg += W) {
-            const uint32_t wk = (uint32_t)(s_work[L.lane] >> (sg * kSeg)) & (uint32_t)((1ull << kSeg) - 1ull);
-            const uint32_t tag = ((uint32_t)L.lane << 8) + (uint32_t)(sg * kSeg);
-            uint16_t *seg = s_pair + sg * kSegCap;
-            uint32_t cnt = 0;  // wave-uniform
-#pragma unroll
-            for (int j = 0; j < kSeg; ++j) {
-                const bool has = (wk >> j) & 1u;
-                const unsigned long long m = __ballot(has);
-                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, cnt));
-                if (has) seg[at] = (uint16_t)(tag + j);
-                cnt += (uint32_t)__popcll(m);
-            }
-            if (L.lane == 0) s_count[sg] = (int)cnt;
-        }
-        pool_fence<W>();
-        int seg_end[kSegs];  // cumulative list lengths
-        total = 0;
-#pragma unroll
-        for (int w = 0; w < kSegs; ++w) seg_end[w] = (total += s_count[w]);
-        auto pair_at = [&](int g) -> uint32_t {
-            int w = 0, start = 0;
-#pragma unroll
-            for (int k = 0; k + 1 < kSegs; ++k) {
-                w += g >= seg_end[k] ? 1 : 0;
-                start = g >= seg_end[k] ? seg_end[k] : start;
-            }
-            return s_pair[w * kSegCap + (g - start)];
-        };
-        // first round: the cheap evaluation; the few pairs where a lift could hand us a line are set aside
-        for (int g = slot; g < total; g += kTile * W) {
-            const uint32_t pair = pair_at(g), o = pair >> 8, a = pair & 0xFFu;
-            const Planes q{s_board[o][0], s_board[o][1], s_board[o][2]};
-            const uint32_t sum = greedy_reply<false>(q, (int)s_board[o][3], s_legal[o], a);
-            if (sum == kGreedyDefer) {
-                s_again[atomicAdd(&s_deferred, 1)] = (uint16_t)pair;
-                atomicOr(&s_defer[o], 1ull << a);
-            } else {
-                record(o, a, sum);
-            }
-        }
-        pool_fence<W>();
-        // the placements held back behind a smaller one on the same square whose stand-in was not calm join the exact
-        // round (a couple per board: they fit the round the set-aside pairs need anyway)
-        if (owner)
-            for (uint64_t it = greedy_second_round(plan.dom, s_threat[L.lane] | s_defer[L.lane]) | plan.exact; it; it &= it - 1)
-                s_again[atomicAdd(&s_deferred, 1)] = (uint16_t)(((uint32_t)L.lane << 8) | (uint32_t)__builtin_ctzll(it));
-        pool_fence<W>();
-        GBL_STAMP_SET(2);
-        const int again = s_deferred;
-        for (int g = slot; g < again; g += kTile * W) {
-            const uint32_t pair = s_again[g], o = pair >> 8, a = pair & 0xFFu;
-            const Planes q{s_board[o][0], s_board[o][1], s_board[o][2]};
-            record(o, a, greedy_reply<true>(q, (int)s_board[o][3], s_legal[o], a));
-        }
-        pool_fence<W>();
-    }
-    GBL_STAMP(3);
+    TileStamps ts{};
+    const GreedyResult g = greedy_tile<W>(S, slot, p, me, mask, depth, depth > 1, prev3, ts);
+    GBL_STAMP_VAL(1, ts.t[0]);
+    GBL_STAMP_VAL(2, ts.t[1]);
+    GBL_STAMP_VAL(3, ts.t[2]);
     if (!owner) return;
-    if (depth > 1)  // :103-157 on the owner's lane, in closed form over the candidate sets
-        greedy_replay_closed(h, ReplySets{s_threat[L.lane], s_allwin[L.lane], s_second[L.lane], s_block[L.lane],
-                                          s_flegal[L.lane]},
-                             [&](int a) { return (uint32_t)s_reply[L.lane][((h.dup >> a) & 1ull) ? a - 9 : a]; });
-    GreedyResult g = greedy_finish(h, prev3);
     if (cand_out) {
         uint32_t d[14];
         mask_row(g.cands, d);
@@ -1102,6 +1145,162 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
     GBL_STAMP_DRAIN(5);
     GBL_STAMP_FLUSH(L.tile);
 }
+
+// gbl_collect_policy: gbl_collect with a DEVICE-SIDE POLICY per side -- masked-random, or the greedy lookahead of
+// GreedyGobbletPolicy.compute_action (depth 1 / 2) -- `plies` plies per launch, every ply materialised in its trajectory
+// slot.  The reference plays whole games with the greedy policy on either or both sides (tutorials/GreedyAgent/
+// tutorial_greedy.py:16-54: one policy object acting for both agents, the first two plies of a game drawn at random;
+// greedy_policy_tianshou.py:63-84: greedy against a learner); here the decision (greedy_tile, all W wavefronts of the
+// workgroup), the fallback draw (:211-217), the history append (:219), the move, winner, auto-reset and the next
+// observation / mask all happen inside one launch, the tile's boards living in LDS and registers between the plies.
+// Wavefront 0 owns the boards and does everything but the pooled depth-2 evaluations.
+// (Register budget: four wavefronts per SIMD = 128 VGPRs.  Left alone the compiler takes ~160 -- the ply loop keeps the
+// decision's literal constants live across iterations -- which costs a wavefront of occupancy for nothing.)
+#ifndef GBL_CP_WAVES_PER_EU
+#define GBL_CP_WAVES_PER_EU 4
+#endif
+template <int W>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 ? GBL_CP_WAVES_PER_EU : 1, 8))) void k_collect_policy(
+    int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n, int64_t ntiles, uint64_t seed, uint64_t env_base,
+    const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies, int8_t *__restrict__ done, int64_t ply_stride,
+    int64_t tile_stride, int32_t *__restrict__ actions_t, int8_t *__restrict__ winner_t, int8_t *__restrict__ reward_t,
+    int8_t *__restrict__ done_t, int8_t *__restrict__ to_move_t, int8_t *__restrict__ mask_t, int8_t *__restrict__ obs_t,
+    int32_t *__restrict__ chosen_t, int8_t *__restrict__ how_t, int8_t *__restrict__ cand_t, int8_t *__restrict__ hist,
+    int policy0, int policy1, int opening_plies, int illegal_mode, int64_t *__restrict__ counters, int32_t *__restrict__ turn)
+{
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    __shared__ GreedyLds<W> S;
+    static_assert(GreedyLds<W>::kScratchBytes >= 4 * image_words<kObs>(), "the output image fits the idle pair lists");
+    uint32_t *const s_out = S.scratch();
+    if (ply_dev) ply0 += *ply_dev;
+    Lane L;
+    if (!lane_setup<1, false>(L, n, ntiles)) return;  // the same for every thread of the workgroup
+    const int slot = L.lane;
+    const bool owner = slot < kTile;
+    if (W > 1) {
+        L.lane = slot & (kTile - 1);
+        L.valid = L.lane < L.rows;
+        L.b = L.tile * kTile + L.lane;
+    }
+    const bool deep = policy0 > 1 || policy1 > 1;
+    Planes p{0u, 0u, 0u};
+    int mover = 0, dn = 0, tabs = 0;
+    uint32_t hp0 = 0x00FFFFFFu, hp1 = 0x00FFFFFFu;  // the two agents' last three actions, one per byte (0xFF = none)
+    Draw4 block{{0u, 0u, 0u, 0u}};
+    const ImageRow row{reinterpret_cast<uint8_t *>(s_state) + L.lane * kCells};
+    uint64_t legal = 0;
+    uint32_t games = 0, w1 = 0, w2 = 0;
+    if (owner) {
+        const int64_t bs = L.valid ? L.b : n - 1;
+        const int tm = to_move[bs];
+        if (turn) tabs = turn[bs];
+        if (hist) {
+            const uint16_t *hp = reinterpret_cast<const uint16_t *>(hist + bs * 6);
+            const uint32_t h0 = hp[0], h1 = hp[1], h2 = hp[2];
+            hp0 = hist_prev3(h0, h1, h2, 0);
+            hp1 = hist_prev3(h0, h1, h2, 1);
+        }
+        uint32_t r[7];
+        load_state(state, s_state, L, r, [&] { block = draw_block(seed, env_base + (uint64_t)L.b, ply0); });
+        mover = L.valid && tm != 0;
+        p = planes_of(L, r);
+        legal = legal54(p, mover);
+    }
+    TileStamps ts{};
+    for (uint32_t t = 0; t < plies; ++t) {
+        const uint32_t ply = ply0 + t;
+        const int pol = mover ? policy1 : policy0;
+        // the greedy policy acts on this board at this ply (tutorial_greedy.py:34-49: not on a game's opening plies)
+        const bool gre = owner && L.valid && pol > 0 && tabs >= opening_plies;
+        const uint32_t prev3 = mover ? hp1 : hp0;
+        const GreedyResult g = greedy_tile<W>(S, slot, p, mover, gre ? legal : 0ull, pol, deep, prev3, ts);
+        if (!owner) continue;
+        int action;
+        {
+            // :211-217 with the library's sampler on generator stream 1 (as gbl_greedy_act, keyed by the ply index)
+            uint32_t r = 0;
+            if (__ballot(gre && g.fallback)) r = draw32(seed, env_base + (uint64_t)L.b, ply, kStreamGreedy);
+            const int greedy_action = g.fallback ? pick54(g.cands, r) : g.chosen;
+            const int random_action = pick54(legal, draw_word(block, ply));
+            action = gre ? greedy_action : random_action;
+            if (gre) {  // :219: the acting agent's history takes the returned action
+                const uint32_t np3 = (prev3 >> 8) | (((uint32_t)action & 0xFFu) << 16);
+                hp0 = mover ? hp0 : np3;
+                hp1 = mover ? np3 : hp1;
+            }
+        }
+        if (t + 1 < plies && ((ply + 1) & 3u) == 0) block = draw_block(seed, env_base + (uint64_t)L.b, ply + 1);
+        const Ply y = play_ply(p, row, mover, legal, action, illegal_mode);
+        dn = y.terminal ? 1 : 0;
+        if (y.terminal) {  // raw_env.reset, gobblet.py:275-290
+            p = Planes{0u, 0u, 0u};
+            mover = 0;
+            row.reset();
+        }
+        tabs = next_turn(tabs, y, 1);
+        if (counters) {
+            games += __popcll(__ballot(L.valid && y.terminal));
+            w1 += __popcll(__ballot(L.valid && y.winner == 1));
+            w2 += __popcll(__ballot(L.valid && y.winner == -1));
+        }
+        const int64_t cell = (int64_t)t * ply_stride + L.tile * tile_stride;
+        if (L.valid) {
+            const int64_t at = cell + L.lane;
+            if (actions_t) actions_t[at] = action;
+            if (winner_t) winner_t[at] = (int8_t)y.winner;
+            if (reward_t) reinterpret_cast<uint16_t *>(reward_t)[at] = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
+            if (done_t) done_t[at] = (int8_t)dn;
+            if (to_move_t) to_move_t[at] = (int8_t)mover;
+            if (chosen_t) chosen_t[at] = (gre && !g.fallback) ? g.chosen : -1;
+            if (how_t) how_t[at] = (int8_t)(gre ? (g.fallback ? GBL_HOW_FALLBACK : GBL_HOW_GREEDY) : GBL_HOW_RANDOM);
+        }
+        constexpr int kPolicy = kStoreStreamDrop;
+        auto mask_rows = [&](uint64_t bits, int8_t *__restrict__ dst) {  // (store_mask / store_obs with few registers)
+            uint32_t d[14];
+            mask_row(bits, d);
+            row_stage<kActions>(s_out, L.lane, d);
+            wave_lds_fence();
+            tile_out_narrow<kActions, kPolicy, 2>(dst, s_out, L.lane, L.rows);
+            wave_lds_fence();
+        };
+        wave_lds_fence();
+        if (cand_t) mask_rows(gre ? g.cands : 0ull, cand_t + cell * kActions);
+        if (obs_t) {
+            obs_image_zero(s_out, L.lane);
+            wave_lds_fence();
+            obs_scatter(s_out, L.lane, p, mover);
+            wave_lds_fence();
+            tile_out_narrow<kObs, kPolicy, 2>(obs_t + cell * kObs, s_out, L.lane, L.rows);
+            wave_lds_fence();
+        }
+        legal = legal54(p, mover);  // the next mover's: stored now, the next ply's policy is handed it
+        if (mask_t) mask_rows(legal, mask_t + cell * kActions);
+    }
+    if (!owner) return;
+    wave_lds_fence();  // every lane's byte patches are in the state image
+    tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
+    if (L.valid) {
+        to_move[L.b] = (int8_t)mover;
+        done[L.b] = (int8_t)dn;
+        if (turn) turn[L.b] = tabs;
+        if (hist) {
+            uint16_t *hp = reinterpret_cast<uint16_t *>(hist + L.b * 6);
+            hp[0] = (uint16_t)(hp0 & 0xFFFFu);
+            hp[1] = (uint16_t)(((hp0 >> 16) & 0xFFu) | ((hp1 & 0xFFu) << 8));
+            hp[2] = (uint16_t)((hp1 >> 8) & 0xFFFFu);
+        }
+    }
+    if (counters && L.lane == 0) {
+        unsigned long long *c = reinterpret_cast<unsigned long long *>(counters) +
+                                (size_t)(L.tile % GBL_COUNTER_STRIPES) * GBL_COUNTER_STRIDE;
+        atomicAdd(c + 0, (unsigned long long)L.rows * plies);
+        if (games) atomicAdd(c + 1, (unsigned long long)games);
+        if (w1) atomicAdd(c + 2, (unsigned long long)w1);
+        if (w2) atomicAdd(c + 3, (unsigned long long)w2);
+    }
+}
+
+int greedy_waves(int depth, int64_t n);  // (defined with the greedy entry points below)
 
 }  // namespace
 
@@ -1430,7 +1629,20 @@ int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_t
                 int64_t n, int64_t ply_stride, int64_t tile_stride, uint64_t seed, uint64_t env_base, uint32_t ply0,
                 const uint32_t *ply_dev, uint32_t plies, int illegal_mode, int64_t *counters, int32_t *turn, void *stream)
 {
+    return gbl_collect_from(state, to_move, done, nullptr, actions_traj, winner_traj, reward_traj, done_traj, to_move_traj,
+                            mask_traj, obs_traj, n, ply_stride, tile_stride, seed, env_base, ply0, ply_dev, plies,
+                            illegal_mode, counters, turn, stream);
+}
+
+int gbl_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *first_actions, int32_t *actions_traj,
+                     int8_t *winner_traj, int8_t *reward_traj, int8_t *done_traj, int8_t *to_move_traj, int8_t *mask_traj,
+                     int8_t *obs_traj, int64_t n, int64_t ply_stride, int64_t tile_stride, uint64_t seed,
+                     uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev, uint32_t plies, int illegal_mode,
+                     int64_t *counters, int32_t *turn, void *stream)
+{
     GBL_CHECK_N(n);
+    if (first_actions && (reinterpret_cast<uintptr_t>(first_actions) & 3u))
+        return fail(GBL_ERR_ALIGN, "first_actions must be 4-byte aligned");
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done");
     if (illegal_mode != GBL_ILLEGAL_NOOP && illegal_mode != GBL_ILLEGAL_TERMINATE)
         return fail(GBL_ERR_ARG, "illegal_mode must be GBL_ILLEGAL_NOOP or GBL_ILLEGAL_TERMINATE");
@@ -1462,12 +1674,13 @@ int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_t
 #define GBL_COLLECT_K2(M, O, D)                                                                                         \
     hipLaunchKernelGGL((k_collect2<M, O, D>), dim3((uint32_t)g.ntiles), dim3(128), 0, s, state, to_move, n, g.ntiles, seed, \
                        env_base, ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj,        \
-                       reward_traj, done_traj, to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn)
+                       reward_traj, done_traj, to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn,         \
+                       first_actions)
 #define GBL_COLLECT_KN(M, O, D, N)                                                                                      \
     hipLaunchKernelGGL((k_collect<M, O, D, N>), dim3(g.grid), dim3(64), 0, s, state, to_move, n, g.ntiles, seed, env_base, \
                        ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj, reward_traj,     \
                        done_traj,                                                                                      \
-                       to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn)
+                       to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn, first_actions)
 #define GBL_COLLECT(M, O)                                       \
     if (ply_dev) { GBL_COLLECT_K(M, O, true); }                 \
     else { GBL_COLLECT_K(M, O, false); }
@@ -1480,6 +1693,55 @@ int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_t
 #undef GBL_COLLECT_KN
 #undef GBL_COLLECT_K2
     GBL_LAUNCHED("gbl_collect");
+}
+
+int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *hist, int32_t *actions_traj,
+                       int8_t *winner_traj, int8_t *reward_traj, int8_t *done_traj, int8_t *to_move_traj, int8_t *mask_traj,
+                       int8_t *obs_traj, int32_t *chosen_traj, int8_t *how_traj, int8_t *cand_traj, int64_t n,
+                       int64_t ply_stride, int64_t tile_stride, uint64_t seed, uint64_t env_base, uint32_t ply0,
+                       const uint32_t *ply_dev, uint32_t plies, int policy0, int policy1, int opening_plies,
+                       int illegal_mode, int64_t *counters, int32_t *turn, void *stream)
+{
+    GBL_CHECK_N(n);
+    GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done");
+    if (illegal_mode != GBL_ILLEGAL_NOOP && illegal_mode != GBL_ILLEGAL_TERMINATE)
+        return fail(GBL_ERR_ARG, "illegal_mode must be GBL_ILLEGAL_NOOP or GBL_ILLEGAL_TERMINATE");
+    if (policy0 < GBL_POLICY_RANDOM || policy0 > GBL_POLICY_GREEDY3 || policy1 < GBL_POLICY_RANDOM || policy1 > GBL_POLICY_GREEDY3)
+        return fail(GBL_ERR_ARG, "policy0 / policy1: GBL_POLICY_RANDOM, GBL_POLICY_GREEDY1, _GREEDY2 or _GREEDY3");
+    if (opening_plies < 0) return fail(GBL_ERR_ARG, "opening_plies < 0");
+    if (opening_plies > 0 && !turn) return fail(GBL_ERR_ARG, "opening_plies > 0 needs the per-board turn counter (turn must not be NULL)");
+    if (plies == 0) return GBL_OK;
+    {   // the (ply, tile) cells of 64 boards must start 16-byte aligned and must not overlap (as gbl_collect)
+        const int64_t tiles = (n + kTile - 1) / kTile;
+        const bool aligned = ply_stride > 0 && tile_stride > 0 && !(ply_stride & 15) && !(tile_stride & 15);
+        const bool time_major = tile_stride >= kTile && (plies == 1 || ply_stride >= (tiles - 1) * tile_stride + kTile);
+        const bool tile_major = ply_stride >= kTile && (tiles == 1 || tile_stride >= ((int64_t)plies - 1) * ply_stride + kTile);
+        if (!aligned || !(time_major || tile_major))
+            return fail(GBL_ERR_ARG, "ply_stride / tile_stride: multiples of 16 boards that keep the (ply, tile) cells apart");
+    }
+    GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask_traj, "mask_traj"); GBL_ALIGNED(obs_traj, "obs_traj"); GBL_ALIGNED(cand_traj, "cand_traj");
+    if (hist && (reinterpret_cast<uintptr_t>(hist) & 1u)) return fail(GBL_ERR_ALIGN, "hist must be 2-byte aligned");
+    if (reward_traj && (reinterpret_cast<uintptr_t>(reward_traj) & 1u))
+        return fail(GBL_ERR_ALIGN, "reward_traj must be 2-byte aligned");
+    if ((actions_traj && (reinterpret_cast<uintptr_t>(actions_traj) & 3u)) || (chosen_traj && (reinterpret_cast<uintptr_t>(chosen_traj) & 3u)))
+        return fail(GBL_ERR_ALIGN, "actions_traj / chosen_traj must be 4-byte aligned");
+    if (turn && (reinterpret_cast<uintptr_t>(turn) & 3u)) return fail(GBL_ERR_ALIGN, "turn must be 4-byte aligned");
+    if (counters && (reinterpret_cast<uintptr_t>(counters) & 127u))
+        return fail(GBL_ERR_ALIGN, "counters must be 128-byte aligned");
+    const Geometry g = geometry(n);
+    hipStream_t s = (hipStream_t)stream;
+    const int depth = policy0 > policy1 ? policy0 : policy1;
+    const int waves = depth <= 1 ? 1 : greedy_waves(depth, n);
+#define GBL_CP(W)                                                                                                          \
+    hipLaunchKernelGGL(k_collect_policy<W>, dim3(g.grid), dim3(64 * W), 0, s, state, to_move, n, g.ntiles, seed, env_base,  \
+                       ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj, reward_traj,        \
+                       done_traj, to_move_traj, mask_traj, obs_traj, chosen_traj, how_traj, cand_traj, hist, policy0,      \
+                       policy1, opening_plies, illegal_mode, counters, turn)
+    if (waves >= 8) GBL_CP(8);
+    else if (waves >= 4) GBL_CP(4);
+    else GBL_CP(1);
+#undef GBL_CP
+    GBL_LAUNCHED("gbl_collect_policy");
 }
 
 int gbl_collect_variant(int64_t n, uint32_t plies, int with_mask, int with_obs)

@@ -58,7 +58,14 @@ class BatchedGobblet:
         # rollout tallies, striped (include/gobblet_hip.h); totals via the ``counters`` property
         self._counters = torch.zeros((nat.COUNTER_STRIPES, nat.COUNTER_STRIDE), dtype=torch.int64, device=dev)
         self._ply, self._ply_dev = 0, None  # lockstep ply counter (keys the sampler), see ``ply`` / ``device_ply``
+        self.policy_hist = None             # int8 (N, 2, 3): the device-side greedy policies' last three actions per agent
         self.reset()
+
+    def reset_policy_history(self) -> None:
+        """Empty action histories (-1) for the device-side greedy policies of ``collect(policies=...)``."""
+        if self.policy_hist is None:
+            self.policy_hist = torch.empty((self.num_envs, 2, 3), dtype=torch.int8, device=self.device)
+        self.policy_hist.fill_(-1)
 
     @property
     def squares(self) -> torch.Tensor:
@@ -163,6 +170,8 @@ class BatchedGobblet:
               "ply": self.ply, "seed": self.seed, "env_base": self.env_base}
         if self.turn is not None:
             sd["turn"] = self.turn.clone()
+        if self.policy_hist is not None:
+            sd["policy_hist"] = self.policy_hist.clone()
         return sd
 
     def load_state_dict(self, sd: dict) -> None:
@@ -177,6 +186,11 @@ class BatchedGobblet:
                 self.turn.copy_(sd["turn"])
             else:
                 self.turn.zero_()
+        if "policy_hist" in sd:
+            self.reset_policy_history()
+            self.policy_hist.copy_(sd["policy_hist"])
+        elif self.policy_hist is not None:
+            self.reset_policy_history()
         self.ply, self.seed, self.env_base = int(sd["ply"]), int(sd["seed"]), int(sd["env_base"])
         self.refresh()
 
@@ -204,9 +218,15 @@ class BatchedGobblet:
         return self.observe(), self.rewards, self.done, self.winner
 
     # -- trajectory collection: T plies per launch, every ply materialised -------------------------------------
+    POLICIES = {"random": nat.POLICY_RANDOM, "greedy1": nat.POLICY_GREEDY1, "greedy": nat.POLICY_GREEDY2,
+                "greedy2": nat.POLICY_GREEDY2, "greedy3": nat.POLICY_GREEDY3}
+
     def trajectory_buffers(self, plies: int, layout: str = "time", pad_boards: int | None = None,
-                           placement: str = "auto") -> dict:
+                           placement: str = "auto", policy_outputs: bool = False, candidates: bool = False) -> dict:
         """Device tensors for ``collect``.
+
+        policy_outputs: also "chosen" (int32) and "how" (int8: 0 random ply, 1 greedy choice, 2 greedy fallback draw) for
+        ``collect(policies=...)``; candidates: also "candidates" (int8 (..., 54): the greedy policy's ``actions_depth1``).
 
         placement "auto" (default): when the observation and the mask trajectory are large enough to be HBM streams
         (64 MiB each), the mask array is placed so that the two do not share one of the three 96 GiB classes of the
@@ -274,8 +294,10 @@ class BatchedGobblet:
             full["action_mask"] = make_mask()
             if placement != "any":
                 placed["why"] = "arrays too small to probe" if self.observation is not None else "no observation stream"
+        extra = ((("chosen", torch.int32, ()), ("how", torch.int8, ())) if policy_outputs else ()) + \
+                ((("candidates", torch.int8, (nat.ACTIONS,)),) if candidates else ())
         for key, dtype, tail in (("actions", torch.int32, ()), ("winner", torch.int8, ()), ("rewards", torch.int8, (2,)),
-                                 ("done", torch.int8, ()), ("to_move", torch.int8, ())):
+                                 ("done", torch.int8, ()), ("to_move", torch.int8, ())) + extra:
             full[key] = torch.zeros(lead + tail, dtype=dtype, device=dev)
         out = {k: (v[:, :n] if layout == "time" else v) for k, v in full.items()}
         out.update(_full=full, _plies=T, _layout=layout, _ply_stride=ply_stride, _tile_stride=tile_stride,
@@ -291,7 +313,7 @@ class BatchedGobblet:
         return v.reshape((v.shape[0] * 64,) + tuple(v.shape[2:]))[:n]
 
     def collect(self, plies: int, out: dict | None = None, count: bool = False, refresh: bool = True,
-                layout: str = "time") -> dict:
+                layout: str = "time", policies=None, opening_plies: int = 0, first_actions=None) -> dict:
         """``plies`` masked-random plies with auto-reset in ONE launch (``gbl_collect``), EVERY ply materialised:
         entry t of the returned tensors -- "actions", "winner", "rewards", "done", "to_move", "action_mask",
         "observation", each (plies, N, ...) in the default time-major layout -- is what ``rollout(1)`` called ``plies``
@@ -302,14 +324,27 @@ class BatchedGobblet:
         ``rewards`` attributes are copied from the last ply (device copies of ~180 B per board: a pure collector that
         only reads the trajectory passes ``refresh=False`` and calls ``refresh()`` before it next steps by hand).
         ``out``: a dict from ``trajectory_buffers(plies)`` to reuse (a replay buffer's staging area; placed for speed,
-        see there).  Without it every call allocates fresh, unplaced buffers."""
+        see there).  Without it every call allocates fresh, unplaced buffers.
+
+        ``first_actions`` (int (N,)): the first ply plays these actions -- an external policy's decision -- and the
+        remaining plies are sampled (``gbl_collect_from``): ``collect(2, out, first_actions=a)`` is one decision of the
+        policy plus the masked-random opponent's reply in one launch; the policy reads ``out["observation"][1]`` /
+        ``out["action_mask"][1]`` next.
+
+        ``policies=(p1, p2)``: how player_1 / player_2 choose their moves INSIDE the launch (``gbl_collect_policy``) --
+        "random" (the masked-uniform sampler, the default for both) or "greedy1" / "greedy" (= "greedy2") / "greedy3": the
+        reference's ``GreedyGobbletPolicy.compute_action`` at that depth (greedy_policy.py:38-221) with its fallback draw
+        and per-agent action history (``policy_hist``, int8 (N, 2, 3), kept across calls and across games like the
+        reference's policy object; ``reset_policy_history()`` clears it).  ``opening_plies``: the first plies of every
+        game are drawn at random by a greedy side too (tutorials/GreedyAgent/tutorial_greedy.py:34-41 uses 2; needs
+        ``track_turn=True``).  Buffers made with ``policy_outputs=True`` also receive "chosen" / "how" (/ "candidates")."""
         if not self.auto_reset:
             raise ValueError("collect() plays with auto-reset; this environment was created with auto_reset=False")
         T = int(plies)
         if out is None:
             # (fresh buffers on every call: no probe, no placement -- a loop that cares about the last 20 % makes its
             # buffers once with trajectory_buffers() and passes them as `out`)
-            out = self.trajectory_buffers(T, layout=layout, placement="any")
+            out = self.trajectory_buffers(T, layout=layout, placement="any", policy_outputs=policies is not None)
         if out["_plies"] != T:
             raise ValueError("trajectory buffers were made for %d plies" % out["_plies"])
         f, n = out["_full"], self.num_envs
@@ -317,14 +352,36 @@ class BatchedGobblet:
         need = (T - 1) * out["_ply_stride"] + (-(-n // 64) - 1) * out["_tile_stride"] + 64
         if f["actions"].device != self.device or cells < need - 64 + (n - 1) % 64 + 1 or ("observation" in f) != (self.observation is not None):
             raise ValueError("trajectory buffers do not fit this environment (made by another one?)")
-        nat.check(self._lib.gbl_collect(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
-                                        f["actions"].data_ptr(), f["winner"].data_ptr(), f["rewards"].data_ptr(),
-                                        f["done"].data_ptr(), f["to_move"].data_ptr(), f["action_mask"].data_ptr(),
-                                        f["observation"].data_ptr() if "observation" in f else None, n,
-                                        out["_ply_stride"], out["_tile_stride"], self.seed, self.env_base, self._ply,
-                                        nat.ptr(self._ply_dev), T, self.illegal_mode,
-                                        self._counters.data_ptr() if count else None, nat.ptr(self.turn),
-                                        self._stream()), "gbl_collect")
+        if first_actions is not None and policies is not None:
+            raise ValueError("first_actions and policies exclude each other")
+        fa = None if first_actions is None else _as_i32(first_actions, n, self.device, "first_actions")
+        if policies is not None:
+            try:
+                p0, p1 = (self.POLICIES[x] if isinstance(x, str) else int(x) for x in policies)
+            except (KeyError, ValueError, TypeError):
+                raise ValueError("policies: a pair out of %s" % sorted(self.POLICIES)) from None
+            if opening_plies and self.turn is None:
+                raise ValueError("opening_plies needs the per-board turn counter: create the environment with track_turn=True")
+            if self.policy_hist is None:
+                self.reset_policy_history()
+            nat.check(self._lib.gbl_collect_policy(
+                self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(), self.policy_hist.data_ptr(),
+                f["actions"].data_ptr(), f["winner"].data_ptr(), f["rewards"].data_ptr(), f["done"].data_ptr(),
+                f["to_move"].data_ptr(), f["action_mask"].data_ptr(),
+                f["observation"].data_ptr() if "observation" in f else None, nat.ptr(f.get("chosen")), nat.ptr(f.get("how")),
+                nat.ptr(f.get("candidates")), n, out["_ply_stride"], out["_tile_stride"], self.seed, self.env_base, self._ply,
+                nat.ptr(self._ply_dev), T, p0, p1, int(opening_plies), self.illegal_mode,
+                self._counters.data_ptr() if count else None, nat.ptr(self.turn), self._stream()), "gbl_collect_policy")
+        else:
+            nat.check(self._lib.gbl_collect_from(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
+                                                 nat.ptr(fa), f["actions"].data_ptr(), f["winner"].data_ptr(),
+                                                 f["rewards"].data_ptr(), f["done"].data_ptr(), f["to_move"].data_ptr(),
+                                                 f["action_mask"].data_ptr(),
+                                                 f["observation"].data_ptr() if "observation" in f else None, n,
+                                                 out["_ply_stride"], out["_tile_stride"], self.seed, self.env_base,
+                                                 self._ply, nat.ptr(self._ply_dev), T, self.illegal_mode,
+                                                 self._counters.data_ptr() if count else None, nat.ptr(self.turn),
+                                                 self._stream()), "gbl_collect")
         self._ply += T
         if not refresh:
             return out

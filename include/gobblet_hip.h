@@ -264,6 +264,42 @@ int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_t
                 int64_t n, int64_t ply_stride, int64_t tile_stride, uint64_t seed, uint64_t env_base, uint32_t ply0,
                 const uint32_t *ply_dev, uint32_t plies, int illegal_mode, int64_t *counters, int32_t *turn,
                 void *stream);
+/* Trajectory collection with a DEVICE-SIDE POLICY per side (the reference plays whole games with its greedy policy on
+ * either or both sides: tutorials/GreedyAgent/tutorial_greedy.py:16-54 -- one GreedyGobbletPolicy object acting for both
+ * agents, the first two plies of every game drawn at random -- and gobblet_rl/game/greedy_policy_tianshou.py:63-84,
+ * greedy against a learner or a random agent).  gbl_collect with the mover's action chosen inside the launch:
+ *   policy0 / policy1  how player_1 / player_2 decide: GBL_POLICY_RANDOM = the masked-uniform draw of gbl_sample
+ *                      (generator stream 0, ply index ply0 + t); GBL_POLICY_GREEDY1 / 2 / 3 =
+ *                      GreedyGobbletPolicy.compute_action at that depth (greedy_policy.py:38-221; 3 decides like 2, see
+ *                      gbl_greedy) on the mover's legal mask and hist[b][mover], and where the reference falls back to
+ *                      np.random.choice(actions_depth1) (:211-217) the gbl_sample rule over that candidate set on
+ *                      generator stream 1 with the same ply index -- exactly gbl_greedy_act(call = ply0 + t) -- followed
+ *                      by the history append of :219.
+ *   opening_plies      a greedy side plays the first plies of every game (turn[b] < opening_plies) at random instead,
+ *                      without touching its history (tutorial_greedy.py:34-41 uses 2); needs `turn`.  0: none.
+ *   hist               int8[n][2][3], read at entry, holds the histories after the last ply on return (they survive a
+ *                      game's end, like the reference's policy object); NULL = empty histories, nothing written back.
+ * Ply t of board b leaves in cell(t, b) (see gbl_collect) what gbl_greedy_act / gbl_sample + gbl_step with auto-reset would:
+ * the seven arrays of gbl_collect, and (each may be NULL)
+ *   chosen_traj int32[cells]      gbl_greedy's action_out: the chosen action, -1 where the fallback fired or no greedy
+ *                                 policy acted
+ *   how_traj    int8 [cells]      GBL_HOW_RANDOM / GBL_HOW_GREEDY / GBL_HOW_FALLBACK: how the action was arrived at
+ *   cand_traj   int8 [cells][54]  membership of actions_depth1 at :211 (zeros where no greedy policy acted)
+ * Everything else (strides, state / to_move / done / turn / counters at entry and on return, ply_dev) as gbl_collect. */
+#define GBL_POLICY_RANDOM 0
+#define GBL_POLICY_GREEDY1 1
+#define GBL_POLICY_GREEDY2 2
+#define GBL_POLICY_GREEDY3 3
+#define GBL_HOW_RANDOM 0
+#define GBL_HOW_GREEDY 1
+#define GBL_HOW_FALLBACK 2
+int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *hist, int32_t *actions_traj,
+                       int8_t *winner_traj, int8_t *reward_traj, int8_t *done_traj, int8_t *to_move_traj, int8_t *mask_traj,
+                       int8_t *obs_traj, int32_t *chosen_traj, int8_t *how_traj, int8_t *cand_traj, int64_t n,
+                       int64_t ply_stride, int64_t tile_stride, uint64_t seed, uint64_t env_base, uint32_t ply0,
+                       const uint32_t *ply_dev, uint32_t plies, int policy0, int policy1, int opening_plies,
+                       int illegal_mode, int64_t *counters, int32_t *turn, void *stream);
+
 /* Which kernel a gbl_collect call of this shape runs (no launch; >= 0, or GBL_ERR_ARG): benchmarks and profiles label
  * their records with it instead of re-deriving the library's dispatch rule.
  *   GBL_COLLECT_STREAM  k_collect,  one wavefront per tile of 64 boards, trajectory rows stored non-temporally
@@ -273,6 +309,18 @@ int gbl_collect(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_t
 #define GBL_COLLECT_CACHED 1
 #define GBL_COLLECT_PAIR 2
 int gbl_collect_variant(int64_t n, uint32_t plies, int with_mask, int with_obs);
+/* gbl_collect whose FIRST ply plays caller-supplied actions (first_actions int32[n]; NULL = gbl_collect): the collector
+ * step of a policy that lives outside the library against masked-random replies -- the loops of the reference's trainers
+ * with a random opponent (gobblet_rl/examples/example_tianshou_DQN.py: MultiAgentPolicyManager([agent, RandomPolicy])) --
+ * in ONE launch per decision of the external policy instead of one per ply: with plies = 2, slot 0 receives the given
+ * action's ply (illegal or out-of-range actions per illegal_mode, as gbl_step) and slot 1 the sampled reply (ply index
+ * ply0 + 1), both with auto-reset; the policy reads slot 1's observation and mask for its next decision.  plies = 1 is
+ * gbl_step_into with auto-reset; plies > 2 lets the sampler play on.  Everything else as gbl_collect. */
+int gbl_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *first_actions, int32_t *actions_traj,
+                     int8_t *winner_traj, int8_t *reward_traj, int8_t *done_traj, int8_t *to_move_traj, int8_t *mask_traj,
+                     int8_t *obs_traj, int64_t n, int64_t ply_stride, int64_t tile_stride, uint64_t seed,
+                     uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev, uint32_t plies, int illegal_mode,
+                     int64_t *counters, int32_t *turn, void *stream);
 /* *counter += by, enqueued on the stream (device uint32). */
 int gbl_counter_add(uint32_t *counter, uint32_t by, void *stream);
 

@@ -291,7 +291,7 @@ def batch_rollout(state, to_move, done, seed, env_base, ply0, plies, illegal_mod
 def batch_greedy(state, to_move, mask=None, hist=None, depth=2, threads=1):
     """Returns (action int32[n] (-1 where fallback), cand_mask int8[n,54], fallback int8[n]).  threads > 1: the
     boards are cut into contiguous chunks evaluated by a thread pool (ctypes releases the GIL; boards are
-    independent; the greedy_work() tallies are then approximate)."""
+    independent; the greedy_work() tallies count the calling thread's work only)."""
     n = state.shape[0]
     act = np.zeros(n, np.int32); cm = np.zeros((n, ACTIONS), np.int8); fb = np.zeros(n, np.int8)
     L = lib()
@@ -310,14 +310,53 @@ def batch_greedy(state, to_move, mask=None, hist=None, depth=2, threads=1):
     return act, cm, fb
 
 
-def batch_greedy_act(state, to_move, hist, seed, env_base, call, mask=None, depth=2):
+def batch_greedy_act(state, to_move, hist, seed, env_base, call, mask=None, depth=2, threads=1):
     """One policy step: (returned action, chosen-or--1, candidate mask, fallback flag); ``hist`` (n,2,3) int8 is
-    updated in place."""
+    updated in place.  threads > 1: contiguous chunks of boards on a thread pool (boards are independent; the fallback
+    draw is keyed by env_base + board index, so a chunk is handed its own base)."""
     n = state.shape[0]
     act = np.zeros(n, np.int32); ch = np.zeros(n, np.int32); cm = np.zeros((n, ACTIONS), np.int8); fb = np.zeros(n, np.int8)
-    lib().gbo_batch_greedy_act(_p(state), _p(to_move), _p(mask), _p(hist), int(depth), int(seed), int(env_base),
-                               int(call), _p(act, C.c_int32), _p(ch, C.c_int32), _p(cm), _p(fb), n)
+    L = lib()
+
+    def part(lo, hi):
+        L.gbo_batch_greedy_act(_p(state[lo:hi]), _p(to_move[lo:hi]), _p(mask[lo:hi]) if mask is not None else None,
+                               _p(hist[lo:hi]), int(depth), int(seed), int(env_base) + lo, int(call),
+                               _p(act[lo:hi], C.c_int32), _p(ch[lo:hi], C.c_int32), _p(cm[lo:hi]), _p(fb[lo:hi]), hi - lo)
+    if threads <= 1 or n < 2 * threads:
+        part(0, n)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        cuts = [n * i // threads for i in range(threads + 1)]
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda i: part(cuts[i], cuts[i + 1]), range(threads)))
     return act, ch, cm, fb
+
+
+def batch_policy_ply(state, to_move, done, hist, turn, seed, env_base, ply, policies, opening_plies=0,
+                     illegal_mode=ILLEGAL_NOOP, threads=1, want_obs=True):
+    """One lockstep ply with a policy per side, restated from the reference's callers (tutorials/GreedyAgent/
+    tutorial_greedy.py:16-54, example_basic.py:50-67): the mover of each board plays policies[mover] -- 0 = the
+    masked-uniform draw (batch_sample, ply index `ply`), 1 / 2 / 3 = GreedyGobbletPolicy.compute_action at that depth
+    through batch_greedy_act(call = ply) (fallback draw and history append included) -- except that a greedy side draws
+    at random while the board's turn counter is below opening_plies (and leaves its history alone); then batch_step with
+    auto-reset.  state / to_move / done / hist / turn are updated in place.
+    Returns dict(actions, chosen, how, cands, winner, reward, mask, obs)."""
+    n = state.shape[0]
+    mask = batch_legal_mask(state, to_move)
+    actions = batch_sample(mask, seed, env_base, ply)
+    pol = np.where(to_move != 0, policies[1], policies[0]).astype(np.int32)
+    gre = (pol > 0) & (turn >= opening_plies)
+    chosen = np.full(n, -1, np.int32); how = np.zeros(n, np.int8); cands = np.zeros((n, ACTIONS), np.int8)
+    for depth in sorted(set(pol[gre].tolist())):
+        sel = gre & (pol == depth)
+        h = hist.copy()
+        act, ch, cm, fb = batch_greedy_act(state, to_move, h, seed, env_base, ply, depth=depth, threads=threads)
+        actions[sel] = act[sel]; chosen[sel] = ch[sel]; cands[sel] = cm[sel]; how[sel] = 1 + fb[sel]
+        hist[sel] = h[sel]
+    o = batch_step(state, to_move, done, actions, illegal_mode=illegal_mode, auto_reset=True, threads=threads,
+                   want_obs=want_obs, turn=turn)
+    o.update(actions=actions, chosen=chosen, how=how, cands=cands)
+    return o
 
 
 def greedy_work(reset=True):

@@ -572,9 +572,10 @@ int gbo_greedy_decode_obs(const int8_t *obs, int8_t *squares)
 }
 
 /* Algorithmic work counters of gbo_greedy: legality tests and leaf
- * evaluations (play_turn + check_for_winner) performed.  Not thread-safe; read by the bench on a
- * single-threaded sample. */
-static int64_t g_greedy_legality_tests = 0, g_greedy_leaves = 0;
+ * evaluations (play_turn + check_for_winner) performed BY THE CALLING THREAD (thread-local: as plain
+ * globals every increment of a threaded run bounced one cache line between the cores, and sixteen
+ * threads ran at the speed of one); read by the bench on a single-threaded sample. */
+static __thread int64_t g_greedy_legality_tests = 0, g_greedy_leaves = 0;
 void gbo_greedy_work(int64_t *out, int reset)
 {
     out[0] = g_greedy_legality_tests;

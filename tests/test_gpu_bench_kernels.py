@@ -222,12 +222,58 @@ def test_bench_step_mode_vs_oracle(G):
                 assert np.array_equal(npy(obs["observation"]), o["obs"])
 
 
+@pytest.mark.parametrize("n,T,illegal,with_obs", [(131072, 2, "noop", True), (262144, 2, "terminate", True),
+                                                  (4099, 3, "terminate", False), (131073, 2, "noop", True), (70, 1, "noop", True)])
+def test_collect_from_external_first_ply_vs_oracle(G, n, T, illegal, with_obs):
+    """gbl_collect_from (bench records step_reply_*): the first ply plays caller-supplied actions -- an external policy's,
+    some of them illegal or out of range -- the rest are sampled; k_collect2 at 131 072 boards, k_collect beyond.  Three
+    launches in a row (the policy: the library's sampler on the previous launch's last mask, with wild actions thrown
+    in), every slot against the oracle: batch_step for the given actions, batch_rollout for the replies."""
+    seed, base, warm = 6, 314159, 8
+    im = 0 if illegal == "noop" else 1
+    env, s, tm, dn = warm_pair(G, n, seed, base, warm, with_observation=with_obs, illegal_mode=illegal)
+    env.refresh()
+    tr = env.trajectory_buffers(T, placement="any")
+    rng = np.random.default_rng(1)
+    mask = env.action_mask
+    for launch in range(3):
+        ply0 = warm + launch * T
+        acts = oracle.batch_sample(npy(mask), seed + 1, base, ply0)          # "the external policy"
+        wild = rng.random(n) < 0.15
+        acts = np.where(wild, rng.integers(-3, 60, n), acts).astype(np.int32)
+        env.collect(T, out=tr, first_actions=torch.from_numpy(acts).to(DEV), refresh=False)
+        torch.cuda.synchronize()
+        for t_ in range(T):
+            if t_ == 0:
+                o = oracle.batch_step(s, tm, dn, acts, illegal_mode=im, auto_reset=True, threads=THREADS, want_obs=with_obs)
+                exp_a = acts
+            else:
+                o = oracle.batch_rollout(s, tm, dn, seed, base, ply0 + t_, 1, illegal_mode=im, threads=THREADS, want_obs=with_obs)
+                exp_a = o["actions"]
+            assert np.array_equal(npy(tr["actions"][t_]), exp_a), ("actions", launch, t_)
+            assert np.array_equal(npy(tr["winner"][t_]), o["winner"]) and np.array_equal(npy(tr["rewards"][t_]), o["reward"])
+            assert np.array_equal(npy(tr["done"][t_]), dn) and np.array_equal(npy(tr["to_move"][t_]), tm), (launch, t_)
+            assert np.array_equal(npy(tr["action_mask"][t_]), o["mask"]), ("mask", launch, t_)
+            if with_obs:
+                assert np.array_equal(npy(tr["observation"][t_]), o["obs"]), ("obs", launch, t_)
+        assert np.array_equal(npy(env.squares), s) and np.array_equal(npy(env.to_move), tm)
+        mask = tr["action_mask"][T - 1]
+    assert env.ply == warm + 3 * T
+    with pytest.raises(ValueError):
+        env.collect(T, out=tr, first_actions=torch.zeros(n, dtype=torch.int32, device=DEV), policies=("random", "random"))
+
+
 def test_bench_config_keys_are_all_covered(G):
     """Every sub-record bench.py emits has a test above (or the named one elsewhere) that compares its kernel with the
     oracle: the key lists are read from bench.py itself, so a new record without a test fails here."""
     import bench
-    keys = set(bench.CONFIG_RECORDS)
-    covered = set(COLLECT_RECORDS) | set(SINGLE_PLY_RECORDS) | {"c5_greedy_65536", "greedy_collect_65536", "step_pipeline_1048576",
-                                                                "two_stream_single_ply_131072", "two_stream_single_ply_262144",
-                                                                "step_into_sampler_131072"}
+    keys = set(bench.CONFIG_RECORDS) | set(bench.EXTRA_RECORDS)
+    covered = set(COLLECT_RECORDS) | set(SINGLE_PLY_RECORDS) | {
+        "step_pipeline_1048576",   # test_bench_step_mode_vs_oracle
+        "c5_greedy_65536",         # test_gpu_parity.py::test_greedy_config5_full_size
+        "greedy_collect_65536",    # test_gpu_policy_collect.py::test_policy_collect_config5_size_selfplay
+        # gbl_collect_from, T = 2: test_collect_from_external_first_ply_vs_oracle; the two-stream records launch the
+        # single_ply kernel on half batches (test_bench_single_ply_record_vs_oracle[single_ply_131072] covers that size's half
+        # through single_ply_4096 .. 131072: the same instantiation at every size below 2^21 boards)
+        "step_reply_131072", "step_reply_262144", "two_stream_single_ply_131072", "two_stream_single_ply_262144"}
     assert keys <= covered, keys - covered
