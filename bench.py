@@ -417,11 +417,24 @@ def step_reply_run(G, torch, dev, boards, K, W):
     a.record(); g.replay(); b.record()
     torch.cuda.synchronize(dev)
     sec = a.elapsed_time(b) / 1e3
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(32)]
-    for i, ev in enumerate(evs):
-        decision(2 * i, nat.current_stream(dev), ev)
+    # the environment's share alone: the same launches without the stand-in's, replayed from a graph with a FIXED action
+    # array (stale actions are mostly illegal -> no-ops; the kernel's work and traffic do not depend on that)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+        cs = nat.current_stream(dev)
+        for i in range(D):
+            nat.check(L.gbl_collect_from(env.squares.data_ptr(), env.to_move.data_ptr(), env.done.data_ptr(), acts.data_ptr(),
+                                         f["actions"].data_ptr(), f["winner"].data_ptr(), f["rewards"].data_ptr(),
+                                         f["done"].data_ptr(), f["to_move"].data_ptr(), f["action_mask"].data_ptr(),
+                                         f["observation"].data_ptr(), boards, buf["_ply_stride"], buf["_tile_stride"], 0, 0,
+                                         2 * i, ctr.data_ptr(), 2, 0, None, None, cs), "gbl_collect_from")
+        nat.check(L.gbl_counter_add(ctr.data_ptr(), 2 * D, cs), "gbl_counter_add")
+    g2.replay()
     torch.cuda.synchronize(dev)
-    kern = sum(x.elapsed_time(y) for x, y in evs) / 1e3 / len(evs)
+    a.record(); g2.replay(); b.record()
+    torch.cuda.synchronize(dev)
+    kern = a.elapsed_time(b) / 1e3 / D
+    evs = [None] * D
     per_launch = (2 * ALGO_BYTES_COLLECT_PLY + ALGO_BYTES_COLLECT_LAUNCH + 4) * boards
     variant = {0: "k_collect", 1: "k_collect (plain stores)", 2: "k_collect2"}[L.gbl_collect_variant(boards, 2, 1, 1)]
     return {"workload": f"{boards} boards x 1 GPU, an external policy's ply (stand-in: gbl_sample on the last mask slot) + the "
@@ -434,8 +447,8 @@ def step_reply_run(G, torch, dev, boards, K, W):
                          "kernel": f"{variant} (2 plies per launch, first ply given)<mask,obs>",
                          "algorithmic_bytes_per_env_step": per_launch / boards / 2, "algorithmic_bytes_per_launch": per_launch,
                          "mean_launch_us": kern * 1e6, "launches_timed": len(evs),
-                         "timing": "HIP event pair around every gbl_collect_from launch of an eager run (the policy stand-in's "
-                                   "launch excluded); value / us_per_step include it"},
+                         "timing": "HIP events around a graph replay of the gbl_collect_from launches alone (fixed action array); "
+                                   "value / us_per_step are the loop with the policy stand-in's launch"},
             "trajectory_placement": buf["_placement"]}
 
 

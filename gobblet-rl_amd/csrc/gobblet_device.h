@@ -1067,6 +1067,132 @@ __device__ __forceinline__ GreedyQuiet greedy_quiet_root(const Planes &p, int me
     return g;
 }
 
+// ---- placements from hand, settled from the ROOT position alone (round 3) ------------------------------------------------
+// Let R be the OPPONENT's winning moves on the root, were it to move.  After a placement `a` of ours from hand on q every
+// winning reply is in R: a reply that wins after `a` is legal on the root too (we only covered q) and finds there the same
+// tops except that q is what it was instead of ours -- which only helps the opponent -- or, if it gobbles our new piece,
+// exactly the same tops.  And a2 = (piece pj, square q2) in R stops winning ("is defused") exactly if
+//   q is where pj stands (we gobbled it: it cannot move), or
+//   q = q2 and our piece is at least as large as pj (the reply is no longer legal), or
+//   q != q2 lies on EVERY line the opponent holds after a2 (each of them now has our piece on it),
+// provided no lift by the opponent can hand US a line (reply_is_plain), which with "have" = our tops and our pieces
+// directly under the opponent's is the case iff q does not complete a line inside have ("risky" squares).  So for the
+// placements from hand on non-risky squares the whole summary -- first / second winning reply, the first one we could
+// play ourselves -- follows from R and a few set operations per member of R, with no depth-2 evaluation at all: two
+// thirds of the (board, candidate) pairs of the masked-random mix.  Placements on risky squares are evaluated.  (R empty
+// -- half of the boards -- means: none of these placements has a winning reply; that special case was round 2's
+// "quiet root".)  Pinned against the exact evaluation on every candidate it settles: tests/emu (emu_greedy_root_rule).
+struct GreedyRoot {
+    uint64_t replies;    // R: the opponent's winning moves on the root
+    uint32_t risky;      // 9 bits: squares where a placement of ours is not "plain" (0x1FF if have already holds a line)
+};
+
+__device__ __forceinline__ uint64_t spread9(uint32_t squares)  // a 9-bit set of squares under all six pieces
+{
+    uint64_t x = squares & 0x1FFu;
+    x |= x << 9;
+    return x | x << 18 | x << 36;
+}
+
+__device__ __forceinline__ GreedyRoot greedy_root(const Planes &p, int me)
+{
+    const GreedyQuiet q = greedy_quiet_root(p, me);  // (the same two results: its test `quiet` is replies == 0)
+    uint64_t ow, ol;
+    outcomes54(p, 1 - me, ow, ol);
+    return GreedyRoot{ow & legal54(p, 1 - me), q.risky};
+}
+
+// the placements from hand (of any of our pieces, on any square: mask with the candidates) that do NOT defuse the
+// opponent's winning move a2 of the root
+__device__ __forceinline__ uint64_t greedy_undefused(const Planes &p, int me, uint32_t a2)
+{
+    const int opp = 1 - me;
+    const uint32_t pj = (a2 * 57u) >> 9, q2 = a2 - 9u * pj, kj = pj >> 1, first = (~pj) & 1u;
+    const uint32_t theirs = me ? (p.nz & ~p.neg) : (p.nz & p.neg);
+    const uint32_t stands = ((theirs & (first ? p.odd : ~p.odd)) >> (9u * kj)) & 0x1FFu;  // where pj stands (0: in hand)
+    const Planes d = moved(p, opp, a2);
+    const uint32_t ours_d = me ? (d.nz & d.neg) : (d.nz & ~d.neg), theirs_d = me ? (d.nz & ~d.neg) : (d.nz & d.neg);
+    const uint32_t t0 = theirs_d & 0x1FFu, t1 = (theirs_d >> 9) & 0x1FFu, t2 = (theirs_d >> 18) & 0x1FFu;
+    const uint32_t m1 = (ours_d >> 9) & 0x1FFu, m2 = (ours_d >> 18) & 0x1FFu;
+    const uint32_t o1 = m1 | t1, o2 = m2 | t2;
+    const uint32_t Tt = t2 | (~o2 & (t1 | (~o1 & t0)));  // the opponent's tops after a2
+    constexpr uint32_t L[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x111u, 0x054u};
+    uint32_t every = 0x1FFu;  // squares on every line the opponent then holds
+#pragma unroll
+    for (int l = 0; l < 8; ++l) every &= (L[l] & ~Tt) == 0 ? L[l] : 0x1FFu;
+    const uint32_t q2bit = 1u << q2, defuse = stands | (every & ~q2bit);
+    uint64_t u = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 3; ++k) {
+        const uint64_t uk = ~(defuse | (k >= kj ? q2bit : 0u)) & 0x1FFu;
+        u |= uk << (18u * k) | uk << (18u * k + 9u);
+    }
+    return u;
+}
+
+// The rule in the shape the kernel uses it: the members of R are dealt out as ITEMS (board, j), j = the member's rank in
+// R, to whichever lane is free; an item's lane leaves undef[j] = greedy_undefused(R's j-th member) & resolved in the
+// board's table, and the board's owner merges the table in ascending order -- the reference's reply order -- into the
+// candidate sets of greedy_replay_closed.  Boards with more than kRootItems members (rare) do not use the rule.
+constexpr int kRootItems = 6;
+
+struct GreedyHandSets {
+    uint64_t threat, second, block, flegal;
+};
+
+__device__ __forceinline__ GreedyHandSets greedy_hand_merge(uint64_t replies, uint64_t legal_me, const uint64_t (&undef)[kRootItems])
+{
+    GreedyHandSets s{0ull, 0ull, 0ull, 0ull};
+    uint64_t it = replies;
+#pragma unroll
+    for (int j = 0; j < kRootItems; ++j) {
+        const bool live = it != 0;
+        const uint32_t a2 = live ? (uint32_t)__builtin_ctzll(it) : 0u;
+        const uint64_t u = live ? undef[j] : 0ull;
+        const bool ours = live && ((legal_me >> a2) & 1ull);
+        s.second |= u & s.threat;
+        s.flegal |= ours ? (u & ~s.threat) : 0ull;  // the FIRST winning reply is a legal move of ours
+        s.block |= ours ? u : 0ull;
+        s.threat |= u;
+        it &= it - 1;
+    }
+    return s;
+}
+
+// the 16-bit summary (see greedy_reply) of ONE settled placement `a`, from the board's table
+__device__ __forceinline__ uint32_t greedy_hand_lookup(uint64_t replies, uint64_t legal_me, const uint64_t (&undef)[kRootItems], uint32_t a)
+{
+    uint64_t ow = 0, it = replies;
+#pragma unroll
+    for (int j = 0; j < kRootItems; ++j) {
+        const bool live = it != 0;
+        const uint32_t a2 = live ? (uint32_t)__builtin_ctzll(it) : 0u;
+        if (live && ((undef[j] >> a) & 1ull)) ow |= 1ull << a2;
+        it &= it - 1;
+    }
+    const uint64_t block = ow & legal_me;
+    uint32_t s = ow ? 1u : 0u;
+    s |= (ow ? (uint32_t)__builtin_ctzll(ow) : 0u) << 1;
+    s |= (ow & (ow - 1)) ? 1u << 7 : 0u;
+    s |= block ? 1u << 8 : 0u;
+    s |= (block ? (uint32_t)__builtin_ctzll(block) : 0u) << 9;
+    return s;
+}
+
+// Which candidates are evaluated (exactly, in the pooled round), which are settled from the root, and the root's
+// replies if they are to be dealt out as items.
+struct GreedyRootPlan {
+    uint64_t eval, resolved, items;
+};
+
+__device__ __forceinline__ GreedyRootPlan greedy_root_plan(const GreedyHead &h, const Planes &p, int me, const GreedyRoot &g)
+{
+    const uint64_t w0 = h.todo & ~h.dup;
+    const bool rule = __popcll(g.replies) <= kRootItems;
+    const uint64_t resolved = rule ? (w0 & greedy_from_hand(p, me) & ~spread9(g.risky)) : 0ull;
+    return GreedyRootPlan{w0 & ~resolved, resolved, resolved ? g.replies : 0ull};
+}
+
 // The candidates' way through the kernel: `first` are evaluated cheaply in the pooled round, `exact` go straight to the
 // exact round, and greedy_second_round() names those that join it depending on the first round's results.
 struct GreedyPlan {

@@ -882,23 +882,25 @@ struct GreedyLds {
     static constexpr int kSegs = W >= 2 ? W : 2, kSeg = (kActions + kSegs - 1) / kSegs, kSegCap = kTile * kSeg;
     static_assert(kSeg <= 32, "a segment's candidates fit one 32-bit word");
     alignas(16) uint16_t pair[kSegs * kSegCap];
-    uint16_t again[kTile * kActions];    // pairs that need the exact evaluation (greedy_reply<true>)
+    unsigned long long undef[kTile][kRootItems];  // per board and member j of the root's replies: greedy_undefused & resolved
+    uint16_t item[kTile * kRootItems];   // (board << 8) | j of every member of a root's replies that is dealt out
     uint32_t board[kTile][4];            // planes nz, neg, odd; bit 0: the agent to move, bit 1: the board wants depth 2
     uint64_t legal[kTile];               // its legal moves on the root position
-    unsigned long long work[kTile];      // the candidates of a board that get an evaluation of their own
+    unsigned long long work[kTile];      // the candidates of a board that are evaluated
+    unsigned long long replies[kTile];   // the opponent's winning moves on the root (greedy_root); after the plan: those dealt out
+    uint32_t risky[kTile];               // 9 bits: squares where a placement from hand has to be evaluated (greedy_root)
     int count[kSegs];
+    int items;
     uint16_t reply[kTile][kActions];     // greedy_reply() of (board, candidate), where bit 0 is set
     unsigned long long threat[kTile];    // candidates whose summary has bit 0 / bit 15 / bit 7 / bit 8,
     unsigned long long allwin[kTile];    // and those whose first winning reply is a legal move of ours
     unsigned long long second[kTile];    // (the sets greedy_replay_closed works on)
     unsigned long long block[kTile];
     unsigned long long flegal[kTile];
-    int deferred;
-    unsigned long long defer[kTile];     // the set-aside pairs as per-board candidate sets (first round)
-    uint32_t quiet[kTile];               // per board: bit 0 quiet root, bits 1-9 risky squares (greedy_quiet_root)
-    // The two pair lists are dead between two decisions (written after the first barriers of greedy_tile, read before
-    // its last): a kernel that decides in a loop stages its output rows through them in between.
-    static constexpr int kScratchBytes = (int)(sizeof(uint16_t) * (kSegs * kSegCap + kTile * kActions));
+    // The pair list and the table are dead between two decisions (written after the first barriers of greedy_tile, read
+    // before it returns): a kernel that decides in a loop stages its output rows through them in between.
+    static constexpr int kScratchBytes = (int)(sizeof(uint16_t) * kSegs * kSegCap + sizeof(unsigned long long) * kTile * kRootItems);
+    static_assert(sizeof(uint16_t) * kSegs * kSegCap % 8 == 0, "the table follows the pair list without padding");
     __device__ __forceinline__ uint32_t *scratch() { return reinterpret_cast<uint32_t *>(pair); }
 };
 
@@ -907,7 +909,16 @@ struct GreedyLds {
 // handed to the policy (0: nothing to decide on this board -- an invalid lane, or in gbl_collect_policy a board whose
 // mover plays at random), the board's depth (1, 2; 3 decides like 2) and the agent's last three actions; the other
 // threads' arguments are ignored and they get an empty result.  deep: some board of SOME tile of the launch may want
-// depth 2 (workgroup-uniform: it decides whether the pooled rounds and their barriers exist at all).
+// depth 2 (workgroup-uniform: it decides whether the pooled round and its barriers exist at all).
+//
+// Depth 2 in five steps between barriers:  (A) the owners publish their boards;  (B) wavefront 0 walks depth 1
+// (greedy_head) while wavefront 1 finds the opponent's winning moves on the root and the risky squares (greedy_root);
+// (C) the owners split their candidates (greedy_root_plan): placements from hand on non-risky squares are settled from the
+// root's replies R, everything else is evaluated;  (D) all wavefronts lay out the work -- the (board, candidate) pairs
+// and the (board, member of R) items -- with one ballot per candidate / rank;  (E) all lanes take pairs (one moved +
+// legal54 + outcomes54 each: every reply's result at once) and items (greedy_undefused) whoever owns them, leaving
+// 16-bit summaries, candidate-set bits and table rows in LDS; then the owners replay the reference's depth-2 loop in closed
+// form over the sets (greedy_replay_closed).
 // Safe to call in a loop: what the owners read last (replay) and write first (heads) is their own wavefront's business,
 // and everybody else's reads of an iteration lie before its last barrier.
 template <int W>
@@ -915,26 +926,26 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<W> &S, int slot, c
                                                     int depth, bool deep, uint32_t prev3, TileStamps &ts)
 {
     constexpr int kSegs = GreedyLds<W>::kSegs, kSeg = GreedyLds<W>::kSeg, kSegCap = GreedyLds<W>::kSegCap;
-    const int lane = slot & (kTile - 1);
+    const int lane = slot & (kTile - 1), wave = slot >> 6;
     const bool owner = slot < kTile;
     GreedyHead h{0ull, 0ull, 0ull, 0ull, 0, -1};
-    GreedyPlan plan{GreedyDom{0ull, {63u, 63u, 63u}, {0u, 0u, 0u}}, 0ull};
-    int total = 0;
-    const bool two = owner && depth > 1 && mask != 0;  // this board takes part in the depth-2 rounds
+    GreedyRootPlan plan{0ull, 0ull, 0ull};
+    const bool two = owner && depth > 1 && mask != 0;  // this board takes part in the depth-2 round
     if (owner && deep) {
         S.board[lane][0] = p.nz;
         S.board[lane][1] = p.neg;
         S.board[lane][2] = p.odd;
         S.board[lane][3] = (uint32_t)me | (two ? 2u : 0u);
     }
-    // While the owners walk depth 1, the second wavefront finds out for every board whether the OPPONENT could win on
-    // the root at once (greedy_quiet_root: as expensive as the depth-1 walk itself, and off the owners' serial path).
+    // (B) While the owners walk depth 1, the second wavefront looks at the root from the OPPONENT's side (greedy_root: as
+    // expensive as the depth-1 walk itself, and off the owners' serial path).
     if (deep && W > 1) {
         pool_fence<W>();
-        if ((slot >> 6) == 1 && (S.board[lane][3] & 2u)) {
+        if (wave == 1 && (S.board[lane][3] & 2u)) {
             const Planes q{S.board[lane][0], S.board[lane][1], S.board[lane][2]};
-            const GreedyQuiet g = greedy_quiet_root(q, (int)(S.board[lane][3] & 1u));
-            S.quiet[lane] = (g.quiet ? 1u : 0u) | (g.risky << 1);
+            const GreedyRoot g = greedy_root(q, (int)(S.board[lane][3] & 1u));
+            S.replies[lane] = g.replies;
+            S.risky[lane] = g.risky;
         }
     }
     if (owner) {
@@ -946,45 +957,28 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<W> &S, int slot, c
             S.second[lane] = 0ull;
             S.block[lane] = 0ull;
             S.flegal[lane] = 0ull;
-            S.defer[lane] = 0ull;
-            if (lane == 0) S.deferred = 0;
         }
     }
+    GreedyRoot root{0ull, 0u};
     if (deep) {
-        if (W > 1) pool_fence<W>();  // the second wavefront's verdicts are in
+        if (W > 1) pool_fence<W>();  // the second wavefront's findings are in
         if (owner) {
-            // twin placements are not evaluated a second time; placements from hand not at all on a root where the
-            // opponent has no winning move (greedy_quiet_root), else behind a smaller one on the same square only
-            // if that one turns out not to be calm (greedy_dominance)
+            // (C) twin placements are not evaluated a second time; placements from hand on non-risky squares not at all
             if (two) {
-                GreedyQuiet g;
-                if (W > 1) {
-                    const uint32_t v = S.quiet[lane];
-                    g = GreedyQuiet{(v & 1u) != 0, v >> 1, greedy_from_hand(p, me)};
-                } else {
-                    g = greedy_quiet_root(p, me);
-                }
-                plan = greedy_plan(h, p, me, g);
+                root = W > 1 ? GreedyRoot{S.replies[lane], S.risky[lane]} : greedy_root(p, me);
+                plan = greedy_root_plan(h, p, me, root);
             }
-            S.work[lane] = plan.dom.first;
+            S.work[lane] = plan.eval;
+            S.replies[lane] = plan.items;
         }
     }
     GBL_TILE_STAMP(ts, 0);
     if (deep) {
-        auto record = [&](uint32_t o, uint32_t a, uint32_t sum) {
-            if (sum & 1u) {
-                S.reply[o][a] = (uint16_t)sum;
-                atomicOr(&S.threat[o], 1ull << a);
-                if (sum & (1u << 7)) atomicOr(&S.second[o], 1ull << a);
-                if (sum & (1u << 8)) atomicOr(&S.block[o], 1ull << a);
-                if ((S.legal[o] >> ((sum >> 1) & 63u)) & 1ull) atomicOr(&S.flegal[o], 1ull << a);
-            }
-            if (sum >> 15) atomicOr(&S.allwin[o], 1ull << a);
-        };
         pool_fence<W>();
-        // The pair lists, by all W wavefronts: lane = board.  One ballot per candidate compacts the boards that have
-        // it (no per-lane loop, no divergence); the order of a list is irrelevant, results land in per-board sets.
-        for (int sg = slot >> 6; sg < kSegs; sg += W) {
+        // (D) The work lists, by all W wavefronts: lane = board.  One ballot per candidate (per rank in R) compacts the
+        // boards that have it -- no per-lane loop, no divergence; the order of a list is irrelevant, results land in
+        // per-board sets and table rows.
+        for (int sg = wave; sg < kSegs; sg += W) {
             const uint32_t wk = (uint32_t)(S.work[lane] >> (sg * kSeg)) & (uint32_t)((1ull << kSeg) - 1ull);
             const uint32_t tag = ((uint32_t)lane << 8) + (uint32_t)(sg * kSeg);
             uint16_t *seg = S.pair + sg * kSegCap;
@@ -999,9 +993,22 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<W> &S, int slot, c
             }
             if (lane == 0) S.count[sg] = (int)cnt;
         }
+        if (wave == W - 1) {
+            const uint32_t nr = (uint32_t)__popcll(S.replies[lane]);
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int j = 0; j < kRootItems; ++j) {
+                const bool has = (uint32_t)j < nr;
+                const unsigned long long m = __ballot(has);
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, cnt));
+                if (has) S.item[at] = (uint16_t)(((uint32_t)lane << 8) + (uint32_t)j);
+                cnt += (uint32_t)__popcll(m);
+            }
+            if (lane == 0) S.items = (int)cnt;
+        }
         pool_fence<W>();
         int seg_end[kSegs];  // cumulative list lengths
-        total = 0;
+        int total = 0;
 #pragma unroll
         for (int w = 0; w < kSegs; ++w) seg_end[w] = (total += S.count[w]);
         auto pair_at = [&](int g) -> uint32_t {
@@ -1013,39 +1020,51 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<W> &S, int slot, c
             }
             return S.pair[w * kSegCap + (g - start)];
         };
-        // first round: the cheap evaluation; the few pairs where a lift could hand us a line are set aside
+        // (E) the pairs, from the first wavefront up ...
         for (int g = slot; g < total; g += kTile * W) {
             const uint32_t pair = pair_at(g), o = pair >> 8, a = pair & 0xFFu;
             const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
-            const uint32_t sum = greedy_reply<false>(q, (int)(S.board[o][3] & 1u), S.legal[o], a);
-            if (sum == kGreedyDefer) {
-                S.again[atomicAdd(&S.deferred, 1)] = (uint16_t)pair;
-                atomicOr(&S.defer[o], 1ull << a);
-            } else {
-                record(o, a, sum);
+            const uint32_t sum = greedy_reply<true>(q, (int)(S.board[o][3] & 1u), S.legal[o], a);
+            if (sum & 1u) {
+                S.reply[o][a] = (uint16_t)sum;
+                atomicOr(&S.threat[o], 1ull << a);
+                if (sum & (1u << 7)) atomicOr(&S.second[o], 1ull << a);
+                if (sum & (1u << 8)) atomicOr(&S.block[o], 1ull << a);
+                if ((S.legal[o] >> ((sum >> 1) & 63u)) & 1ull) atomicOr(&S.flegal[o], 1ull << a);
             }
+            if (sum >> 15) atomicOr(&S.allwin[o], 1ull << a);
         }
-        pool_fence<W>();
-        // the placements held back behind a smaller one on the same square whose stand-in was not calm join the exact
-        // round (a couple per board: they fit the round the set-aside pairs need anyway)
-        if (owner)
-            for (uint64_t it = greedy_second_round(plan.dom, S.threat[lane] | S.defer[lane]) | plan.exact; it; it &= it - 1)
-                S.again[atomicAdd(&S.deferred, 1)] = (uint16_t)(((uint32_t)lane << 8) | (uint32_t)__builtin_ctzll(it));
-        pool_fence<W>();
-        GBL_TILE_STAMP(ts, 1);
-        const int again = S.deferred;
-        for (int g = slot; g < again; g += kTile * W) {
-            const uint32_t pair = S.again[g], o = pair >> 8, a = pair & 0xFFu;
+        // ... and the items, from the last wavefront down (it has the fewest pairs)
+        const int nitems = S.items;
+        for (int g = (W - 1 - wave) * kTile + lane; g < nitems; g += kTile * W) {
+            const uint32_t it = S.item[g], o = it >> 8, j = it & 0xFFu;
             const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
-            record(o, a, greedy_reply<true>(q, (int)(S.board[o][3] & 1u), S.legal[o], a));
+            const uint32_t a2 = kth_bit64(S.replies[o], j);
+            S.undef[o][j] = greedy_undefused(q, (int)(S.board[o][3] & 1u), a2);
         }
+        GBL_TILE_STAMP(ts, 1);
         pool_fence<W>();
     }
     GBL_TILE_STAMP(ts, 2);
     if (!owner) return GreedyResult{-1, 0ull, false};
-    if (two)  // :103-157 on the owner's lane, in closed form over the candidate sets
-        greedy_replay_closed(h, ReplySets{S.threat[lane], S.allwin[lane], S.second[lane], S.block[lane], S.flegal[lane]},
-                             [&](int a) { return (uint32_t)S.reply[lane][((h.dup >> a) & 1ull) ? a - 9 : a]; });
+    if (two) {  // :103-157 on the owner's lane, in closed form over the candidate sets
+        ReplySets r{S.threat[lane], S.allwin[lane], S.second[lane], S.block[lane], S.flegal[lane]};
+        uint64_t undef[kRootItems] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+        if (plan.items) {  // the placements settled from the root: the table's rows merged in the reference's reply order
+#pragma unroll
+            for (int j = 0; j < kRootItems; ++j) undef[j] = S.undef[lane][j] & plan.resolved;
+            const GreedyHandSets hs = greedy_hand_merge(plan.items, h.legal_me, undef);
+            r.threat |= hs.threat;
+            r.second |= hs.second;
+            r.block |= hs.block;
+            r.flegal |= hs.flegal;
+        }
+        greedy_replay_closed(h, r, [&](int a) {
+            const uint32_t twin = ((h.dup >> a) & 1ull) ? (uint32_t)a - 9u : (uint32_t)a;  // twin placements share a summary
+            return ((plan.resolved >> twin) & 1ull) ? greedy_hand_lookup(plan.items, h.legal_me, undef, twin)
+                                                    : (uint32_t)S.reply[lane][twin];
+        });
+    }
     return greedy_finish(h, prev3);
 }
 

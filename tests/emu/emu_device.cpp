@@ -365,7 +365,7 @@ void emu_decode_obs(const int8_t *obs, int8_t *state, int8_t *to_move, int64_t n
 
 // statistics of the pooled flow: pairs evaluated, pairs deferred to the exact evaluation, and pairs whose
 // cheap evaluation differs from the exact one (a bug if ever non-zero)
-static int64_t g_pairs = 0, g_deferred = 0, g_fast_mismatch = 0, g_held = 0, g_held_back = 0;
+static int64_t g_pairs = 0, g_deferred = 0, g_fast_mismatch = 0, g_held = 0, g_items = 0;
 // The rule of greedy_root_rule.h against the exact evaluation, on every candidate it would settle.
 // out: boards, candidates settled from the root, of them with a winning reply, placements sent to the exact evaluation
 // (risky squares), MISMATCHES (summary or candidate-set bits differ from greedy_reply<true>: must be 0)
@@ -408,7 +408,7 @@ void emu_greedy_stats(int64_t *out)
     out[1] = g_deferred;
     out[2] = g_fast_mismatch;
     out[3] = g_held;
-    out[4] = g_held_back;
+    out[4] = g_items;
 }
 
 // pooled != 0: the kernel's flow (candidate lists of a tile back to back, every pair evaluated by
@@ -454,20 +454,23 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
         }
         static uint16_t pair[64 * kActions], reply[64][kActions];
         uint64_t threat[64] = {0}, allwin[64] = {0}, second[64] = {0}, block[64] = {0}, flegal[64] = {0};
-        // first round: the candidates minus the placements held back behind a smaller one on the same square
-        // (greedy_dominance); the held ones whose stand-in turned out not to be calm join the exact round
-        GreedyDom DOM[64];
-        GreedyPlan PLAN[64];
-        uint64_t deferred_set[64] = {0};
+        // the kernel's flow (greedy_tile): the candidates split by greedy_root_plan -- placements from hand on non-risky
+        // squares are settled from the root's replies (table rows written by "item lanes", merged by the owner), all
+        // others are evaluated exactly
+        GreedyRootPlan PLAN[64];
+        static uint64_t undef[64][kRootItems];
         int total = 0;
         for (int l = 0; l < 64; ++l) {
-            PLAN[l] = greedy_plan(H[l], P[l], ME[l], greedy_quiet_root(P[l], ME[l]));
-            DOM[l] = PLAN[l].dom;
-            for (uint64_t it = pooled ? DOM[l].first : 0ull; it; it &= it - 1)
-                pair[total++] = (uint16_t)((l << 8) | __builtin_ctzll(it));
+            PLAN[l] = GreedyRootPlan{0ull, 0ull, 0ull};
+            for (int j = 0; j < kRootItems; ++j) undef[l][j] = 0xDEADBEEFDEADBEEFull;  // rows nobody writes are never read
+            if (pooled && depth > 1 && MASK[l] != 0) PLAN[l] = greedy_root_plan(H[l], P[l], ME[l], greedy_root(P[l], ME[l]));
+            for (uint64_t it = PLAN[l].eval; it; it &= it - 1) pair[total++] = (uint16_t)((l << 8) | __builtin_ctzll(it));
+            const int nr = __builtin_popcountll(PLAN[l].items);
+            for (int j = 0; j < nr; ++j) {  // the items (board, j)
+                undef[l][j] = greedy_undefused(P[l], ME[l], kth_bit64(PLAN[l].items, (uint32_t)j));
+                g_items++;
+            }
         }
-        static uint16_t again[64 * kActions];
-        int deferred = 0;
         auto record = [&](uint32_t o, uint32_t a, uint32_t sum) {
             if (sum & 1u) {
                 reply[o][a] = (uint16_t)sum;
@@ -478,46 +481,47 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
             }
             if (sum >> 15) allwin[o] |= 1ull << a;
         };
-        auto cheap_round = [&](int from, int to) {
-            for (int g = from; g < to; ++g) {
-                uint32_t o = pair[g] >> 8, a = pair[g] & 0xFFu;
-                uint32_t sum = greedy_reply<false>(P[o], ME[o], H[o].legal_me, a);
-                g_pairs++;
-                if (sum == kGreedyDefer) {
-                    again[deferred++] = pair[g];
-                    deferred_set[o] |= 1ull << a;
-                    g_deferred++;
-                } else {
-                    record(o, a, sum);
-                    if (sum != greedy_reply<true>(P[o], ME[o], H[o].legal_me, a)) g_fast_mismatch++;  // must stay 0
-                }
-            }
-        };
-        cheap_round(0, total);
-        if (pooled) {
-            for (int l = 0; l < 64; ++l) {
-                const uint64_t w0 = H[l].todo & ~H[l].dup, held = w0 & ~DOM[l].first;
-                const uint64_t second_round = greedy_second_round(DOM[l], threat[l] | deferred_set[l]) | PLAN[l].exact;
-                if (second_round & ~held) g_fast_mismatch++;  // only held candidates can come back
-                // (they join the exact round, as in the kernel)
-                for (uint64_t it = second_round; it; it &= it - 1) again[deferred++] = (uint16_t)((l << 8) | __builtin_ctzll(it));
-                // the rule itself: a held candidate that is never evaluated has summary 0
-                for (uint64_t it = held & ~second_round; it; it &= it - 1)
-                    if (greedy_reply<true>(P[l], ME[l], H[l].legal_me, (uint32_t)__builtin_ctzll(it)) != 0) g_fast_mismatch++;
-                g_held += __builtin_popcountll(held);
-                g_held_back += __builtin_popcountll(second_round);
-            }
+        for (int g = 0; g < total; ++g) {
+            const uint32_t o = pair[g] >> 8, a = pair[g] & 0xFFu;
+            const uint32_t sum = greedy_reply<true>(P[o], ME[o], H[o].legal_me, a);
+            g_pairs++;
+            record(o, a, sum);
+            // (the cheap evaluation is no longer used by the kernel; where it claims to apply it must still agree)
+            const uint32_t cheap = greedy_reply<false>(P[o], ME[o], H[o].legal_me, a);
+            if (cheap == kGreedyDefer) g_deferred++;
+            else if (cheap != sum) g_fast_mismatch++;
         }
-        for (int g = 0; g < deferred; ++g) {
-            uint32_t o = again[g] >> 8, a = again[g] & 0xFFu;
-            record(o, a, greedy_reply<true>(P[o], ME[o], H[o].legal_me, a));
+        uint64_t UND[64][kRootItems];
+        for (int l = 0; l < 64; ++l) {
+            for (int j = 0; j < kRootItems; ++j) UND[l][j] = 0ull;
+            if (!PLAN[l].items) continue;
+            for (int j = 0; j < kRootItems; ++j) UND[l][j] = (j < __builtin_popcountll(PLAN[l].items) ? undef[l][j] : 0ull) & PLAN[l].resolved;
+            const GreedyHandSets hs = greedy_hand_merge(PLAN[l].items, H[l].legal_me, UND[l]);
+            threat[l] |= hs.threat; second[l] |= hs.second; block[l] |= hs.block; flegal[l] |= hs.flegal;
         }
+        // THE RULE ITSELF, on every candidate it settles: the summary looked up in the table and the merged set bits must be
+        // what the exact evaluation gives (a settled candidate of a board with no replies to deal out: summary 0)
+        for (int l = 0; l < 64; ++l)
+            for (uint64_t it = PLAN[l].resolved; it; it &= it - 1) {
+                const uint32_t a = (uint32_t)__builtin_ctzll(it);
+                const uint32_t want = greedy_reply<true>(P[l], ME[l], H[l].legal_me, a);
+                const uint32_t got = PLAN[l].items ? greedy_hand_lookup(PLAN[l].items, H[l].legal_me, UND[l], a) : 0u;
+                const bool fl = (want & 1u) && ((H[l].legal_me >> ((want >> 1) & 63u)) & 1ull);
+                g_held++;
+                if (want != got || ((threat[l] >> a) & 1ull) != (want & 1u) || ((second[l] >> a) & 1ull) != ((want >> 7) & 1u) ||
+                    ((block[l] >> a) & 1ull) != ((want >> 8) & 1u) || ((flegal[l] >> a) & 1ull) != (fl ? 1u : 0u) || ((allwin[l] >> a) & 1ull))
+                    g_fast_mismatch++;
+            }
         for (int l = 0; l < 64; ++l) {
             bool valid = l < t.rows;
             int64_t b = t.tile * 64 + l;
             GreedyResult g;
             if (pooled) {
-                auto reply_of = [&](int a) { return (uint32_t)reply[l][((H[l].dup >> a) & 1ull) ? a - 9 : a]; };
+                auto reply_of = [&](int a) {
+                    const uint32_t twin = ((H[l].dup >> a) & 1ull) ? (uint32_t)a - 9u : (uint32_t)a;
+                    return ((PLAN[l].resolved >> twin) & 1ull) ? greedy_hand_lookup(PLAN[l].items, H[l].legal_me, UND[l], twin)
+                                                               : (uint32_t)reply[l][twin];
+                };
                 GreedyHead seq = H[l];  // the loop form and the closed form must agree on everything they leave behind
                 greedy_replay_sets(seq, threat[l], allwin[l], reply_of);
                 greedy_replay_closed(H[l], ReplySets{threat[l], allwin[l], second[l], block[l], flegal[l]}, reply_of);

@@ -167,11 +167,12 @@ def test_greedy_vs_oracle_selfplay(boards):
     for x, y in zip(e, o):
         assert np.array_equal(x, y)
     # (inside the pooled flow the closed form of the depth-2 loop, greedy_replay_closed, is cross-checked against the
-    #  loop form, greedy_replay_sets, on every board, the cheap reply evaluation against the exact one, and every placement
-    #  that is never evaluated because a smaller one on the same square was calm against its exact summary, which must be 0)
-    pairs, deferred, bad, held, held_back = emu.greedy_stats()
+    #  loop form, greedy_replay_sets, on every board; the cheap reply evaluation against the exact one wherever it claims
+    #  to apply; and EVERY placement from hand that the root rule settles without an evaluation -- its summary looked up
+    #  in the board's table and its bits in the merged candidate sets -- against its exact evaluation)
+    pairs, deferred, bad, settled, items = emu.greedy_stats()
     assert bad == 0
-    assert held > 0.2 * (pairs + held - held_back) and held_back < 0.5 * held  # the rule bites, and mostly holds
+    assert settled > 1.2 * pairs and 0 < items < pairs  # the rule settles most candidates, from a few items per board
     # the per-board composition (greedy_decide) next to the kernel's pooled one
     for kw in ({"hist": hist}, {"mask": m}):
         for x, y in zip(emu.greedy(state, tm, depth=2, pooled=False, **kw), oracle.batch_greedy(state, tm, depth=2, **kw)):
@@ -270,7 +271,8 @@ def test_greedy_policy_step_selfplay():
 
 
 def test_greedy_root_rule(boards):
-    """tests/emu/greedy_root_rule.h (not in the product yet): the summaries of our placements from hand,
+    """The root rule in its LOOP form (tests/emu/greedy_root_rule.h; the kernel's table form is checked on every settled
+    candidate inside emu.greedy's pooled flow, test_greedy_vs_oracle_selfplay): the summaries of our placements from hand,
     derived from the opponent's winning moves on the ROOT alone, equal the exact depth-2 evaluation on every candidate --
     selfplay positions, the dense random boards of the golden set (both movers), restricted masks."""
     state, tm, dn, rng = selfplay_states(8000, 30, seed=11)
