@@ -822,13 +822,9 @@ struct GreedyResult {
 // A lift never adds a top piece of the mover, so no line can then be complete for the mover before the
 // drop, and the "nothing missing" term is dropped.
 //
-// WINS_ONLY (with QUIET): the caller also guarantees that no lift can complete a line for the other side
-// (see reply_is_plain); then `lose` is 0, every completed line is the mover's, and the order of the
-// lines does not matter.
-template <bool QUIET = false, bool WINS_ONLY = false>
+template <bool QUIET = false>
 __device__ __forceinline__ void outcomes54(const Planes &p, int mover, uint64_t &win, uint64_t &lose)
 {
-    static_assert(QUIET || !WINS_ONLY, "WINS_ONLY needs QUIET");
     uint32_t mine = mover ? (p.nz & p.neg) : (p.nz & ~p.neg);
     uint32_t othr = mover ? (p.nz & ~p.neg) : (p.nz & p.neg);
     uint32_t m0 = mine & 0x1FFu, m1 = (mine >> 9) & 0x1FFu, m2 = (mine >> 18) & 0x1FFu;
@@ -858,23 +854,6 @@ __device__ __forceinline__ void outcomes54(const Planes &p, int mover, uint64_t 
         }
         uint32_t nTm = ~(TmR & ~lost), nTo = ~(ToR | gain);  // complements of the tops after the lift
         uint32_t W = 0, Z = 0, open = F3;
-        if (WINS_ONLY) {
-            // Every completed line is the mover's and no line is complete before the drop, so the winning
-            // destinations are the "threat squares" of the mover's tops T after the lift: squares whose two partners
-            // on some line are both in T.  Per direction the partners are shifted onto the square (rows: neighbours
-            // at distance 1, columns 3, diagonal 4, anti-diagonal 2); the masks pick the squares for which that pair of
-            // shifts IS the line and cut off what a shift drags in from the neighbouring 10-bit field.
-            constexpr uint32_t M0 = 0x049u * LOW3, M1 = 0x092u * LOW3, M2 = 0x124u * LOW3;  // column 0 / 1 / 2 of the board
-            constexpr uint32_t R0 = 0x007u * LOW3, R1 = 0x038u * LOW3, R2 = 0x1C0u * LOW3;  // row 0 / 1 / 2
-            constexpr uint32_t B0 = 0x001u * LOW3, B2 = 0x004u * LOW3, B4 = 0x010u * LOW3, B6 = 0x040u * LOW3,
-                               B8 = 0x100u * LOW3;
-            const uint32_t T = ~nTm & F3;
-            W = ((T >> 1) & (T >> 2) & M0) | ((T << 1) & (T >> 1) & M1) | ((T << 1) & (T << 2) & M2)     // (0,1,2) (3,4,5) (6,7,8)
-              | ((T >> 3) & (T >> 6) & R0) | ((T << 3) & (T >> 3) & R1) | ((T << 3) & (T << 6) & R2)     // (0,3,6) (1,4,7) (2,5,8)
-              | ((T >> 4) & (T >> 8) & B0) | ((T << 4) & (T >> 4) & B4) | ((T << 4) & (T << 8) & B8)     // (0,4,8)
-              | ((T >> 2) & (T >> 4) & B2) | ((T << 2) & (T >> 2) & B4) | ((T << 2) & (T << 4) & B6);    // (2,4,6)
-            W &= nTm;  // (a square the mover already tops completes nothing by being dropped on)
-        } else {
 #pragma unroll
         for (int l = 7; l >= 0; --l) {
             const uint32_t Lr = L[l] | (L[l] << 10) | (L[l] << 20);
@@ -894,7 +873,6 @@ __device__ __forceinline__ void outcomes54(const Planes &p, int mover, uint64_t 
             uint32_t xv = keep & open;
             Z |= xv;
             open &= ~xv;
-        }
         }
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
@@ -968,61 +946,6 @@ __device__ __forceinline__ GreedyHead greedy_head(const Planes &p, int me, uint6
     return h;
 }
 
-// Placements from hand on the same square, one size above the other.  If placing a piece of ours from hand on q
-// leaves the opponent no winning reply, placing a LARGER piece from hand on q leaves none either: the two positions
-// differ only in the level of our piece on q, the opponent's replies elsewhere find the same tops (ours on q in both),
-// and of the replies onto q the larger piece admits a subset.  Which piece of a size stands on q is invisible to the
-// opponent's terms (see dup), and reply_is_plain() reads tops and what lies under the OPPONENT's pieces, so it is the
-// same for both -- hence: the smaller placement evaluated cheaply with summary 0 => the larger one has summary 0, and
-// is not evaluated at all (a summary of 0 leaves no trace in the candidate sets).  ~40 % of the pairs on the
-// masked-random mix.  Placements whose stand-in has a winning reply, or went to the exact evaluation, get a second round.
-struct GreedyDom {
-    uint64_t first;    // evaluated in the first round: h.todo & ~h.dup minus the held ones
-    uint32_t shift[3]; // 9 * (piece that places size k from hand), 63 = no such piece
-    uint32_t dst[3];   // its destinations among the candidates (9 bits)
-};
-
-__device__ __forceinline__ GreedyDom greedy_dominance(const GreedyHead &h, const Planes &p, int me)
-{
-    const uint64_t w0 = h.todo & ~h.dup;
-    const uint32_t mine = me ? (p.nz & p.neg) : (p.nz & ~p.neg);
-    GreedyDom d;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const uint32_t lvl = (mine >> (9 * k)) & 0x1FFu, oddp = (p.odd >> (9 * k)) & 0x1FFu;
-        const bool even_in_hand = (lvl & oddp) == 0, odd_in_hand = (lvl & ~oddp) == 0;  // piece 2k / 2k + 1 (numbers 2k+1 / 2k+2)
-        d.shift[k] = even_in_hand ? 18u * k : odd_in_hand ? 18u * k + 9u : 63u;
-        d.dst[k] = d.shift[k] < 63u ? (uint32_t)(w0 >> d.shift[k]) & 0x1FFu : 0u;
-    }
-    const uint32_t held1 = d.dst[1] & d.dst[0], held2 = d.dst[2] & (d.dst[0] | d.dst[1]);
-    d.first = w0 & ~(((uint64_t)held1 << (d.shift[1] & 63u)) | ((uint64_t)held2 << (d.shift[2] & 63u)));
-    return d;
-}
-
-// the held placements that need an evaluation after all; bad: candidates of the first round with a winning reply
-// (summary bit 0) or sent to the exact evaluation
-__device__ __forceinline__ uint64_t greedy_second_round(const GreedyDom &d, uint64_t bad)
-{
-    const uint32_t bad0 = (uint32_t)(bad >> (d.shift[0] & 63u)) & d.dst[0], bad1 = (uint32_t)(bad >> (d.shift[1] & 63u)) & d.dst[1];
-    const uint32_t need1 = d.dst[1] & bad0;                                    // (stand-in: the small placement)
-    const uint32_t need2 = d.dst[2] & (bad0 | (~d.dst[0] & bad1));             // (small if there is one, else medium)
-    return ((uint64_t)need1 << (d.shift[1] & 63u)) | ((uint64_t)need2 << (d.shift[2] & 63u));
-}
-
-// A root position on which the OPPONENT, were it to move, has no winning move: then no placement of ours from hand
-// gives it one.  (A reply that wins after our placement on q is legal on the root too -- we only covered q -- and leaves
-// the same tops except that q is ours instead of what it was, or, if it gobbles our new piece, exactly the same tops:
-// it wins on the root as well.)  Such a placement has summary 0 unless a lift by the opponent could hand US a line
-// (reply_is_plain false), which with "have" = our tops and our pieces directly under the opponent's is the case iff
-// q completes a line inside have: the threat squares of have, or every q if have holds a line already.  So on a quiet
-// root the placements from hand on non-risky squares are not evaluated at all, and those on risky squares go straight
-// to the exact evaluation.  Half of the boards of the masked-random mix are quiet; a third of the first-round pairs go.
-struct GreedyQuiet {
-    bool quiet;          // the opponent has no winning move on the root
-    uint32_t risky;      // 9 bits: squares where a placement of ours is not "plain" (0x1FF if have already holds a line)
-    uint64_t from_hand;  // all placements of our pieces still in hand (54-bit set)
-};
-
 // all placements of `me`'s pieces that are still in hand (54-bit set)
 __device__ __forceinline__ uint64_t greedy_from_hand(const Planes &p, int me)
 {
@@ -1037,23 +960,19 @@ __device__ __forceinline__ uint64_t greedy_from_hand(const Planes &p, int me)
     return from_hand;
 }
 
-__device__ __forceinline__ GreedyQuiet greedy_quiet_root(const Planes &p, int me)
+// The squares on which a placement of ours could let a LIFT by the opponent hand us a line (then the opponent's replies
+// are not just "the root's winning moves, minus the defused ones", see below): with "have" = our tops and our pieces
+// directly under the opponent's, the squares that complete a line inside have -- or every square, if have holds a line already.
+__device__ __forceinline__ uint32_t greedy_risky_squares(const Planes &p, int me)
 {
-    GreedyQuiet g;
-    uint64_t ow, ol;
-    outcomes54(p, 1 - me, ow, ol);  // (the general form: the root itself need not be free of lines)
-    g.quiet = (ow & legal54(p, 1 - me)) == 0;
     const uint32_t mine = me ? (p.nz & p.neg) : (p.nz & ~p.neg);
     const uint32_t othr = me ? (p.nz & ~p.neg) : (p.nz & p.neg);
-    g.from_hand = greedy_from_hand(p, me);
-    // have: as in reply_is_plain(d1, opponent) -- our tops, and ours directly below a piece of the opponent's
     const uint32_t t0 = mine & 0x1FFu, t1 = (mine >> 9) & 0x1FFu, t2 = (mine >> 18) & 0x1FFu;
-    const uint32_t m1 = (othr >> 9) & 0x1FFu, m2 = (othr >> 18) & 0x1FFu, m0 = othr & 0x1FFu;
+    const uint32_t m1 = (othr >> 9) & 0x1FFu, m2 = (othr >> 18) & 0x1FFu;
     const uint32_t o1 = m1 | t1, o2 = m2 | t2;
-    const uint32_t To = t2 | (~o2 & (t1 | (~o1 & t0)));
-    const uint32_t X = (m1 & t0) | (m2 & (t1 | (~o1 & t0)));
+    const uint32_t To = t2 | (~o2 & (t1 | (~o1 & t0)));       // our tops
+    const uint32_t X = (m1 & t0) | (m2 & (t1 | (~o1 & t0)));  // ours directly below a piece of the opponent's
     const uint32_t T = (To | X) & 0x1FFu;
-    (void)m0;
     constexpr uint32_t L[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x111u, 0x054u};
     uint32_t risky = 0;
     bool full = false;
@@ -1063,8 +982,7 @@ __device__ __forceinline__ GreedyQuiet greedy_quiet_root(const Planes &p, int me
         full = full || miss == 0;
         if ((miss & (miss - 1)) == 0) risky |= miss;  // exactly one square missing: that square completes the line
     }
-    g.risky = full ? 0x1FFu : risky;
-    return g;
+    return full ? 0x1FFu : risky;
 }
 
 // ---- placements from hand, settled from the ROOT position alone (round 3) ------------------------------------------------
@@ -1075,13 +993,12 @@ __device__ __forceinline__ GreedyQuiet greedy_quiet_root(const Planes &p, int me
 //   q is where pj stands (we gobbled it: it cannot move), or
 //   q = q2 and our piece is at least as large as pj (the reply is no longer legal), or
 //   q != q2 lies on EVERY line the opponent holds after a2 (each of them now has our piece on it),
-// provided no lift by the opponent can hand US a line (reply_is_plain), which with "have" = our tops and our pieces
-// directly under the opponent's is the case iff q does not complete a line inside have ("risky" squares).  So for the
+// provided no lift by the opponent can hand US a line, which with "have" = our tops and our pieces directly under the
+// opponent's is the case iff q does not complete a line inside have (greedy_risky_squares).  So for the
 // placements from hand on non-risky squares the whole summary -- first / second winning reply, the first one we could
 // play ourselves -- follows from R and a few set operations per member of R, with no depth-2 evaluation at all: two
 // thirds of the (board, candidate) pairs of the masked-random mix.  Placements on risky squares are evaluated.  (R empty
-// -- half of the boards -- means: none of these placements has a winning reply; that special case was round 2's
-// "quiet root".)  Pinned against the exact evaluation on every candidate it settles: tests/emu (emu_greedy_root_rule).
+// -- half of the boards -- means: none of these placements has a winning reply.)  Pinned against the exact evaluation on every candidate it settles: tests/emu (emu_greedy_root_rule).
 struct GreedyRoot {
     uint64_t replies;    // R: the opponent's winning moves on the root
     uint32_t risky;      // 9 bits: squares where a placement of ours is not "plain" (0x1FF if have already holds a line)
@@ -1096,10 +1013,9 @@ __device__ __forceinline__ uint64_t spread9(uint32_t squares)  // a 9-bit set of
 
 __device__ __forceinline__ GreedyRoot greedy_root(const Planes &p, int me)
 {
-    const GreedyQuiet q = greedy_quiet_root(p, me);  // (the same two results: its test `quiet` is replies == 0)
     uint64_t ow, ol;
-    outcomes54(p, 1 - me, ow, ol);
-    return GreedyRoot{ow & legal54(p, 1 - me), q.risky};
+    outcomes54(p, 1 - me, ow, ol);  // (the general form: the root itself need not be free of lines)
+    return GreedyRoot{ow & legal54(p, 1 - me), greedy_risky_squares(p, me)};
 }
 
 // the placements from hand (of any of our pieces, on any square: mask with the candidates) that do NOT defuse the
@@ -1193,30 +1109,6 @@ __device__ __forceinline__ GreedyRootPlan greedy_root_plan(const GreedyHead &h, 
     return GreedyRootPlan{w0 & ~resolved, resolved, resolved ? g.replies : 0ull};
 }
 
-// The candidates' way through the kernel: `first` are evaluated cheaply in the pooled round, `exact` go straight to the
-// exact round, and greedy_second_round() names those that join it depending on the first round's results.
-struct GreedyPlan {
-    GreedyDom dom;
-    uint64_t exact;
-};
-
-__device__ __forceinline__ GreedyPlan greedy_plan(const GreedyHead &h, const Planes &p, int me, const GreedyQuiet &g)
-{
-    GreedyPlan plan;
-    if (g.quiet) {
-        const uint64_t w0 = h.todo & ~h.dup;
-        uint64_t risky54 = g.risky;
-        risky54 |= risky54 << 9;
-        risky54 |= risky54 << 18 | risky54 << 36;
-        plan.dom = GreedyDom{w0 & ~g.from_hand, {63u, 63u, 63u}, {0u, 0u, 0u}};
-        plan.exact = w0 & g.from_hand & risky54;
-    } else {
-        plan.dom = greedy_dominance(h, p, me);
-        plan.exact = 0;
-    }
-    return plan;
-}
-
 // What the depth-2 loop needs to know about candidate `a` (:107-126), packed in 16 bits:
 //   bit 0      the opponent has a winning reply            (ow != 0)
 //   bits 1-6   the first winning reply f
@@ -1224,46 +1116,13 @@ __device__ __forceinline__ GreedyPlan greedy_plan(const GreedyHead &h, const Pla
 //   bit 8      some winning reply is a legal move of ours on the root position (:141)
 //   bits 9-14  the first such reply
 //   bit 15     every reply wins the game for us            (all(), :146-149; implies bit 0 clear)
-// On a position where nobody holds a line: can a lift by `mover` hand the other side one?  Only by
-// exposing a piece of theirs (a square where the mover's piece lies directly on one) that is the third
-// square of a line they otherwise hold.  False here = outcomes54 may run WINS_ONLY.  (Conservative:
-// pieces the mover cannot lift count too.)
-__device__ __forceinline__ bool reply_is_plain(const Planes &p, int mover)
-{
-    uint32_t mine = mover ? (p.nz & p.neg) : (p.nz & ~p.neg);
-    uint32_t othr = mover ? (p.nz & ~p.neg) : (p.nz & p.neg);
-    uint32_t m1 = (mine >> 9) & 0x1FFu, m2 = (mine >> 18) & 0x1FFu;
-    uint32_t t0 = othr & 0x1FFu, t1 = (othr >> 9) & 0x1FFu, t2 = (othr >> 18) & 0x1FFu;
-    uint32_t o1 = m1 | t1, o2 = m2 | t2;
-    uint32_t To = t2 | (~o2 & (t1 | (~o1 & t0)));          // the other side's tops
-    uint32_t X = (m1 & t0) | (m2 & (t1 | (~o1 & t0)));     // theirs directly below a piece of the mover
-    uint32_t have = To | X;
-    uint32_t nh = ~(have | (have << 10) | (have << 20));
-    constexpr uint32_t LOW3 = 0x00100401u, G3 = LOW3 << 9, F3 = LOW3 * 0x1FFu;
-    constexpr uint32_t LA = 0x007u | (0x038u << 10) | (0x1C0u << 20), LB = 0x049u | (0x092u << 10) | (0x124u << 20);
-    constexpr uint32_t LC = 0x111u | (0x054u << 10) | (0x1FFu << 20);  // third field: a "line" nobody can hold
-    // guard bit of a field stays clear iff none of the line's squares is missing from `have`
-    uint32_t full = (G3 & ~((LA & nh) + F3)) | (G3 & ~((LB & nh) + F3)) | (G3 & ~(((LC & nh) | (1u << 20)) + F3));
-    return full == 0;
-}
-
-// EXACT = false: the cheap evaluation when reply_is_plain() allows it, else kGreedyDefer (the caller
-// evaluates the pair again with EXACT = true).
-constexpr uint32_t kGreedyDefer = 0xFFFFFFFFu;
-
-template <bool EXACT = true>
 __device__ __forceinline__ uint32_t greedy_reply(const Planes &p, int me, uint64_t legal_me, uint32_t a)
 {
     const int opp = 1 - me;
     Planes d1 = moved(p, me, a);         // :107-109
-    if (!EXACT && !reply_is_plain(d1, opp)) return kGreedyDefer;
     uint64_t legal2 = legal54(d1, opp);  // :112-116
     uint64_t ow, mw;                     // the opponent wins / we win after reply a2, :120-126
-    // a is a depth-1 result with value 0: nobody holds a line on d1
-    if (EXACT)
-        outcomes54<true, false>(d1, opp, ow, mw);
-    else
-        outcomes54<true, true>(d1, opp, ow, mw);
+    outcomes54<true>(d1, opp, ow, mw);   // (a is a depth-1 result with value 0: nobody holds a line on d1)
     ow &= legal2;
     mw &= legal2;
     uint64_t block = ow & legal_me;

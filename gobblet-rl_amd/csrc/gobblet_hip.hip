@@ -46,6 +46,16 @@ inline Geometry geometry(int64_t n, int waves = 1)
     return g;
 }
 
+// blocks of nt tiles per workgroup (the greedy kernels): ntiles counts TILES, the grid blocks
+inline Geometry block_geometry(int64_t n, int nt)
+{
+    Geometry g;
+    g.ntiles = (n + kTile - 1) / kTile;
+    const int64_t blocks = (g.ntiles + nt - 1) / nt;
+    g.grid = (uint32_t)(((blocks + 7) / 8) * 8);
+    return g;
+}
+
 // Wavefronts per workgroup of the step kernels.  The wavefronts of a workgroup are independent (a tile and an LDS
 // image each, no barrier); a workgroup is only the unit of dispatch.
 #ifndef GBL_WG_WAVES
@@ -874,157 +884,165 @@ __device__ __forceinline__ void pool_fence()
         wave_lds_fence();
 }
 
-// The LDS a tile's decision works in (one per workgroup).
-template <int W>
+// ---- the greedy decision of a BLOCK of NT tiles (64 NT boards) by a workgroup of W wavefronts -----------------------------
+// Wavefronts 0 .. NT-1 each OWN a tile (lane = board: loads, depth-1 walk, replay, outputs); wavefronts NT .. 2 NT - 1 look at
+// the same tiles from the opponent's side while the owners walk depth 1; ALL W wavefronts lay out and evaluate the block's
+// depth-2 work, whoever owns it.  Shapes: <1, 8> a lone tile spread over eight wavefronts (small batches: the shortest
+// serial chain), <1, 4> the same over four (large batches: most wavefronts per CU), <4, 8>: as many owners as helpers --
+// every wavefront of the workgroup has work in every phase (with one owner among four wavefronts, three quarters of a CU's
+// wavefronts idle through the owner phases: the tiles of a CU run in step) -- for batches of one generation of tiles,
+// <1, 1>: depth 1 only, no shared phase, no barrier.
+template <int NT, int W>
 struct GreedyLds {
-    // (board << 8) | candidate of every depth-2 evaluation, in kSegs segments: segment g lists candidates
-    // [g * kSeg, (g + 1) * kSeg) of all 64 boards and is built by wavefront g mod W
-    static constexpr int kSegs = W >= 2 ? W : 2, kSeg = (kActions + kSegs - 1) / kSegs, kSegCap = kTile * kSeg;
-    static_assert(kSeg <= 32, "a segment's candidates fit one 32-bit word");
-    alignas(16) uint16_t pair[kSegs * kSegCap];
-    unsigned long long undef[kTile][kRootItems];  // per board and member j of the root's replies: greedy_undefused & resolved
-    uint16_t item[kTile * kRootItems];   // (board << 8) | j of every member of a root's replies that is dealt out
-    uint32_t board[kTile][4];            // planes nz, neg, odd; bit 0: the agent to move, bit 1: the board wants depth 2
-    uint64_t legal[kTile];               // its legal moves on the root position
-    unsigned long long work[kTile];      // the candidates of a board that are evaluated
-    unsigned long long replies[kTile];   // the opponent's winning moves on the root (greedy_root); after the plan: those dealt out
-    uint32_t risky[kTile];               // 9 bits: squares where a placement from hand has to be evaluated (greedy_root)
-    int count[kSegs];
-    int items;
-    uint16_t reply[kTile][kActions];     // greedy_reply() of (board, candidate), where bit 0 is set
-    unsigned long long threat[kTile];    // candidates whose summary has bit 0 / bit 15 / bit 7 / bit 8,
-    unsigned long long allwin[kTile];    // and those whose first winning reply is a legal move of ours
-    unsigned long long second[kTile];    // (the sets greedy_replay_closed works on)
-    unsigned long long block[kTile];
-    unsigned long long flegal[kTile];
+    static_assert(W == 1 || W >= 2 * NT, "a helper wavefront per owner");
+    static constexpr int kBoards = kTile * NT;
+    static_assert(kBoards <= 256, "(board << 8) | candidate fits 16 bits");
+    alignas(16) uint16_t pair[kBoards * kActions];    // (board << 8) | candidate of every depth-2 evaluation of the block
+    unsigned long long undef[kBoards][kRootItems];    // per board and member j of the root's replies: greedy_undefused
+    uint16_t item[kBoards * kRootItems];              // (board << 8) | j of every member of a root's replies that is dealt out
+    uint32_t board[kBoards][4];            // planes nz, neg, odd; bit 0: the agent to move, bit 1: the board wants depth 2
+    uint64_t legal[kBoards];               // its legal moves on the root position
+    unsigned long long work[kBoards];      // the candidates of a board that are evaluated
+    unsigned long long replies[kBoards];   // the opponent's winning moves on the root (greedy_root); after the plan: those dealt out
+    uint32_t risky[kBoards];               // 9 bits: squares where a placement from hand has to be evaluated (greedy_root)
+    int npairs, nitems;
+    uint16_t reply[kBoards][kActions];     // greedy_reply() of (board, candidate), where bit 0 is set
+    unsigned long long threat[kBoards];    // candidates whose summary has bit 0 / bit 15 / bit 7 / bit 8,
+    unsigned long long allwin[kBoards];    // and those whose first winning reply is a legal move of ours
+    unsigned long long second[kBoards];    // (the sets greedy_replay_closed works on)
+    unsigned long long block[kBoards];
+    unsigned long long flegal[kBoards];
     // The pair list and the table are dead between two decisions (written after the first barriers of greedy_tile, read
-    // before it returns): a kernel that decides in a loop stages its output rows through them in between.
-    static constexpr int kScratchBytes = (int)(sizeof(uint16_t) * kSegs * kSegCap + sizeof(unsigned long long) * kTile * kRootItems);
-    static_assert(sizeof(uint16_t) * kSegs * kSegCap % 8 == 0, "the table follows the pair list without padding");
-    __device__ __forceinline__ uint32_t *scratch() { return reinterpret_cast<uint32_t *>(pair); }
+    // before it returns): a kernel that decides in a loop stages its owners' output rows through them in between.
+    static constexpr int kScratchBytes = (int)(sizeof(uint16_t) * kBoards * kActions + sizeof(unsigned long long) * kBoards * kRootItems);
+    static_assert(sizeof(uint16_t) * kBoards * kActions % 16 == 0, "the table follows the pair list without padding");
+    __device__ __forceinline__ uint32_t *scratch(int owner_wave)
+    {
+        return reinterpret_cast<uint32_t *>(pair) + owner_wave * (kScratchBytes / 4 / NT / 4 * 4);
+    }
 };
 
-// One decision per board of a tile, by ALL 64 W threads of the workgroup (slot = 0 .. 64 W - 1; every thread calls, the
-// barriers are inside).  The owners (slot < 64, lane = board) pass their board, the agent to move, the legal mask
-// handed to the policy (0: nothing to decide on this board -- an invalid lane, or in gbl_collect_policy a board whose
-// mover plays at random), the board's depth (1, 2; 3 decides like 2) and the agent's last three actions; the other
-// threads' arguments are ignored and they get an empty result.  deep: some board of SOME tile of the launch may want
-// depth 2 (workgroup-uniform: it decides whether the pooled round and its barriers exist at all).
+// One ballot per (candidate | rank) and group of 64 boards compacts the boards that have it into a list shared by the whole
+// block -- no per-lane loop, no divergence.  A wavefront counts its steps first, reserves its stretch of the list with ONE
+// atomic, then writes (the ballots are recomputed: two instructions each, against 2 x STEPS live scalar registers).
+template <int STEPS, typename Has>
+__device__ __forceinline__ void list_append(uint16_t *list, int *fill, uint32_t tag, int lane, Has has)
+{
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < STEPS; ++j) mine += (uint32_t)__popcll(__ballot(has(j)));
+    uint32_t base = 0;
+    if (lane == 0 && mine) base = (uint32_t)atomicAdd(fill, (int)mine);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+    for (int j = 0; j < STEPS; ++j) {
+        const bool h = has(j);
+        const unsigned long long m = __ballot(h);
+        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
+        if (h) list[at] = (uint16_t)(tag + (uint32_t)j);
+        base += (uint32_t)__popcll(m);
+    }
+}
+
+// One decision per board of the block, by ALL 64 W threads of the workgroup (every thread calls, the barriers are inside).
+// The owners (wave < NT, lane = board of their tile) pass their board, the agent to move, the legal mask handed to the
+// policy (0: nothing to decide on this board -- an invalid lane, or in gbl_collect_policy a board whose mover plays at
+// random), the board's depth (1, 2; 3 decides like 2) and the agent's last three actions; the other threads' arguments are
+// ignored and they get an empty result.  deep: some board of SOME block of the launch may want depth 2 (workgroup-uniform:
+// it decides whether the shared phases and their barriers exist at all; W == 1 has none).
 //
-// Depth 2 in five steps between barriers:  (A) the owners publish their boards;  (B) wavefront 0 walks depth 1
-// (greedy_head) while wavefront 1 finds the opponent's winning moves on the root and the risky squares (greedy_root);
-// (C) the owners split their candidates (greedy_root_plan): placements from hand on non-risky squares are settled from the
-// root's replies R, everything else is evaluated;  (D) all wavefronts lay out the work -- the (board, candidate) pairs
-// and the (board, member of R) items -- with one ballot per candidate / rank;  (E) all lanes take pairs (one moved +
-// legal54 + outcomes54 each: every reply's result at once) and items (greedy_undefused) whoever owns them, leaving
-// 16-bit summaries, candidate-set bits and table rows in LDS; then the owners replay the reference's depth-2 loop in closed
-// form over the sets (greedy_replay_closed).
+// Depth 2 in five steps between barriers:  (A) the owners publish their boards;  (B) they walk depth 1 (greedy_head) while
+// their helpers find the opponent's winning moves on the root and the risky squares (greedy_root);  (C) the owners split
+// their candidates (greedy_root_plan): placements from hand on non-risky squares are settled from the root's replies R,
+// everything else is evaluated;  (D) all wavefronts lay out the work -- the (board, candidate) pairs and the (board,
+// member of R) items;  (E) all lanes take pairs (one moved + legal54 + outcomes54 each: every reply's result at once) and
+// items (greedy_undefused) whoever owns them, leaving 16-bit summaries, candidate-set bits and table rows in LDS; then the
+// owners replay the reference's depth-2 loop in closed form over the sets (greedy_replay_closed).
 // Safe to call in a loop: what the owners read last (replay) and write first (heads) is their own wavefront's business,
 // and everybody else's reads of an iteration lie before its last barrier.
-template <int W>
-__device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<W> &S, int slot, const Planes &p, int me, uint64_t mask,
-                                                    int depth, bool deep, uint32_t prev3, TileStamps &ts)
+template <int NT, int W>
+__device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const Planes &p, int me, uint64_t mask, int depth,
+                                                    bool deep, uint32_t prev3, TileStamps &ts)
 {
-    constexpr int kSegs = GreedyLds<W>::kSegs, kSeg = GreedyLds<W>::kSeg, kSegCap = GreedyLds<W>::kSegCap;
-    const int lane = slot & (kTile - 1), wave = slot >> 6;
-    const bool owner = slot < kTile;
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const bool owner = wave < NT;
+    const int bi = (owner ? wave : wave - NT) * kTile + lane;  // the board this thread owns, or helps with (wave < 2 NT)
     GreedyHead h{0ull, 0ull, 0ull, 0ull, 0, -1};
     GreedyRootPlan plan{0ull, 0ull, 0ull};
     const bool two = owner && depth > 1 && mask != 0;  // this board takes part in the depth-2 round
+    if constexpr (W == 1) {
+        (void)S; (void)deep; (void)ts; (void)bi; (void)two;
+        h = greedy_head(p, me, mask, 1);  // (one wavefront: depth 1 only -- the hosts never launch it for more)
+        return greedy_finish(h, prev3);
+    } else {
     if (owner && deep) {
-        S.board[lane][0] = p.nz;
-        S.board[lane][1] = p.neg;
-        S.board[lane][2] = p.odd;
-        S.board[lane][3] = (uint32_t)me | (two ? 2u : 0u);
+        S.board[bi][0] = p.nz;
+        S.board[bi][1] = p.neg;
+        S.board[bi][2] = p.odd;
+        S.board[bi][3] = (uint32_t)me | (two ? 2u : 0u);
+        if (threadIdx.x == 0) {
+            S.npairs = 0;
+            S.nitems = 0;
+        }
     }
-    // (B) While the owners walk depth 1, the second wavefront looks at the root from the OPPONENT's side (greedy_root: as
-    // expensive as the depth-1 walk itself, and off the owners' serial path).
-    if (deep && W > 1) {
+    if (deep) {
         pool_fence<W>();
-        if (wave == 1 && (S.board[lane][3] & 2u)) {
-            const Planes q{S.board[lane][0], S.board[lane][1], S.board[lane][2]};
-            const GreedyRoot g = greedy_root(q, (int)(S.board[lane][3] & 1u));
-            S.replies[lane] = g.replies;
-            S.risky[lane] = g.risky;
+        // (B) the helpers look at the root from the OPPONENT's side (as expensive as the depth-1 walk itself)
+        if (wave >= NT && wave < 2 * NT && (S.board[bi][3] & 2u)) {
+            const Planes q{S.board[bi][0], S.board[bi][1], S.board[bi][2]};
+            const GreedyRoot g = greedy_root(q, (int)(S.board[bi][3] & 1u));
+            S.replies[bi] = g.replies;
+            S.risky[bi] = g.risky;
         }
     }
     if (owner) {
         h = greedy_head(p, me, mask, depth);  // empty mask: nothing to do
         if (deep) {
-            S.legal[lane] = h.legal_me;
-            S.threat[lane] = 0ull;
-            S.allwin[lane] = 0ull;
-            S.second[lane] = 0ull;
-            S.block[lane] = 0ull;
-            S.flegal[lane] = 0ull;
+            S.legal[bi] = h.legal_me;
+            S.threat[bi] = 0ull;
+            S.allwin[bi] = 0ull;
+            S.second[bi] = 0ull;
+            S.block[bi] = 0ull;
+            S.flegal[bi] = 0ull;
         }
     }
-    GreedyRoot root{0ull, 0u};
     if (deep) {
-        if (W > 1) pool_fence<W>();  // the second wavefront's findings are in
+        pool_fence<W>();  // the helpers' findings are in
         if (owner) {
             // (C) twin placements are not evaluated a second time; placements from hand on non-risky squares not at all
-            if (two) {
-                root = W > 1 ? GreedyRoot{S.replies[lane], S.risky[lane]} : greedy_root(p, me);
-                plan = greedy_root_plan(h, p, me, root);
-            }
-            S.work[lane] = plan.eval;
-            S.replies[lane] = plan.items;
+            if (two) plan = greedy_root_plan(h, p, me, GreedyRoot{S.replies[bi], S.risky[bi]});
+            S.work[bi] = plan.eval;
+            S.replies[bi] = plan.items;
         }
     }
     GBL_TILE_STAMP(ts, 0);
     if (deep) {
         pool_fence<W>();
-        // (D) The work lists, by all W wavefronts: lane = board.  One ballot per candidate (per rank in R) compacts the
-        // boards that have it -- no per-lane loop, no divergence; the order of a list is irrelevant, results land in
-        // per-board sets and table rows.
-        for (int sg = wave; sg < kSegs; sg += W) {
-            const uint32_t wk = (uint32_t)(S.work[lane] >> (sg * kSeg)) & (uint32_t)((1ull << kSeg) - 1ull);
-            const uint32_t tag = ((uint32_t)lane << 8) + (uint32_t)(sg * kSeg);
-            uint16_t *seg = S.pair + sg * kSegCap;
-            uint32_t cnt = 0;  // wave-uniform
-#pragma unroll
-            for (int j = 0; j < kSeg; ++j) {
-                const bool has = (wk >> j) & 1u;
-                const unsigned long long m = __ballot(has);
-                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, cnt));
-                if (has) seg[at] = (uint16_t)(tag + j);
-                cnt += (uint32_t)__popcll(m);
+        // (D) the work lists: wavefront w takes a stretch of the NT x 54 (tile, candidate) steps -- inside ONE tile -- and
+        // the last NT wavefronts a tile's NT x 6 (tile, rank) steps each
+        constexpr int kSteps = (NT * kActions + W - 1) / W;
+        static_assert(kActions % kSteps == 0 || NT == 1, "a wavefront's steps stay inside one tile");
+        {
+            const int first = wave * kSteps, g = first / kActions, c0 = first - g * kActions;
+            if (first < NT * kActions) {
+                const unsigned long long wk = S.work[g * kTile + lane] >> c0;
+                list_append<kSteps>(S.pair, &S.npairs, ((uint32_t)(g * kTile + lane) << 8) + (uint32_t)c0, lane,
+                                    [&](int j) { return c0 + j < kActions && ((wk >> j) & 1ull); });
             }
-            if (lane == 0) S.count[sg] = (int)cnt;
         }
-        if (wave == W - 1) {
-            const uint32_t nr = (uint32_t)__popcll(S.replies[lane]);
-            uint32_t cnt = 0;
-#pragma unroll
-            for (int j = 0; j < kRootItems; ++j) {
-                const bool has = (uint32_t)j < nr;
-                const unsigned long long m = __ballot(has);
-                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, cnt));
-                if (has) S.item[at] = (uint16_t)(((uint32_t)lane << 8) + (uint32_t)j);
-                cnt += (uint32_t)__popcll(m);
-            }
-            if (lane == 0) S.items = (int)cnt;
+        if (wave >= W - NT) {
+            const int g = W - 1 - wave;
+            const uint32_t nr = (uint32_t)__popcll(S.replies[g * kTile + lane]);
+            list_append<kRootItems>(S.item, &S.nitems, (uint32_t)(g * kTile + lane) << 8, lane,
+                                    [&](int j) { return (uint32_t)j < nr; });
         }
         pool_fence<W>();
-        int seg_end[kSegs];  // cumulative list lengths
-        int total = 0;
-#pragma unroll
-        for (int w = 0; w < kSegs; ++w) seg_end[w] = (total += S.count[w]);
-        auto pair_at = [&](int g) -> uint32_t {
-            int w = 0, start = 0;
-#pragma unroll
-            for (int k = 0; k + 1 < kSegs; ++k) {
-                w += g >= seg_end[k] ? 1 : 0;
-                start = g >= seg_end[k] ? seg_end[k] : start;
-            }
-            return S.pair[w * kSegCap + (g - start)];
-        };
         // (E) the pairs, from the first wavefront up ...
-        for (int g = slot; g < total; g += kTile * W) {
-            const uint32_t pair = pair_at(g), o = pair >> 8, a = pair & 0xFFu;
+        const int total = S.npairs;
+        for (int g = (int)threadIdx.x; g < total; g += kTile * W) {
+            const uint32_t pair = S.pair[g], o = pair >> 8, a = pair & 0xFFu;
             const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
-            const uint32_t sum = greedy_reply<true>(q, (int)(S.board[o][3] & 1u), S.legal[o], a);
+            const uint32_t sum = greedy_reply(q, (int)(S.board[o][3] & 1u), S.legal[o], a);
             if (sum & 1u) {
                 S.reply[o][a] = (uint16_t)sum;
                 atomicOr(&S.threat[o], 1ull << a);
@@ -1035,7 +1053,7 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<W> &S, int slot, c
             if (sum >> 15) atomicOr(&S.allwin[o], 1ull << a);
         }
         // ... and the items, from the last wavefront down (it has the fewest pairs)
-        const int nitems = S.items;
+        const int nitems = S.nitems;
         for (int g = (W - 1 - wave) * kTile + lane; g < nitems; g += kTile * W) {
             const uint32_t it = S.item[g], o = it >> 8, j = it & 0xFFu;
             const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
@@ -1048,11 +1066,11 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<W> &S, int slot, c
     GBL_TILE_STAMP(ts, 2);
     if (!owner) return GreedyResult{-1, 0ull, false};
     if (two) {  // :103-157 on the owner's lane, in closed form over the candidate sets
-        ReplySets r{S.threat[lane], S.allwin[lane], S.second[lane], S.block[lane], S.flegal[lane]};
+        ReplySets r{S.threat[bi], S.allwin[bi], S.second[bi], S.block[bi], S.flegal[bi]};
         uint64_t undef[kRootItems] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
         if (plan.items) {  // the placements settled from the root: the table's rows merged in the reference's reply order
 #pragma unroll
-            for (int j = 0; j < kRootItems; ++j) undef[j] = S.undef[lane][j] & plan.resolved;
+            for (int j = 0; j < kRootItems; ++j) undef[j] = S.undef[bi][j] & plan.resolved;
             const GreedyHandSets hs = greedy_hand_merge(plan.items, h.legal_me, undef);
             r.threat |= hs.threat;
             r.second |= hs.second;
@@ -1062,10 +1080,22 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<W> &S, int slot, c
         greedy_replay_closed(h, r, [&](int a) {
             const uint32_t twin = ((h.dup >> a) & 1ull) ? (uint32_t)a - 9u : (uint32_t)a;  // twin placements share a summary
             return ((plan.resolved >> twin) & 1ull) ? greedy_hand_lookup(plan.items, h.legal_me, undef, twin)
-                                                    : (uint32_t)S.reply[lane][twin];
+                                                    : (uint32_t)S.reply[bi][twin];
         });
     }
     return greedy_finish(h, prev3);
+    }
+}
+
+// greedy_tile as a real function call, for the ply loop of gbl_collect_policy: inlined there, the decision's literal
+// constants are hoisted out of the loop and stay live across the whole iteration (~160 VGPRs, or spills under the kernel's
+// register budget); behind a call they live and die inside the callee.
+template <int NT, int W>
+__device__ __attribute__((noinline)) GreedyResult greedy_tile_call(GreedyLds<NT, W> &S, Planes p, int me, uint64_t mask, int depth,
+                                                                   bool deep, uint32_t prev3)
+{
+    TileStamps ts{};
+    return greedy_tile<NT, W>(S, p, me, mask, depth, deep, prev3, ts);
 }
 
 // the agent's last three actions (one per byte, 0xFF = none) from the 6 history bytes of a board, read as three 16-bit words
@@ -1074,7 +1104,23 @@ __device__ __forceinline__ uint32_t hist_prev3(uint32_t h0, uint32_t h1, uint32_
     return me ? ((h1 >> 8) | (h2 << 8)) & 0x00FFFFFFu : (h0 | (h1 << 16)) & 0x00FFFFFFu;
 }
 
-template <int W>
+// The tile of an owner wavefront of a block: tile = block * NT + wave; tiles past the end have no rows (their wavefront still
+// takes part in the block's barriers).  False: the whole block lies past the end.
+template <int NT>
+__device__ __forceinline__ bool block_lane_setup(Lane &L, int64_t n, int64_t ntiles)
+{
+    const int wave = (int)(threadIdx.x >> 6);
+    if ((int64_t)blockIdx.x * NT >= ntiles) return false;
+    L.tile = (int64_t)blockIdx.x * NT + (wave < NT ? wave : 0);
+    L.lane = (int)(threadIdx.x & 63u);
+    const int64_t left = n - L.tile * kTile;
+    L.rows = (wave >= NT || left <= 0) ? 0 : left < kTile ? (int)left : kTile;
+    L.valid = L.lane < L.rows;
+    L.b = L.tile * kTile + L.lane;
+    return true;
+}
+
+template <int NT, int W>
 __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ state,
                                                    const int8_t *__restrict__ to_move,
                                                    const int8_t *__restrict__ mask_in,
@@ -1089,25 +1135,21 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
     // hist_rw != NULL: gbl_greedy_act -- the history is read from and appended to hist_rw, and final_out gets
     // the action the policy returns (the fallback draw included); hist is then unused.
     if (hist_rw) hist = hist_rw;
-    __shared__ uint32_t s_state[image_words<kCells>()];
-    __shared__ uint32_t s_mask[image_words<kActions>()];
-    __shared__ GreedyLds<W> S;
+    __shared__ uint32_t s_states[NT][image_words<kCells>()];
+    __shared__ uint32_t s_masks[NT][image_words<kActions>()];
+    __shared__ GreedyLds<NT, W> S;
     GBL_STAMP(0);
     GBL_STAMP_REAL(0);
     Lane L;
-    if (!lane_setup(L, n, ntiles)) return;  // the same for every thread of the workgroup
-    const int slot = L.lane;                // 0 .. 64 W - 1
-    const bool owner = slot < kTile;
-    if (W > 1) {
-        L.lane = slot & (kTile - 1);
-        L.valid = L.lane < L.rows;
-        L.b = L.tile * kTile + L.lane;
-    }
+    if (!block_lane_setup<NT>(L, n, ntiles)) return;  // the same for every thread of the workgroup
+    const int wave = (int)(threadIdx.x >> 6);
+    const bool owner = wave < NT;
+    uint32_t *const s_state = s_states[owner ? wave : 0], *const s_mask = s_masks[owner ? wave : 0];
     Planes p{0u, 0u, 0u};
     uint32_t prev3 = 0x00FFFFFFu, h0 = 0xFFFFu, h1 = 0xFFFFu, h2 = 0xFFFFu;
     int me = 0;
     uint64_t mask = 0;
-    if (owner) {
+    if (owner && L.rows > 0) {
         // per-board scalars first, branch-free from a clamped index: in flight together with the tile (see k_step);
         // the history of BOTH agents (6 bytes, 2-byte aligned), the mover picks its three below
         const int64_t bs = L.valid ? L.b : n - 1;
@@ -1135,11 +1177,11 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
             prev3 = hist_prev3(h0, h1, h2, me);
     }
     TileStamps ts{};
-    const GreedyResult g = greedy_tile<W>(S, slot, p, me, mask, depth, depth > 1, prev3, ts);
+    const GreedyResult g = greedy_tile<NT, W>(S, p, me, mask, depth, depth > 1, prev3, ts);
     GBL_STAMP_VAL(1, ts.t[0]);
     GBL_STAMP_VAL(2, ts.t[1]);
     GBL_STAMP_VAL(3, ts.t[2]);
-    if (!owner) return;
+    if (!owner || L.rows == 0) return;
     if (cand_out) {
         uint32_t d[14];
         mask_row(g.cands, d);
@@ -1171,15 +1213,15 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
 // tutorial_greedy.py:16-54: one policy object acting for both agents, the first two plies of a game drawn at random;
 // greedy_policy_tianshou.py:63-84: greedy against a learner); here the decision (greedy_tile, all W wavefronts of the
 // workgroup), the fallback draw (:211-217), the history append (:219), the move, winner, auto-reset and the next
-// observation / mask all happen inside one launch, the tile's boards living in LDS and registers between the plies.
-// Wavefront 0 owns the boards and does everything but the pooled depth-2 evaluations.
+// observation / mask all happen inside one launch, the block's boards living in LDS and registers between the plies.
+// The owner wavefronts do everything but the shared depth-2 work.
 // (Register budget: four wavefronts per SIMD = 128 VGPRs.  Left alone the compiler takes ~160 -- the ply loop keeps the
 // decision's literal constants live across iterations -- which costs a wavefront of occupancy for nothing.)
 #ifndef GBL_CP_WAVES_PER_EU
 #define GBL_CP_WAVES_PER_EU 4
 #endif
-template <int W>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 ? GBL_CP_WAVES_PER_EU : 1, 8))) void k_collect_policy(
+template <int NT, int W>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 && NT == 1 ? GBL_CP_WAVES_PER_EU : 1, 8))) void k_collect_policy(
     int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n, int64_t ntiles, uint64_t seed, uint64_t env_base,
     const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies, int8_t *__restrict__ done, int64_t ply_stride,
     int64_t tile_stride, int32_t *__restrict__ actions_t, int8_t *__restrict__ winner_t, int8_t *__restrict__ reward_t,
@@ -1187,20 +1229,15 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 ? 
     int32_t *__restrict__ chosen_t, int8_t *__restrict__ how_t, int8_t *__restrict__ cand_t, int8_t *__restrict__ hist,
     int policy0, int policy1, int opening_plies, int illegal_mode, int64_t *__restrict__ counters, int32_t *__restrict__ turn)
 {
-    __shared__ uint32_t s_state[image_words<kCells>()];
-    __shared__ GreedyLds<W> S;
-    static_assert(GreedyLds<W>::kScratchBytes >= 4 * image_words<kObs>(), "the output image fits the idle pair lists");
-    uint32_t *const s_out = S.scratch();
+    __shared__ uint32_t s_states[NT][image_words<kCells>()];
+    __shared__ GreedyLds<NT, W> S;
+    static_assert(GreedyLds<NT, W>::kScratchBytes / NT / 16 * 16 >= 4 * image_words<kObs>(), "an owner's output image fits its share of the idle lists");
     if (ply_dev) ply0 += *ply_dev;
     Lane L;
-    if (!lane_setup<1, false>(L, n, ntiles)) return;  // the same for every thread of the workgroup
-    const int slot = L.lane;
-    const bool owner = slot < kTile;
-    if (W > 1) {
-        L.lane = slot & (kTile - 1);
-        L.valid = L.lane < L.rows;
-        L.b = L.tile * kTile + L.lane;
-    }
+    if (!block_lane_setup<NT>(L, n, ntiles)) return;  // the same for every thread of the workgroup
+    const int wave = (int)(threadIdx.x >> 6);
+    const bool owner = wave < NT, active = owner && L.rows > 0;
+    uint32_t *const s_state = s_states[owner ? wave : 0], *const s_out = S.scratch(owner ? wave : 0);
     const bool deep = policy0 > 1 || policy1 > 1;
     Planes p{0u, 0u, 0u};
     int mover = 0, dn = 0, tabs = 0;
@@ -1209,7 +1246,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 ? 
     const ImageRow row{reinterpret_cast<uint8_t *>(s_state) + L.lane * kCells};
     uint64_t legal = 0;
     uint32_t games = 0, w1 = 0, w2 = 0;
-    if (owner) {
+    if (active) {
         const int64_t bs = L.valid ? L.b : n - 1;
         const int tm = to_move[bs];
         if (turn) tabs = turn[bs];
@@ -1230,10 +1267,16 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 ? 
         const uint32_t ply = ply0 + t;
         const int pol = mover ? policy1 : policy0;
         // the greedy policy acts on this board at this ply (tutorial_greedy.py:34-49: not on a game's opening plies)
-        const bool gre = owner && L.valid && pol > 0 && tabs >= opening_plies;
+        const bool gre = active && L.valid && pol > 0 && tabs >= opening_plies;
         const uint32_t prev3 = mover ? hp1 : hp0;
-        const GreedyResult g = greedy_tile<W>(S, slot, p, mover, gre ? legal : 0ull, pol, deep, prev3, ts);
-        if (!owner) continue;
+        // (one tile per workgroup: behind a call, see greedy_tile_call -- 12.6 -> 11.6 us per ply at 16 384 boards, 79 -> 71 at
+        // 262 144; blocks of tiles run at two wavefronts per SIMD anyway and have the registers: inlined, 19.1 -> 18.8 at 65 536)
+        GreedyResult g;
+        if constexpr (NT == 1 && W > 1)
+            g = greedy_tile_call<NT, W>(S, p, mover, gre ? legal : 0ull, pol, deep, prev3);
+        else
+            g = greedy_tile<NT, W>(S, p, mover, gre ? legal : 0ull, pol, deep, prev3, ts);
+        if (!active) continue;
         int action;
         {
             // :211-217 with the library's sampler on generator stream 1 (as gbl_greedy_act, keyed by the ply index)
@@ -1295,7 +1338,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 ? 
         legal = legal54(p, mover);  // the next mover's: stored now, the next ply's policy is handed it
         if (mask_t) mask_rows(legal, mask_t + cell * kActions);
     }
-    if (!owner) return;
+    if (!active) return;
     wave_lds_fence();  // every lane's byte patches are in the state image
     tile_out<kCells>(state + L.tile * (kTile * kCells), s_state, L.lane, L.rows);
     if (L.valid) {
@@ -1319,7 +1362,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 ? 
     }
 }
 
-int greedy_waves(int depth, int64_t n);  // (defined with the greedy entry points below)
+int greedy_shape(int depth, int64_t n);  // (defined with the greedy entry points below)
 
 }  // namespace
 
@@ -1747,18 +1790,21 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
     if (turn && (reinterpret_cast<uintptr_t>(turn) & 3u)) return fail(GBL_ERR_ALIGN, "turn must be 4-byte aligned");
     if (counters && (reinterpret_cast<uintptr_t>(counters) & 127u))
         return fail(GBL_ERR_ALIGN, "counters must be 128-byte aligned");
-    const Geometry g = geometry(n);
     hipStream_t s = (hipStream_t)stream;
     const int depth = policy0 > policy1 ? policy0 : policy1;
-    const int waves = depth <= 1 ? 1 : greedy_waves(depth, n);
-#define GBL_CP(W)                                                                                                          \
-    hipLaunchKernelGGL(k_collect_policy<W>, dim3(g.grid), dim3(64 * W), 0, s, state, to_move, n, g.ntiles, seed, env_base,  \
-                       ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj, reward_traj,        \
-                       done_traj, to_move_traj, mask_traj, obs_traj, chosen_traj, how_traj, cand_traj, hist, policy0,      \
-                       policy1, opening_plies, illegal_mode, counters, turn)
-    if (waves >= 8) GBL_CP(8);
-    else if (waves >= 4) GBL_CP(4);
-    else GBL_CP(1);
+    const int shape = greedy_shape(depth, n);
+#define GBL_CP(NT, W)                                                                                                      \
+    do {                                                                                                                   \
+        const Geometry g = block_geometry(n, NT);                                                                          \
+        hipLaunchKernelGGL((k_collect_policy<NT, W>), dim3(g.grid), dim3(64 * W), 0, s, state, to_move, n, g.ntiles, seed,  \
+                           env_base, ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj,       \
+                           reward_traj, done_traj, to_move_traj, mask_traj, obs_traj, chosen_traj, how_traj, cand_traj,    \
+                           hist, policy0, policy1, opening_plies, illegal_mode, counters, turn);                           \
+    } while (0)
+    if (shape == 48) GBL_CP(4, 8);
+    else if (shape == 18) GBL_CP(1, 8);
+    else if (shape == 14) GBL_CP(1, 4);
+    else GBL_CP(1, 1);
 #undef GBL_CP
     GBL_LAUNCHED("gbl_collect_policy");
 }
@@ -1849,34 +1895,40 @@ int gbl_validate(const int8_t *state, int8_t *flags, int64_t n, void *stream)
 }
 
 namespace {
-// Wavefronts per tile (depth 2).  Round 1 (scripts/bench_greedy.py, 65 536 / 262 144 / 2^20 boards):
-// 1: 49 / 155 / 518 us, 2: 43 / 139 / 487, 4: 41 / 121 / 451, 8: 40 / 136 / 520, 16: 50 / 176 / 679.
-// Round 2 (scripts/ab_greedy.py, in-process): 8 wavefronts shorten a lone tile's serial chain -- 4 096 / 16 384 boards
-// 11.2 / 11.4 -> 10.0 / 10.2 us -- are level at 65 536 - 131 072 boards (18.1 us both) and lose 2-4 % beyond, where
-// the CUs' issue rate decides: small batches take 8, the others 4.
-int greedy_waves(int depth, int64_t n)
+// The shape of the greedy kernels' workgroups (see GreedyLds): 10 * (tiles per workgroup) + wavefronts.
+// Round 1 (one tile per workgroup; scripts/bench_greedy.py, 65 536 / 262 144 / 2^20 boards): 1 wavefront 49 / 155 / 518 us,
+// 2: 43 / 139 / 487, 4: 41 / 121 / 451, 8: 40 / 136 / 520, 16: 50 / 176 / 679.  Round 2 (scripts/ab_greedy.py, in-process):
+// eight wavefronts shorten a lone tile's serial chain -- 4 096 / 16 384 boards 11.2 / 11.4 -> 10.0 / 10.2 us -- and lose
+// 2-4 % beyond 131 072 boards.  Round 3 (ab_greedy.py / ab_policy_collect.py): blocks of four tiles with four owners and four
+// helpers (48) -- every wavefront busy in every phase, one workgroup per CU -- win where the batch is ONE generation of tiles
+// (65 536 boards: 15.9 -> 15.4 us, gbl_collect_policy 20.6 -> 18.8 us per ply), are level at 131 072 and lose beyond (2^20
+// boards: 182 -> 218 us: a CU then holds 8 wavefronts instead of 20); blocks of two tiles (24) lost everywhere.
+int greedy_shape(int depth, int64_t n)
 {
-#ifdef GBL_FORCE_GREEDY_WAVES  // 1, 2, 4 or 8: A/B builds (scripts/build_variant.sh)
-    (void)depth; (void)n;
-    return GBL_FORCE_GREEDY_WAVES;
+#ifdef GBL_FORCE_GREEDY_SHAPE  // 14, 18 or 48: A/B builds (scripts/build_variant.sh)
+    (void)n;
+    return depth == 1 ? 11 : GBL_FORCE_GREEDY_SHAPE;
 #else
-    return depth == 1 ? 1 : n <= 32768 ? 8 : 4;
+    return depth == 1 ? 11 : n <= 32768 ? 18 : n <= 131072 ? 48 : 14;
 #endif
 }
 
-void launch_greedy(int waves, const Geometry &g, hipStream_t stream, const int8_t *state, const int8_t *to_move,
+void launch_greedy(int shape, int64_t n, hipStream_t stream, const int8_t *state, const int8_t *to_move,
                    const int8_t *mask, const int8_t *hist, int depth, int32_t *action_out, int8_t *cand_mask_out,
-                   int8_t *fallback_out, int64_t n, int8_t *hist_rw, int32_t *final_out, uint64_t seed,
+                   int8_t *fallback_out, int8_t *hist_rw, int32_t *final_out, uint64_t seed,
                    uint64_t env_base, uint32_t call, const uint32_t *call_dev = nullptr)
 {
-#define GBL_GREEDY(W)                                                                                            \
-    hipLaunchKernelGGL(k_greedy<W>, dim3(g.grid), dim3(64 * W), 0, stream, state, to_move, mask, hist, depth,      \
-                       action_out, cand_mask_out, fallback_out, n, g.ntiles, hist_rw, final_out, seed, env_base, \
-                       call, call_dev)
-    if (waves >= 8) GBL_GREEDY(8);
-    else if (waves >= 4) GBL_GREEDY(4);
-    else if (waves == 2) GBL_GREEDY(2);
-    else GBL_GREEDY(1);
+#define GBL_GREEDY(NT, W)                                                                                              \
+    do {                                                                                                               \
+        const Geometry g = block_geometry(n, NT);                                                                      \
+        hipLaunchKernelGGL((k_greedy<NT, W>), dim3(g.grid), dim3(64 * W), 0, stream, state, to_move, mask, hist, depth, \
+                           action_out, cand_mask_out, fallback_out, n, g.ntiles, hist_rw, final_out, seed, env_base,   \
+                           call, call_dev);                                                                            \
+    } while (0)
+    if (shape == 48) GBL_GREEDY(4, 8);
+    else if (shape == 18) GBL_GREEDY(1, 8);
+    else if (shape == 14) GBL_GREEDY(1, 4);
+    else GBL_GREEDY(1, 1);
 #undef GBL_GREEDY
 }
 }  // namespace
@@ -1889,8 +1941,8 @@ int gbl_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask, c
     if (depth < 1 || depth > 3) return fail(GBL_ERR_ARG, "depth must be 1, 2 or 3");
     GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask, "mask"); GBL_ALIGNED(cand_mask_out, "cand_mask_out");
     if (hist && (reinterpret_cast<uintptr_t>(hist) & 1u)) return fail(GBL_ERR_ALIGN, "hist must be 2-byte aligned");
-    launch_greedy(greedy_waves(depth, n), geometry(n), (hipStream_t)stream, state, to_move, mask, hist, depth, action_out,
-                  cand_mask_out, fallback_out, n, nullptr, nullptr, 0, 0, 0);
+    launch_greedy(greedy_shape(depth, n), n, (hipStream_t)stream, state, to_move, mask, hist, depth, action_out,
+                  cand_mask_out, fallback_out, nullptr, nullptr, 0, 0, 0);
     GBL_LAUNCHED("gbl_greedy");
 }
 
@@ -1911,8 +1963,8 @@ int gbl_greedy_act_at(const int8_t *state, const int8_t *to_move, const int8_t *
     if (depth < 1 || depth > 3) return fail(GBL_ERR_ARG, "depth must be 1, 2 or 3");
     GBL_ALIGNED(state, "state"); GBL_ALIGNED(mask, "mask"); GBL_ALIGNED(cand_mask_out, "cand_mask_out");
     if (hist && (reinterpret_cast<uintptr_t>(hist) & 1u)) return fail(GBL_ERR_ALIGN, "hist must be 2-byte aligned");
-    launch_greedy(greedy_waves(depth, n), geometry(n), (hipStream_t)stream, state, to_move, mask, nullptr, depth, chosen_out,
-                  cand_mask_out, fallback_out, n, hist, action_out, seed, env_base, call, call_dev);
+    launch_greedy(greedy_shape(depth, n), n, (hipStream_t)stream, state, to_move, mask, nullptr, depth, chosen_out,
+                  cand_mask_out, fallback_out, hist, action_out, seed, env_base, call, call_dev);
     GBL_LAUNCHED("gbl_greedy_act");
 }
 

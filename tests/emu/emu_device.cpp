@@ -368,7 +368,7 @@ void emu_decode_obs(const int8_t *obs, int8_t *state, int8_t *to_move, int64_t n
 static int64_t g_pairs = 0, g_deferred = 0, g_fast_mismatch = 0, g_held = 0, g_items = 0;
 // The rule of greedy_root_rule.h against the exact evaluation, on every candidate it would settle.
 // out: boards, candidates settled from the root, of them with a winning reply, placements sent to the exact evaluation
-// (risky squares), MISMATCHES (summary or candidate-set bits differ from greedy_reply<true>: must be 0)
+// (risky squares), MISMATCHES (summary or candidate-set bits differ from greedy_reply: must be 0)
 void emu_greedy_root_rule(const int8_t *state, const int8_t *to_move, const int8_t *mask_in, int64_t n, int64_t *out)
 {
     for (int k = 0; k < 5; ++k) out[k] = 0;
@@ -390,7 +390,7 @@ void emu_greedy_root_rule(const int8_t *state, const int8_t *to_move, const int8
         out[3] += __builtin_popcountll(hand & ~resolved);
         for (uint64_t it = resolved; it; it &= it - 1) {
             const uint32_t a = (uint32_t)__builtin_ctzll(it);
-            const uint32_t want = greedy_reply<true>(p, me, h.legal_me, a);
+            const uint32_t want = greedy_reply(p, me, h.legal_me, a);
             const uint32_t got = greedy_hand_summary(p, me, g.replies, h.legal_me, a);
             const bool fl = (want & 1u) && ((h.legal_me >> ((want >> 1) & 63u)) & 1ull);
             out[1]++;
@@ -483,13 +483,9 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
         };
         for (int g = 0; g < total; ++g) {
             const uint32_t o = pair[g] >> 8, a = pair[g] & 0xFFu;
-            const uint32_t sum = greedy_reply<true>(P[o], ME[o], H[o].legal_me, a);
+            const uint32_t sum = greedy_reply(P[o], ME[o], H[o].legal_me, a);
             g_pairs++;
             record(o, a, sum);
-            // (the cheap evaluation is no longer used by the kernel; where it claims to apply it must still agree)
-            const uint32_t cheap = greedy_reply<false>(P[o], ME[o], H[o].legal_me, a);
-            if (cheap == kGreedyDefer) g_deferred++;
-            else if (cheap != sum) g_fast_mismatch++;
         }
         uint64_t UND[64][kRootItems];
         for (int l = 0; l < 64; ++l) {
@@ -504,7 +500,7 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
         for (int l = 0; l < 64; ++l)
             for (uint64_t it = PLAN[l].resolved; it; it &= it - 1) {
                 const uint32_t a = (uint32_t)__builtin_ctzll(it);
-                const uint32_t want = greedy_reply<true>(P[l], ME[l], H[l].legal_me, a);
+                const uint32_t want = greedy_reply(P[l], ME[l], H[l].legal_me, a);
                 const uint32_t got = PLAN[l].items ? greedy_hand_lookup(PLAN[l].items, H[l].legal_me, UND[l], a) : 0u;
                 const bool fl = (want & 1u) && ((H[l].legal_me >> ((want >> 1) & 63u)) & 1ull);
                 g_held++;

@@ -167,9 +167,9 @@ def test_greedy_vs_oracle_selfplay(boards):
     for x, y in zip(e, o):
         assert np.array_equal(x, y)
     # (inside the pooled flow the closed form of the depth-2 loop, greedy_replay_closed, is cross-checked against the
-    #  loop form, greedy_replay_sets, on every board; the cheap reply evaluation against the exact one wherever it claims
-    #  to apply; and EVERY placement from hand that the root rule settles without an evaluation -- its summary looked up
-    #  in the board's table and its bits in the merged candidate sets -- against its exact evaluation)
+    #  loop form, greedy_replay_sets, on every board; and EVERY placement from hand that the root rule settles without an
+    #  evaluation -- its summary looked up in the board's table and its bits in the merged candidate sets -- against its
+    #  exact evaluation)
     pairs, deferred, bad, settled, items = emu.greedy_stats()
     assert bad == 0
     assert settled > 1.2 * pairs and 0 < items < pairs  # the rule settles most candidates, from a few items per board
