@@ -637,19 +637,26 @@ def main():
         timing = "HIP event pair around each of %d eager gbl_step launches after the timed replay" % launches
     mean_kernel_s = kernel_s / launches
     per_rank_us = [mean_kernel_s * 1e6]
-    per_rank_placement = [p.traj["_placement"] if p.traj is not None else None]
+    mine_pl = p.traj["_placement"] if p.traj is not None else None
+    per_rank_placement = [mine_pl]
     if dist is not None:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, per_rank_placement[0])  # (after the timed region: a few hundred bytes per rank)
-        per_rank_placement = gathered
         cpu = args.dist_backend != "nccl"
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if cpu else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        mine = torch.tensor([mean_kernel_s * 1e6], dtype=torch.float64, device="cpu" if cpu else dev)
+        # per rank: kernel time, and where its trajectory arrays ended up (probe ratio, probes, GiB held while searching, its
+        # cap, spread flag; -1 = no search) -- one small all-gather of numbers, after the timed region
+        pl = mine_pl or {}
+        mine = torch.tensor([mean_kernel_s * 1e6, pl.get("ratio", -1.0), len(pl.get("probes", ())), pl.get("held_gib", -1.0),
+                             pl.get("cap_gib", -1.0), 1.0 if pl.get("spread") else 0.0],
+                            dtype=torch.float64, device="cpu" if cpu else dev)
         allk = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allk, mine)
-        per_rank_us = [float(x.item()) for x in allk]
+        rows = [[float(v) for v in x.tolist()] for x in allk]
+        per_rank_us = [r[0] for r in rows]
+        per_rank_placement = [{"ratio": r[1], "probes": int(r[2]), "held_gib": r[3], "cap_gib": r[4], "spread": bool(r[5])}
+                              if r[1] >= 0 else None for r in rows]
+        per_rank_placement[0] = mine_pl if rank == 0 else per_rank_placement[0]
 
     if rank == 0:
         roof = p.kernel_roofline(kernel_s, plies_timed, launches, timing)

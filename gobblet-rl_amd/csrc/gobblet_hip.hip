@@ -76,13 +76,9 @@ inline int nt_policy(int64_t n)
 #endif
 }
 
-// gbl_collect stores a trajectory of up to this many bytes with plain (cached) stores, a larger one non-temporally.
-// 0 = always non-temporal, the robust choice: plain stores win 5-12 % where the trajectory fits the Infinity Cache AND
-// the batch is 131 072 - 262 144 boards, but lose 15 % at 65 536 boards and 30 % once it does not fit (see k_collect).
-#ifndef GBL_COLLECT_CACHED_BYTES
-#define GBL_COLLECT_CACHED_BYTES ((int64_t)0)
-#endif
-constexpr int64_t kCollectCachedBytes = GBL_COLLECT_CACHED_BYTES;
+// gbl_collect always stores its trajectory rows non-temporally.  Plain (cached) stores win 5-12 % where the trajectory fits
+// the Infinity Cache AND the batch is 131 072 - 262 144 boards, but lose 15 % at 65 536 boards and 30 % once it does not fit
+// (see k_collect): the product build has no such path; A/B builds get it back with -DGBL_FORCE_COLLECT_NT=0.
 
 // Which kernel a gbl_collect call runs (also reported by gbl_collect_variant): GBL_COLLECT_PAIR = k_collect2 (grids of up
 // to kCollect2MaxTiles tiles that stream), GBL_COLLECT_STREAM / GBL_COLLECT_CACHED = k_collect with non-temporal / plain
@@ -91,13 +87,11 @@ constexpr int64_t kCollect2MaxTiles = 2048;  // 8 workgroups per CU (110 VGPRs: 
 
 inline int collect_variant(int64_t n, uint32_t plies, bool with_mask, bool with_obs)
 {
-    // bytes of trajectory rows the launch writes, against what the Infinity Cache keeps (see k_collect)
-    const int64_t row_bytes = (int64_t)plies * n * ((with_mask ? kActions : 0) + (with_obs ? kObs : 0) + 9);
+    (void)plies;
 #ifdef GBL_FORCE_COLLECT_NT
     const bool nt = (GBL_FORCE_COLLECT_NT) != 0;
-    (void)row_bytes;
 #else
-    const bool nt = row_bytes > kCollectCachedBytes;
+    const bool nt = true;
 #endif
 #ifdef GBL_FORCE_COLLECT_PAIR  // 0 / 1: A/B builds
     const bool pair = (GBL_FORCE_COLLECT_PAIR) != 0;
@@ -557,7 +551,7 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_rollout(int8_t *__restrict_
 // write-once stream to HBM: 2^20 boards x 8 plies 34.6 vs 45.0 us per ply) or plainly (a trajectory that fits the
 // 256 MiB cache stays there for whoever reads it next and is overwritten there by the next launch: 131 072 boards x 8
 // plies 4.15 vs 4.76 us per ply, 262 144 x 4: 8.5 vs 9.5 -- but 65 536 x 16: 2.44 vs 2.12); the host decides by the
-// footprint against kCollectCachedBytes (gpurun_out/ab5, scripts/sweep_sizes.py with -DGBL_FORCE_COLLECT_NT=0|1).
+// footprint in A/B builds only (gpurun_out/ab5, scripts/sweep_sizes.py with -DGBL_FORCE_COLLECT_NT=0|1); the product streams.
 template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY, bool NT>
 __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n,
                                                 int64_t ntiles, uint64_t seed, uint64_t env_base,
@@ -1039,10 +1033,7 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
         pool_fence<W>();
         // (E) the pairs, from the first wavefront up ...
         const int total = S.npairs;
-        for (int g = (int)threadIdx.x; g < total; g += kTile * W) {
-            const uint32_t pair = S.pair[g], o = pair >> 8, a = pair & 0xFFu;
-            const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
-            const uint32_t sum = greedy_reply(q, (int)(S.board[o][3] & 1u), S.legal[o], a);
+        auto record = [&](uint32_t o, uint32_t a, uint32_t sum) {
             if (sum & 1u) {
                 S.reply[o][a] = (uint16_t)sum;
                 atomicOr(&S.threat[o], 1ull << a);
@@ -1051,6 +1042,11 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
                 if ((S.legal[o] >> ((sum >> 1) & 63u)) & 1ull) atomicOr(&S.flegal[o], 1ull << a);
             }
             if (sum >> 15) atomicOr(&S.allwin[o], 1ull << a);
+        };
+        for (int g = (int)threadIdx.x; g < total; g += kTile * W) {
+            const uint32_t pair = S.pair[g], o = pair >> 8, a = pair & 0xFFu;
+            const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
+            record(o, a, greedy_reply(q, (int)(S.board[o][3] & 1u), S.legal[o], a));
         }
         // ... and the items, from the last wavefront down (it has the fewest pairs)
         const int nitems = S.nitems;
@@ -1728,11 +1724,18 @@ int gbl_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int32_t
     Geometry g = geometry(n);
     hipStream_t s = (hipStream_t)stream;
     const int variant = collect_variant(n, plies, mask_traj != nullptr, obs_traj != nullptr);
-    const bool pair = variant == GBL_COLLECT_PAIR, nt = variant != GBL_COLLECT_CACHED;
+    const bool pair = variant == GBL_COLLECT_PAIR;
+    [[maybe_unused]] const bool nt = variant != GBL_COLLECT_CACHED;
+#ifdef GBL_FORCE_COLLECT_NT  // (A/B builds: the plain-store instantiation exists only there)
 #define GBL_COLLECT_K(M, O, D)                                  \
     if (pair) GBL_COLLECT_K2(M, O, D);                          \
     else if (nt) GBL_COLLECT_KN(M, O, D, true);                 \
     else GBL_COLLECT_KN(M, O, D, false)
+#else
+#define GBL_COLLECT_K(M, O, D)                                  \
+    if (pair) GBL_COLLECT_K2(M, O, D);                          \
+    else GBL_COLLECT_KN(M, O, D, true)
+#endif
 #define GBL_COLLECT_K2(M, O, D)                                                                                         \
     hipLaunchKernelGGL((k_collect2<M, O, D>), dim3((uint32_t)g.ntiles), dim3(128), 0, s, state, to_move, n, g.ntiles, seed, \
                        env_base, ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj,        \

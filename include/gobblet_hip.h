@@ -303,7 +303,7 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
 /* Which kernel a gbl_collect call of this shape runs (no launch; >= 0, or GBL_ERR_ARG): benchmarks and profiles label
  * their records with it instead of re-deriving the library's dispatch rule.
  *   GBL_COLLECT_STREAM  k_collect,  one wavefront per tile of 64 boards, trajectory rows stored non-temporally
- *   GBL_COLLECT_CACHED  k_collect with plain stores (never chosen by the product build: A/B builds only)
+ *   GBL_COLLECT_CACHED  k_collect with plain stores (does not exist in the product build: A/B builds only)
  *   GBL_COLLECT_PAIR    k_collect2, two wavefronts per tile (one plays, one stores): grids of up to 2048 tiles */
 #define GBL_COLLECT_STREAM 0
 #define GBL_COLLECT_CACHED 1

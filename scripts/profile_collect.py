@@ -52,11 +52,13 @@ def main():
                  "bench_c4_shard_131072", "greedy_65536", "greedy_1048576", "greedy_policy", "playouts"):
         shutil.copy(os.path.join(SRC, name + ".json"), os.path.join(dst, name + ".json"))
     for name in ("facade.txt", "valu_rates.txt", "winner_lanes.txt", "write_classes.txt", "placement_probe_check.txt",
-                 "placement_ab.txt"):
-        shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
-    for run in ("collect", "single", "step", "greedy"):
-        open(os.path.join(dst, f"{run}_kernel_stats.csv"), "w").write(
-            capture(rocpd_summary.stats, os.path.join(SRC, f"{run}_stats", "p_results.db")))
+                 "placement_ab.txt", "soak_parity.txt", "wave_placement.txt"):
+        if os.path.exists(os.path.join(SRC, name)):
+            shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
+    for run in ("collect", "single", "step", "greedy", "policy", "driver"):
+        if os.path.exists(os.path.join(SRC, f"{run}_stats", "p_results.db")):
+            open(os.path.join(dst, f"{run}_kernel_stats.csv"), "w").write(
+                capture(rocpd_summary.stats, os.path.join(SRC, f"{run}_stats", "p_results.db")))
     open(os.path.join(dst, "kernel_durations_by_size.csv"), "w").write(
         "# scripts/sweep_sizes.py under rocprofv3 --kernel-trace: k_rollout = one ply per launch, k_collect = 32 plies per launch\n"
         + capture(rocpd_summary.bygrid, "k_rollout", os.path.join(SRC, "sweep_trace", "p_results.db"), 64)
@@ -64,17 +66,28 @@ def main():
     # ---- HBM traffic per launch ---------------------------------------------------------------------------------
     traffic = {}
     rows = ["kernel,counter,dispatches,mean_value_KB"]
-    for key, run, kernel in (("collect:1048576:T8", "collect", "k_collect<true, true"),
-                             ("fused:1048576", "single", "k_rollout<true, true"),
-                             ("collect:131072:T32", "shard_131072_T32", "k_collect2<true, true"),
-                             ("collect:131072:T20", "shard_131072_T20", "k_collect2<true, true"),
-                             ("collect:262144:T16", "shard_262144_T16", "k_collect<true, true"),
-                             ("collect:524288:T8", "shard_524288_T8", "k_collect<true, true")):
-        if not os.path.exists(os.path.join(SRC, f"{run}_pmc_FETCH_SIZE", "p_results.db")):
+    # run name (scripts/profile_round.sh: pmc_runs.txt) -> (key bench.py looks up, kernel name substring)
+    runs = {"collect_T8": ("collect:1048576:T8", "k_collect<true, true"), "collect_T20": ("collect:1048576:T20", "k_collect<true, true"),
+            "collect_4096_T32": ("collect:4096:T32", "k_collect2<true, true"),
+            "collect_131072_T32": ("collect:131072:T32", "k_collect2<true, true"),
+            "collect_131072_T20": ("collect:131072:T20", "k_collect2<true, true"),
+            "collect_262144_T16": ("collect:262144:T16", "k_collect<true, true"),
+            "collect_262144_T20": ("collect:262144:T20", "k_collect<true, true"),
+            "collect_524288_T8": ("collect:524288:T8", "k_collect<true, true"),
+            "collect_524288_T20": ("collect:524288:T20", "k_collect<true, true"),
+            "collect_4194304_T8": ("collect:4194304:T8", "k_collect<true, true"),
+            "collect_noobs_T8": ("collect-noobs:1048576:T8", "k_collect<true, false"),
+            "fused_1048576": ("fused:1048576", "k_rollout<true, true"), "fused_262144": ("fused:262144", "k_rollout<true, true"),
+            "fused_131072": ("fused:131072", "k_rollout<true, true"), "fused_4096": ("fused:4096", "k_rollout<true, true"),
+            "fused_4194304": ("fused:4194304", "k_rollout<true, true"),
+            "fused_noobs_1048576": ("fused-noobs:1048576", "k_rollout<true, false"),
+            "step_1048576": ("step:1048576", "k_step<true, true")}
+    for run, (key, kernel) in runs.items():
+        if not os.path.exists(os.path.join(SRC, f"pmc_{run}_FETCH_SIZE", "p_results.db")):
             continue
         kb = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            kb[c], n = counter_mean(os.path.join(SRC, f"{run}_pmc_{c}", "p_results.db"), kernel, c)
+            kb[c], n = counter_mean(os.path.join(SRC, f"pmc_{run}_{c}", "p_results.db"), kernel, c)
             rows.append(f"{kernel.replace(',', ';')} [{key}],{c},{n},{kb[c]:.3f}")
         traffic[key] = {
             # gfx950 reports half of wide coalesced reads (MI355X_MICROARCH.md): FETCH_SIZE is doubled
@@ -89,7 +102,8 @@ def main():
                             ("trajmask", "k_collect<true, false", "gbl_collect MASK_ONLY, 8 plies per launch, 2^20 boards"),
                             ("full", "k_rollout<true, true", "gbl_rollout FULL, one ply per launch, 2^20 boards"),
                             ("mask", "k_rollout<true, false", "gbl_rollout MASK_ONLY, one ply per launch, 2^20 boards"),
-                            ("greedy", "k_greedy", "gbl_greedy depth 2, 65536 boards")):
+                            ("greedy", "k_greedy", "gbl_greedy depth 2, 65536 boards"),
+                            ("policy", "k_collect_policy", "gbl_collect_policy greedy vs greedy, 16 plies per launch, 65536 boards")):
         sq = f"# {what}; rocprofv3 --pmc (two passes), summed over instances, mean per dispatch\n"
         sq += capture(rocpd_summary.counters, kernel, [os.path.join(SRC, f"{m}_sq1", "p_results.db"),
                                                        os.path.join(SRC, f"{m}_sq2", "p_results.db")])
@@ -98,6 +112,10 @@ def main():
             insts, _ = counter_mean(os.path.join(SRC, "greedy_sq1", "p_results.db"), "k_greedy", "SQ_INSTS_VALU")
             traffic["greedy:65536"] = {"SQ_INSTS_VALU": insts, "kernel_source_hash": khash,
                                        "source": f"profiles/{rnd}/sq_counters_greedy.csv"}
+        if m == "policy":
+            insts, _ = counter_mean(os.path.join(SRC, "policy_sq1", "p_results.db"), "k_collect_policy", "SQ_INSTS_VALU")
+            traffic["policy-collect:65536:T16"] = {"SQ_INSTS_VALU": insts, "kernel_source_hash": khash,
+                                                   "source": f"profiles/{rnd}/sq_counters_policy.csv"}
         print(sq)
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print(open(os.path.join(dst, "pmc_summary.csv")).read())

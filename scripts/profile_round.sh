@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 O=gpurun_out/final
 rm -rf $O && mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1   # (no compiler may run under the profiler's preload)
-for m in valu_rates winner_lanes write_classes; do   # the microbenchmarks this script runs
+for m in valu_rates winner_lanes write_classes wave_placement; do   # the microbenchmarks this script runs
   [ scripts/microbench/$m -nt scripts/microbench/$m.hip ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scripts/microbench/$m scripts/microbench/$m.hip >> $O/build.log 2>&1
 done
 # ---- bench lines --------------------------------------------------------------------------------------------
@@ -24,6 +24,7 @@ python scripts/bench_playouts.py > $O/playouts.json 2> /dev/null
 python scripts/bench_facade.py > $O/facade.txt
 scripts/microbench/valu_rates > $O/valu_rates.txt
 scripts/microbench/winner_lanes > $O/winner_lanes.txt
+scripts/microbench/wave_placement 1024 28672 > $O/wave_placement.txt
 # ---- placement of the trajectory arrays -------------------------------------------------------
 scripts/microbench/write_classes 160 > $O/write_classes.txt
 scripts/microbench/write_classes 160 131072 32 | grep -v "^  policy" >> $O/write_classes.txt
@@ -37,6 +38,12 @@ d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('run $i placement $pl: %.3e env-steps/s, %.2f us per ply, roofline.frac %.3f, %s' % (d['value'], d['ms_per_step'] * 1e3, d['roofline']['frac'], json.dumps(d['config']['trajectory_placement'])))" >> $O/placement_ab.txt
   done
 done
+# the same with 200 GiB of the device already taken by the process (a trainer's model and replay buffer): the search is capped
+# by a quarter of what is free
+for i in 1 2 3; do
+  python scripts/placement_full_device.py 200 >> $O/placement_ab.txt 2> /dev/null
+done
+python scripts/soak_parity.py 150 3 > $O/soak_parity.txt 2>&1
 echo "bench lines done"
 # ---- kernel traces (durations) ------------------------------------------------------------------------------
 rocprofv3 --kernel-trace --stats -d $O/collect_stats -o p -- python3 bench.py --steps 320 --no-configs --no-cpu-baseline > $O/collect_stats.log 2>&1
@@ -44,19 +51,39 @@ rocprofv3 --kernel-trace --stats -d $O/single_stats -o p -- python3 bench.py --m
 rocprofv3 --kernel-trace --stats -d $O/step_stats -o p -- python3 bench.py --mode step --steps 300 --no-configs --no-cpu-baseline > $O/step_stats.log 2>&1
 rocprofv3 --kernel-trace -d $O/sweep_trace -o p -- python3 scripts/sweep_sizes.py --sizes 4096,131072,262144,1048576 --modes full,mask,traj,trajmask --plies 128 --reps 2 > $O/sweep_trace.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/greedy_stats -o p -- python3 scripts/run_eager.py greedy 65536 20 > $O/greedy_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/policy_stats -o p -- python3 scripts/run_eager.py policy 65536 8 16 > $O/policy_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/driver_stats -o p -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-configs --no-cpu-baseline > $O/driver_stats.log 2>&1
 echo "kernel traces done"
 # ---- HBM traffic (separate --pmc passes; eager launches so that counters are attributed per dispatch) ----------
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $O/collect_pmc_$c -o p -- python3 scripts/run_eager.py traj 1048576 6 8 > $O/collect_pmc_$c.log 2>&1
-  rocprofv3 --pmc $c -d $O/single_pmc_$c -o p -- python3 scripts/run_eager.py full 1048576 20 > $O/single_pmc_$c.log 2>&1
-done
-# (the shards of BASELINE C4 at 8 / 4 / 2 GPUs, at the plies per launch bench.py picks for --steps 1000 and for --steps 20)
-for cfg in "131072 32" "131072 20" "262144 16" "524288 8"; do
-  set -- $cfg
+# one line per bench.py record: "run-name mode boards launches plies-per-launch" (profile_collect.py maps them to the keys of
+# profiles/pmc_traffic.json: the headline at 8 plies per launch and at the driver's single 20-ply launch, the C2 / C3 / C4-shard /
+# 2^22 / MASK_ONLY records, the one-ply kernels at every size bench.py reports, k_step)
+cat > $O/pmc_runs.txt <<EOT
+collect_T8 traj 1048576 6 8
+collect_T20 traj 1048576 4 20
+collect_4096_T32 traj 4096 6 32
+collect_131072_T32 traj 131072 6 32
+collect_131072_T20 traj 131072 6 20
+collect_262144_T16 traj 262144 6 16
+collect_262144_T20 traj 262144 6 20
+collect_524288_T8 traj 524288 6 8
+collect_524288_T20 traj 524288 4 20
+collect_4194304_T8 traj 4194304 4 8
+collect_noobs_T8 trajmask 1048576 6 8
+fused_1048576 full 1048576 20 1
+fused_262144 full 262144 20 1
+fused_131072 full 131072 20 1
+fused_4096 full 4096 20 1
+fused_4194304 full 4194304 10 1
+fused_noobs_1048576 mask 1048576 20 1
+step_1048576 step 1048576 12 1
+EOT
+while read name mode boards launches T; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c -d $O/shard_$1_T$2_pmc_$c -o p -- python3 scripts/run_eager.py traj $1 6 $2 > $O/shard_$1_T$2_pmc_$c.log 2>&1
+    rocprofv3 --pmc $c -d $O/pmc_${name}_$c -o p -- python3 scripts/run_eager.py $mode $boards $launches $T > $O/pmc_${name}_$c.log 2>&1
   done
-done
+done < $O/pmc_runs.txt
+echo "traffic counters done"
 # ---- SQ counters ------------------------------------------------------------------------------------------------
 SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES"
 SQ2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
@@ -66,5 +93,7 @@ for m in traj trajmask full mask; do
 done
 rocprofv3 --pmc $SQ1 -d $O/greedy_sq1 -o p -- python3 scripts/run_eager.py greedy 65536 20 > $O/greedy_sq1.log 2>&1
 rocprofv3 --pmc $SQ2 -d $O/greedy_sq2 -o p -- python3 scripts/run_eager.py greedy 65536 20 > $O/greedy_sq2.log 2>&1
+rocprofv3 --pmc $SQ1 -d $O/policy_sq1 -o p -- python3 scripts/run_eager.py policy 65536 6 16 > $O/policy_sq1.log 2>&1
+rocprofv3 --pmc $SQ2 -d $O/policy_sq2 -o p -- python3 scripts/run_eager.py policy 65536 6 16 > $O/policy_sq2.log 2>&1
 echo "counters done"
 ls $O

@@ -2,7 +2,8 @@
 """A few EAGER launches of one pipeline, for rocprofv3 --pmc passes (counters are attributed per dispatch):
     python scripts/run_eager.py MODE BOARDS [LAUNCHES] [T]
 MODE: full | mask (gbl_rollout, one ply per launch) | traj | trajmask (gbl_collect, T plies per launch) |
-      greedy (gbl_greedy depth 2 on the stationary mix)."""
+      step (gbl_sample + gbl_step per ply) | greedy (gbl_greedy depth 2 on the stationary mix) |
+      policy (gbl_collect_policy, greedy vs greedy, T plies per launch)."""
 import os
 import sys
 
@@ -14,7 +15,7 @@ import gobblet_rl_amd as G  # noqa: E402
 mode, n = sys.argv[1], int(sys.argv[2])
 launches = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 T = int(sys.argv[4]) if len(sys.argv) > 4 else 32
-env = G.BatchedGobblet(n, "cuda:0", auto_reset=True, seed=0, with_observation=mode in ("full", "traj", "greedy"))
+env = G.BatchedGobblet(n, "cuda:0", auto_reset=True, seed=0, with_observation=mode in ("full", "traj", "greedy", "step", "policy"))
 if mode in ("full", "mask"):  # warm up with another kernel, so that every k_rollout dispatch of the profile is a measured one
     for _ in range(4):
         env.collect(16)
@@ -25,6 +26,13 @@ if mode in ("traj", "trajmask"):
     buf = env.trajectory_buffers(T)
     for _ in range(launches):
         env.collect(T, out=buf)
+elif mode == "policy":
+    buf = env.trajectory_buffers(T, policy_outputs=True)
+    for _ in range(launches):
+        env.collect(T, out=buf, policies=("greedy", "greedy"), refresh=False)
+elif mode == "step":
+    for _ in range(launches):
+        env.step(env.sample_actions())
 elif mode == "greedy":
     nat, L = G._native, G._native.lib()
     act = torch.empty(n, dtype=torch.int32, device="cuda:0")

@@ -971,6 +971,16 @@ def test_bench_script_runs_and_reports(G):
         r = d["roofline"]
         assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
         assert abs(d["value"] - 16384 * 20 / (d["ms_per_step"] * 20 / 1e3)) / d["value"] < 1e-6
+    # the RCCL path of an N > 1 run -- process group on the device, barriers around the timed region, MAX-reduce of the elapsed
+    # time, all-gather of the per-rank numbers -- rehearsed at world size 1 (an 8-GPU node is the driver's to launch)
+    env = dict(os.environ, GBL_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--boards", "262144", "--steps", "20", "--warmup", "5",
+                          "--no-configs", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["rccl_ranks"] == 1 and d["config"]["dist_backend"] == "nccl" and len(d["config"]["kernel_us_per_rank"]) == 1
+    assert d["config"]["trajectory_placement_per_rank"][0]["probes"]
 
 
 def test_bench_script_two_ranks_rehearsal(G):
