@@ -2,6 +2,8 @@
 """The throughput path: N boards in lockstep on one MI355X.
 
     python examples/example_batched.py --boards 1048576 --plies 200 --policy random|greedy [--graph K] [--collect T]
+    python examples/example_batched.py --boards 65536 --plies 64 --policy greedy --opponent random --collect 16
+        (whole games greedy vs random inside the launches: the decisions are taken on the device, gbl_collect_policy)
 """
 import argparse
 import os
@@ -21,28 +23,33 @@ def main():
     ap.add_argument("--policy", default="random", choices=["random", "greedy"])
     ap.add_argument("--graph", type=int, default=0,
                     help="capture this many plies in one hipGraph and replay it (launch latency off the critical path)")
+    ap.add_argument("--opponent", default=None, choices=["random", "greedy"],
+                    help="with --collect: player_2's policy (default: the same as --policy)")
     ap.add_argument("--collect", type=int, default=0,
-                    help="random policy only: T plies per launch with every ply kept (gbl_collect) -- what a rollout "
-                         "collector hands a trainer: trajectory tensors (T, N, ...)")
+                    help="T plies per launch with every ply kept (gbl_collect; with a greedy side gbl_collect_policy: the "
+                         "reference's greedy lookahead decides on the device, two random opening plies per game as in "
+                         "tutorials/GreedyAgent/tutorial_greedy.py) -- what a rollout collector hands a trainer: trajectory "
+                         "tensors (T, N, ...)")
     args = ap.parse_args()
-    env = G.BatchedGobblet(args.boards, "cuda:0", auto_reset=True, seed=0)
+    env = G.BatchedGobblet(args.boards, "cuda:0", auto_reset=True, seed=0, track_turn=True)
     if args.collect:
-        assert args.policy == "random", "--collect plays masked-random moves"
+        sides = (args.policy, args.opponent or args.policy)
+        device_policy = dict(policies=sides, opening_plies=2) if "greedy" in sides else {}
         T, launches = args.collect, max(1, args.plies // args.collect)
-        buf = env.trajectory_buffers(T)              # reused by every launch: the staging area of a replay buffer
-        env.collect(T, out=buf)                      # warm-up
+        buf = env.trajectory_buffers(T, policy_outputs=bool(device_policy))  # reused by every launch: a replay buffer's staging area
+        env.collect(T, out=buf, **device_policy)     # warm-up
         wins = torch.zeros(3, dtype=torch.int64, device=env.device)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(launches):
-            tr = env.collect(T, out=buf, refresh=False)
+            tr = env.collect(T, out=buf, refresh=False, **device_policy)
             # a consumer would now read tr["observation"] (T,N,3,3,13), tr["action_mask"] (T,N,54), tr["actions"],
             # tr["rewards"], tr["done"], tr["to_move"]; here: tally the results of the games that ended
             wins += torch.bincount((tr["winner"][tr["done"] != 0] + 1).long(), minlength=3)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         games = int(wins[0] + wins[2])
-        print(f"{args.boards} boards x {launches * T} plies (random, {T} plies per launch, every ply kept): "
+        print(f"{args.boards} boards x {launches * T} plies ({sides[0]} vs {sides[1]}, {T} plies per launch, every ply kept): "
               f"{args.boards * launches * T / dt:.3e} env-steps/s incl. the tally, {games} games finished, player_1 won "
               f"{int(wins[2]) / max(1, games):.1%}")
         return

@@ -20,12 +20,15 @@ on a fresh device consecutive blocks can stay inside one 96 GiB class -- stops a
 other blocks and the gaps at the end.
 
 What a caller that shares the device can rely on (round 3):
+  * the pair as torch's allocator places it is probed first and stays in the race: if it is clean it is used as it is (no
+    block, nothing pinned), and a block pair replaces it only if it is clearly better -- the result is never worse than
+    the caller's own placement (with 200 GiB of the device taken the capped search found nothing in three runs out of
+    three while the allocator's pair was clean, profiles/r03/placement_ab.txt);
   * the search never holds more than ``MAX_HOLD_BYTES`` (64 GiB) nor more than a quarter of the memory that was free
     when it started (the two arrays' own blocks always count), and leaves ``RESERVE_BYTES`` untouched;
   * an allocation the device refuses ENDS the search (the best pair seen so far is used); if not even the two arrays'
-    own blocks fit, ``PlacementUnavailable`` is raised and ``BatchedGobblet.trajectory_buffers`` falls back to plain
-    torch allocations, recording why;
-  * ``torch.cuda.empty_cache()`` is never called, and nothing is taken from or returned to torch's allocator.
+    own blocks fit the plain pair is kept (without one, ``PlacementUnavailable`` is raised) -- the reason is recorded;
+  * ``torch.cuda.empty_cache()`` is never called: rejected blocks are ``hipFree``d, torch's cache is left alone.
 """
 from __future__ import annotations
 
@@ -48,6 +51,7 @@ FREE_FRACTION = 4          # ... and never more than 1 / FREE_FRACTION of the me
 MAX_SKIP_BYTES = 32 * GIB  # the largest single gap
 MAX_PROBES = 16
 RESERVE_BYTES = 4 * GIB    # never take the device's last few GiB for the search
+PLAIN_MARGIN = 0.03        # a block pair must beat the allocator's own placement by this much to be worth its blocks
 
 
 class PlacementUnavailable(RuntimeError):
@@ -113,28 +117,56 @@ _OOM = (torch.OutOfMemoryError, nat.GobbletHipError, MemoryError)
 
 
 def spread_pair(bytes_a: int, bytes_b: int, device, slot_boards: int = 0, plies: int = 0, max_probes: int = MAX_PROBES,
-                max_hold_bytes: int | None = None, alloc=None, free=None):
-    """Two zero-filled uint8 tensors of bytes_a / bytes_b bytes on `device` (each the head of a block of its own, see the
-    module docstring), placed so that writes to them overlap.  Returns (a, b, info); info records every probe, what was
-    held and why the search ended.  If no pair is clean, the best one seen is returned.  alloc(nbytes) -> uint8 tensor
-    (raising on out-of-memory) and free() -> free bytes: the allocator and the memory gauge (tests script them)."""
+                max_hold_bytes: int | None = None, alloc=None, free=None, plain=None):
+    """Two zero-filled uint8 tensors of bytes_a / bytes_b bytes on `device`, placed so that writes to them overlap.
+    Returns (a, b, info); info records every probe, what was held and why the search ended.
+
+    plain: () -> (a, b), the two arrays as the caller would otherwise allocate them (torch's allocator).  That pair is
+    probed FIRST: if it is clean already it is used as it is -- no block, nothing pinned; otherwise the block search runs
+    (each array the head of a block of its own, see the module docstring) and the plain pair stays in the race: the best
+    pair seen wins, so the result is never worse than the caller's own placement (with most of a device taken the capped
+    search may find nothing better).  alloc(nbytes) -> uint8 tensor (raising on out-of-memory) and free() -> free bytes:
+    the allocator and the memory gauge (tests script them)."""
     t0 = time.perf_counter()
     dev = torch.device(device)
     alloc = alloc or device_alloc(dev)
     free = free or (lambda: free_bytes(dev))
     size = {"a": int(bytes_a), "b": int(bytes_b)}
+    first = None  # (a, b, ratio) of the caller's own placement
+    if plain is not None:
+        pa, pb = plain()
+        us_both, us_a, us_b = probe(pa, pb, slot_boards, plies)
+        first = (pa, pb, us_both / max(us_a + us_b, 1e-9))
+        if first[2] <= ACCEPT_RATIO:
+            pa.zero_(); pb.zero_()
+            return pa, pb, {"spread": True, "ratio": round(first[2], 3), "probes": [round(first[2], 3)], "block_gib": [0.0, 0.0],
+                            "held_gib": 0.0, "cap_gib": 0.0, "released_blocks": 0,
+                            "ended": "the allocator's own placement is clean", "seconds": round(time.perf_counter() - t0, 3)}
+
+    def keep_plain(why):
+        pa, pb, r = first
+        pa.zero_(); pb.zero_()
+        return pa, pb, {"spread": bool(r <= SPREAD_RATIO), "ratio": round(r, 3), "probes": [round(r, 3)], "block_gib": [0.0, 0.0],
+                        "held_gib": 0.0, "cap_gib": 0.0, "released_blocks": 0, "ended": why,
+                        "seconds": round(time.perf_counter() - t0, 3)}
+
     block = {k: block_bytes(v) for k, v in size.items()}
     own = block["a"] + block["b"]
     free0 = free()
     if free0 < own + RESERVE_BYTES:
-        raise PlacementUnavailable("%.1f GiB free, the arrays' own blocks need %.1f GiB + %d GiB reserve"
-                                   % (free0 / GIB, own / GIB, RESERVE_BYTES // GIB))
+        why = ("%.1f GiB free, the arrays' own blocks need %.1f GiB + %d GiB reserve"
+               % (free0 / GIB, own / GIB, RESERVE_BYTES // GIB))
+        if first is not None:
+            return keep_plain("no block search: " + why)
+        raise PlacementUnavailable(why)
     cap = min(MAX_HOLD_BYTES if max_hold_bytes is None else int(max_hold_bytes), free0 // FREE_FRACTION)
     cap = max(cap, own)
     try:
         pool = {"a": [alloc(block["a"])]}
         pool["b"] = [alloc(block["b"])]
     except _OOM as e:
+        if first is not None:
+            return keep_plain("no block search: the device refused the arrays' own blocks")
         raise PlacementUnavailable("the device refused the arrays' own blocks: %s" % e) from None
     held = own
     tried = []
@@ -182,6 +214,14 @@ def spread_pair(bytes_a: int, bytes_b: int, device, slot_boards: int = 0, plies:
             try_pair(*((new, k) if grow == "a" else (k, new)))
         grow = other
     ratio, ia, ib = best
+    if first is not None and first[2] <= ratio + PLAIN_MARGIN:  # nothing (clearly) better than the caller's own placement turned up
+        out = keep_plain("%s; the allocator's own placement (%.3f) was not beaten" % (ended, first[2]))
+        out[2].update(probes=[round(first[2], 3)] + tried, held_gib=round(held / GIB, 1), cap_gib=round(cap / GIB, 1),
+                      released_blocks=len(pool["a"]) + len(pool["b"]) + len(skips))
+        pool.clear(); skips.clear()
+        return out
+    if first is not None:
+        tried.insert(0, round(first[2], 3))
     a, b = pool["a"][ia][:size["a"]], pool["b"][ib][:size["b"]]
     a.zero_(); b.zero_()  # (a probe writes only zeros, but say so explicitly)
     released = len(pool["a"]) + len(pool["b"]) - 2 + len(skips)

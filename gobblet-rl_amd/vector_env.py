@@ -230,11 +230,12 @@ class BatchedGobblet:
 
         placement "auto" (default): when the observation and the mask trajectory are large enough to be HBM streams
         (64 MiB each), the mask array is placed so that the two do not share one of the three 96 GiB classes of the
-        device's memory, in which their writes would not overlap (``placement.py``: a probe kernel; either array is then
-        the head of a hipMalloc block of its own of at least 2 GiB -- a 64 MiB mask array pins 2 GiB for its lifetime --
-        and a few more blocks are held while searching: at most 64 GiB and at most a quarter of what is free, all handed
-        straight back to the driver afterwards, torch's allocator and its cache are not involved; 33 -> 27 us per ply at
-        2^20 boards).  When the device cannot spare the blocks the arrays are plain torch allocations and ``_placement``
+        device's memory, in which their writes would not overlap (``placement.py``: a probe kernel measures the pair as
+        torch's allocator places it; only if that pair shares a class either array becomes the head of a hipMalloc block
+        of its own of at least 2 GiB -- a 64 MiB mask array then pins 2 GiB for its lifetime -- and a few more blocks are
+        held while searching: at most 64 GiB and at most a quarter of what is free, all handed straight back to the driver
+        afterwards, torch's cache is never flushed; the best pair seen wins, so the result is never worse than the
+        allocator's own; 33 -> 27 us per ply at 2^20 boards).  When the device cannot spare the blocks the arrays are plain torch allocations and ``_placement``
         says why.  "spread" insists (raises if the arrays are too small to probe or the memory is not there), "any" takes
         the allocator's addresses as they come.  The search synchronises the device and takes a few milliseconds: make
         the buffers once and reuse them (``collect(out=...)``).  What happened is recorded under ``_placement``.
@@ -279,7 +280,10 @@ class BatchedGobblet:
             geometry = dict(slot_boards=ply_stride, plies=T) if layout == "time" and ply_stride % 128 == 0 else {}
             cells = T * ply_stride if layout == "time" else tiles * T * 64
             try:
-                a, b, placed = _placement.spread_pair(cells * 117, cells * nat.ACTIONS, dev, **geometry)
+                a, b, placed = _placement.spread_pair(
+                    cells * 117, cells * nat.ACTIONS, dev, **geometry,
+                    plain=lambda: (torch.empty(cells * 117, dtype=torch.uint8, device=dev),
+                                   torch.empty(cells * nat.ACTIONS, dtype=torch.uint8, device=dev)))
                 full["observation"] = a.view(torch.int8).view(lead + (3, 3, 13))
                 full["action_mask"] = b.view(torch.int8).view(lead + (nat.ACTIONS,))
             except _placement.PlacementUnavailable as e:

@@ -35,12 +35,32 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def counter_mean(db, kernel, counter, skip=1):
-    q = ("select dispatch_id, sum(value) from counters_collection where kernel_name like ? and counter_name = ? "
-         "group by dispatch_id order by dispatch_id")
-    v = [r[1] for r in sqlite3.connect(db).execute(q, (f"%{kernel}%", counter))]
-    v = v[skip:] if len(v) > skip else v  # (the first dispatch of a process includes one-off effects)
-    return sum(v) / len(v), len(v)
+def reduced(run):
+    """rows of gpurun_out/final/RUN.counters.csv (scripts/profile_reduce.py): [(kernel, counter, dispatches, mean, mean w/o first)]"""
+    import csv
+    path = os.path.join(SRC, run + ".counters.csv")
+    if not os.path.exists(path):
+        return []
+    return [(r["kernel"], r["counter"], int(r["dispatches"]), float(r["mean_value"]), float(r["mean_without_first_dispatch"]))
+            for r in csv.DictReader(open(path))]
+
+
+def counter_mean(run, kernel, counter):
+    """mean per dispatch of `counter` over the dispatches of the kernel whose name contains `kernel`, first dispatch of the
+    process left out (one-off effects); (value, dispatches counted)"""
+    for k, c, n, _, rest in reduced(run):
+        if kernel in k and c == counter:
+            return rest, max(1, n - 1)
+    raise KeyError((run, kernel, counter))
+
+
+def counters_table(kernel, runs):
+    out = "counter,dispatches,mean_value\n"
+    for run in runs:
+        for k, c, n, mean, _ in sorted(reduced(run), key=lambda r: r[1]):
+            if kernel in k:
+                out += f"{c},{n},{mean:.1f}\n"
+    return out
 
 
 def main():
@@ -56,13 +76,13 @@ def main():
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
     for run in ("collect", "single", "step", "greedy", "policy", "driver"):
-        if os.path.exists(os.path.join(SRC, f"{run}_stats", "p_results.db")):
-            open(os.path.join(dst, f"{run}_kernel_stats.csv"), "w").write(
-                capture(rocpd_summary.stats, os.path.join(SRC, f"{run}_stats", "p_results.db")))
-    open(os.path.join(dst, "kernel_durations_by_size.csv"), "w").write(
-        "# scripts/sweep_sizes.py under rocprofv3 --kernel-trace: k_rollout = one ply per launch, k_collect = 32 plies per launch\n"
-        + capture(rocpd_summary.bygrid, "k_rollout", os.path.join(SRC, "sweep_trace", "p_results.db"), 64)
-        + capture(rocpd_summary.bygrid, "k_collect", os.path.join(SRC, "sweep_trace", "p_results.db"), 1))
+        src = os.path.join(SRC, f"{run}_stats.kernel_stats.csv")
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(dst, f"{run}_kernel_stats.csv"))
+    if os.path.exists(os.path.join(SRC, "sweep_trace.by_grid.csv")):
+        open(os.path.join(dst, "kernel_durations_by_size.csv"), "w").write(
+            "# scripts/sweep_sizes.py under rocprofv3 --kernel-trace: k_rollout = one ply per launch, k_collect = 32 plies per launch\n"
+            + open(os.path.join(SRC, "sweep_trace.by_grid.csv")).read())
     # ---- HBM traffic per launch ---------------------------------------------------------------------------------
     traffic = {}
     rows = ["kernel,counter,dispatches,mean_value_KB"]
@@ -83,11 +103,11 @@ def main():
             "fused_noobs_1048576": ("fused-noobs:1048576", "k_rollout<true, false"),
             "step_1048576": ("step:1048576", "k_step<true, true")}
     for run, (key, kernel) in runs.items():
-        if not os.path.exists(os.path.join(SRC, f"pmc_{run}_FETCH_SIZE", "p_results.db")):
+        if not os.path.exists(os.path.join(SRC, f"pmc_{run}_FETCH_SIZE.counters.csv")):
             continue
         kb = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            kb[c], n = counter_mean(os.path.join(SRC, f"pmc_{run}_{c}", "p_results.db"), kernel, c)
+            kb[c], n = counter_mean(f"pmc_{run}_{c}", kernel, c)
             rows.append(f"{kernel.replace(',', ';')} [{key}],{c},{n},{kb[c]:.3f}")
         traffic[key] = {
             # gfx950 reports half of wide coalesced reads (MI355X_MICROARCH.md): FETCH_SIZE is doubled
@@ -105,15 +125,16 @@ def main():
                             ("greedy", "k_greedy", "gbl_greedy depth 2, 65536 boards"),
                             ("policy", "k_collect_policy", "gbl_collect_policy greedy vs greedy, 16 plies per launch, 65536 boards")):
         sq = f"# {what}; rocprofv3 --pmc (two passes), summed over instances, mean per dispatch\n"
-        sq += capture(rocpd_summary.counters, kernel, [os.path.join(SRC, f"{m}_sq1", "p_results.db"),
-                                                       os.path.join(SRC, f"{m}_sq2", "p_results.db")])
+        if not reduced(f"{m}_sq1"):
+            continue
+        sq += counters_table(kernel, [f"{m}_sq1", f"{m}_sq2"])
         open(os.path.join(dst, f"sq_counters_{m}.csv"), "w").write(sq)
         if m == "greedy":
-            insts, _ = counter_mean(os.path.join(SRC, "greedy_sq1", "p_results.db"), "k_greedy", "SQ_INSTS_VALU")
+            insts, _ = counter_mean("greedy_sq1", "k_greedy", "SQ_INSTS_VALU")
             traffic["greedy:65536"] = {"SQ_INSTS_VALU": insts, "kernel_source_hash": khash,
                                        "source": f"profiles/{rnd}/sq_counters_greedy.csv"}
         if m == "policy":
-            insts, _ = counter_mean(os.path.join(SRC, "policy_sq1", "p_results.db"), "k_collect_policy", "SQ_INSTS_VALU")
+            insts, _ = counter_mean("policy_sq1", "k_collect_policy", "SQ_INSTS_VALU")
             traffic["policy-collect:65536:T16"] = {"SQ_INSTS_VALU": insts, "kernel_source_hash": khash,
                                                    "source": f"profiles/{rnd}/sq_counters_policy.csv"}
         print(sq)

@@ -2,14 +2,18 @@
 # Everything the numbers in README.md / DESIGN.md / profiles/ come from, in one GPU call:
 #   gpurun -- 'scripts/profile_round.sh'      then      python scripts/profile_collect.py r02
 # Writes bench lines and rocprofv3 databases under gpurun_out/final/.
+#   (two calls when one does not fit gpurun's time limit:  scripts/profile_round.sh a   then   scripts/profile_round.sh b)
 set -e -o pipefail
 export TMPDIR=/tmp
+STAGE=${1:-all}
 O=gpurun_out/final
-rm -rf $O && mkdir -p $O
-python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1   # (no compiler may run under the profiler's preload)
+[ "$STAGE" = b ] || rm -rf $O
+mkdir -p $O
+python -c "import __graft_entry__ as g; g.build()" > $O/build_$STAGE.log 2>&1   # (no compiler may run under the profiler's preload)
 for m in valu_rates winner_lanes write_classes wave_placement; do   # the microbenchmarks this script runs
-  [ scripts/microbench/$m -nt scripts/microbench/$m.hip ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scripts/microbench/$m scripts/microbench/$m.hip >> $O/build.log 2>&1
+  [ scripts/microbench/$m -nt scripts/microbench/$m.hip ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scripts/microbench/$m scripts/microbench/$m.hip >> $O/build_$STAGE.log 2>&1
 done
+if [ "$STAGE" != b ]; then
 # ---- bench lines --------------------------------------------------------------------------------------------
 python bench.py > $O/bench_default.json
 python bench.py --gpus 1 --steps 20 --warmup 5 --no-configs --no-cpu-baseline > $O/bench_driver_cmd.json
@@ -54,6 +58,8 @@ rocprofv3 --kernel-trace --stats -d $O/greedy_stats -o p -- python3 scripts/run_
 rocprofv3 --kernel-trace --stats -d $O/policy_stats -o p -- python3 scripts/run_eager.py policy 65536 8 16 > $O/policy_stats.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/driver_stats -o p -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-configs --no-cpu-baseline > $O/driver_stats.log 2>&1
 echo "kernel traces done"
+fi
+if [ "$STAGE" != a ]; then
 # ---- HBM traffic (separate --pmc passes; eager launches so that counters are attributed per dispatch) ----------
 # one line per bench.py record: "run-name mode boards launches plies-per-launch" (profile_collect.py maps them to the keys of
 # profiles/pmc_traffic.json: the headline at 8 plies per launch and at the driver's single 20-ply launch, the C2 / C3 / C4-shard /
@@ -96,4 +102,6 @@ rocprofv3 --pmc $SQ2 -d $O/greedy_sq2 -o p -- python3 scripts/run_eager.py greed
 rocprofv3 --pmc $SQ1 -d $O/policy_sq1 -o p -- python3 scripts/run_eager.py policy 65536 6 16 > $O/policy_sq1.log 2>&1
 rocprofv3 --pmc $SQ2 -d $O/policy_sq2 -o p -- python3 scripts/run_eager.py policy 65536 6 16 > $O/policy_sq2.log 2>&1
 echo "counters done"
+fi
+python scripts/profile_reduce.py   # (databases -> small summaries: gpurun copies at most 64 MiB back)
 ls $O

@@ -357,3 +357,18 @@ def test_placement_search_logic(monkeypatch):
     with pytest.raises(placement.PlacementUnavailable):
         run([0.8], refuse_after=1)
     assert made == [2 << 30]
+    # the pair as the caller's allocator places it is probed first and stays in the race
+    plain_made = []
+
+    def plain():
+        plain_made.append(1)
+        return torch.full((1000,), 77, dtype=torch.uint8), torch.full((500,), 78, dtype=torch.uint8)
+
+    seen, info = run([0.80], plain=plain)                 # clean as it is: no block at all
+    assert seen == [(77, 78, 0, 0)] and made == [] and info["ended"] == "the allocator's own placement is clean" and info["spread"]
+    seen, info = run([1.0, 1.0, 0.81], plain=plain)       # not clean: the block search runs and wins
+    assert [s[:2] for s in seen] == [(77, 78), (1, 2), (1, 4)] and info["ratio"] == 0.81 and info["probes"] == [1.0, 1.0, 0.81]
+    seen, info = run([0.90] + [0.89] * 40, plain=plain)   # nothing clearly better turns up: the caller's own pair is kept
+    assert info["ratio"] == 0.9 and "was not beaten" in info["ended"] and info["block_gib"] == [0.0, 0.0]
+    seen, info = run([1.0], plain=plain, free=7 * GIB)    # no memory for blocks: no search, the plain pair, the reason recorded
+    assert made == [] and info["ended"].startswith("no block search") and info["ratio"] == 1.0

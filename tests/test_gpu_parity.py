@@ -676,7 +676,9 @@ def test_example_scripts_run(G):
             ["examples/example_batched.py", "--boards", "4096", "--plies", "12", "--policy", "greedy"],
             ["examples/example_batched.py", "--boards", "65536", "--plies", "40", "--policy", "random", "--graph", "8"],
             ["examples/example_batched.py", "--boards", "4096", "--plies", "12", "--policy", "greedy", "--graph", "4"],
-            ["examples/example_batched.py", "--boards", "65536", "--plies", "48", "--policy", "random", "--collect", "16"]]
+            ["examples/example_batched.py", "--boards", "65536", "--plies", "48", "--policy", "random", "--collect", "16"],
+            ["examples/example_batched.py", "--boards", "16384", "--plies", "32", "--policy", "greedy", "--opponent", "random",
+             "--collect", "16"]]
     for cmd in runs:
         r = subprocess.run([sys.executable] + cmd, cwd=root, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -1127,7 +1129,7 @@ def test_placement_on_a_nearly_full_device(G):
     e1 = G.BatchedGobblet(n, DEV, **kw)
     tr = e1.trajectory_buffers(T)
     info = tr["_placement"]
-    assert "probes" in info and info["cap_gib"] <= 30 / placement.FREE_FRACTION + 0.5 and info["held_gib"] <= info["cap_gib"]
+    assert "probes" in info and info["cap_gib"] <= 30 / placement.FREE_FRACTION + 0.5 and info["held_gib"] <= max(info["cap_gib"], 4.0)
     assert torch.cuda.memory_reserved() >= reserved0 + hog.numel()      # torch's cache was not flushed
     free1, _ = torch.cuda.mem_get_info()
     assert free1 >= 30 * GIB - 5 * GIB                                   # the rejected blocks and gaps went back to the driver
@@ -1138,10 +1140,9 @@ def test_placement_on_a_nearly_full_device(G):
     free2, _ = torch.cuda.mem_get_info()
     hog2 = torch.empty(max(free2 - 6 * GIB, 1), dtype=torch.uint8, device=DEV)   # ~6 GiB left: < 2 + 2 + 4 GiB reserve
     e2 = G.BatchedGobblet(n, DEV, **kw)
-    tr = e2.trajectory_buffers(T)
-    assert tr["_placement"]["spread"] is False and "fell back to plain allocations" in tr["_placement"]["why"]
-    with pytest.raises(placement.PlacementUnavailable):
-        e2.trajectory_buffers(T, placement="spread")
+    tr = e2.trajectory_buffers(T)   # no room for blocks: the pair as torch places it, probed, the reason recorded
+    assert tr["_placement"]["block_gib"] == [0.0, 0.0] and len(tr["_placement"]["probes"]) == 1
+    assert tr["_placement"]["ended"].startswith(("no block search", "the allocator's own placement is clean"))
     e2.collect(T, out=tr)
     for key in ("actions", "winner", "action_mask", "observation"):
         assert torch.equal(tr[key], plain[key]), key
