@@ -59,7 +59,7 @@ TOTAL_BOARDS = 1 << 20
 # the kernel instantiation each one times with the oracle, at the same batch size and through the same entry point.
 CONFIG_RECORDS = {
     "c2_4096": (4096, 256, False, "collect"), "c3_262144": (262144, 128, False, "collect"),
-    "c4_shard_131072": (131072, 256, False, "collect"), "large_4194304": (1 << 22, 32, False, "collect"),
+    "c4_shard_131072": (131072, 256, False, "collect"), "large_4194304": (1 << 22, 64, False, "collect"),
     "maskonly_1048576": (1 << 20, 64, True, "collect"),
     # round 1's pipeline, one launch per ply (gbl_rollout, 234 algorithmic bytes per env-step)
     "single_ply_1048576": (1 << 20, 200, False, "fused"), "single_ply_262144": (262144, 200, False, "fused"),

@@ -5,7 +5,7 @@ instantiation each one reaches.  Bit-exact (integer / byte work).
 
     bench record                  entry point (as bench.py calls it)        kernel instantiation
     ----------------------------  ----------------------------------------  -------------------------------------------
-    headline (2^20, collect)      gbl_collect, ply index on the device      k_collect<mask, obs, DEV_PLY, NT>
+    headline (2^20, collect)      gbl_collect, ply index on the device      k_collect<mask, obs, DEV_PLY, NT>, 8 and 20 plies per launch
     c2_4096                       gbl_collect                               k_collect2<mask, obs, DEV_PLY>  (<= 2048 tiles)
     c3_262144                     gbl_collect                               k_collect<mask, obs, DEV_PLY, NT>
     c4_shard_131072               gbl_collect                               k_collect2<mask, obs, DEV_PLY>  (2048 tiles)
@@ -87,6 +87,7 @@ def check_trajectory(env, tr, T, ply0, s, tm, dn, illegal, with_obs=True, with_m
 # bench record -> (boards, plies per launch as bench.py's auto_traj picks them (cut where the oracle needs the time), obs)
 COLLECT_RECORDS = {
     "headline_1048576": (1 << 20, 8, True),
+    "headline_driver_cmd_1048576": (1 << 20, 20, True),   # `--steps 20`: the whole timed run is ONE launch of 20 plies
     "c2_4096": (4096, 32, True),
     "c3_262144": (262144, 16, True),
     "c4_shard_131072": (131072, 32, True),
