@@ -614,6 +614,7 @@ def main():
     else:
         p.eager(K, ev)
     torch.cuda.synchronize(dev)
+    local_elapsed = time.perf_counter() - t0  # this rank's K plies done (the trailing barrier's own latency not yet in)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -648,12 +649,13 @@ def main():
         # cap, spread flag; -1 = no search) -- one small all-gather of numbers, after the timed region
         pl = mine_pl or {}
         mine = torch.tensor([mean_kernel_s * 1e6, pl.get("ratio", -1.0), len(pl.get("probes", ())), pl.get("held_gib", -1.0),
-                             pl.get("cap_gib", -1.0), 1.0 if pl.get("spread") else 0.0],
+                             pl.get("cap_gib", -1.0), 1.0 if pl.get("spread") else 0.0, local_elapsed * 1e6],
                             dtype=torch.float64, device="cpu" if cpu else dev)
         allk = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allk, mine)
         rows = [[float(v) for v in x.tolist()] for x in allk]
         per_rank_us = [r[0] for r in rows]
+        local_elapsed = max(r[6] for r in rows) / 1e6
         per_rank_placement = [{"ratio": r[1], "probes": int(r[2]), "held_gib": r[3], "cap_gib": r[4], "spread": bool(r[5])}
                               if r[1] >= 0 else None for r in rows]
         per_rank_placement[0] = mine_pl if rank == 0 else per_rank_placement[0]
@@ -686,6 +688,10 @@ def main():
                        "launch": ("hipGraph replay of the K plies' launches (device-resident ply index; one untimed warm "
                                   "replay of the same graph = K more untimed plies before the timed one)") if graph is not None else "eager",
                        "kernel_us_per_rank": per_rank_us, "kernel_us_max": max(per_rank_us),
+                       # MAX over ranks of (barrier, sync, K plies, sync) -- i.e. `ms_per_step` without the trailing barrier's
+                       # own latency, which at N > 1 is an RCCL collective of tens of microseconds on a timed region that
+                       # is 72 us of kernel time at 8 GPUs x 20 plies; `value` / `ms_per_step` keep it in, as the contract says
+                       "ms_per_step_before_trailing_barrier": local_elapsed / K * 1e3,
                        # ranks that took part in the barriers / reductions, and the backend that carried them
                        "rccl_ranks": world if (dist is not None and args.dist_backend == "nccl") else 0,
                        "dist_backend": (args.dist_backend if dist is not None else None),
