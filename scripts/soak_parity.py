@@ -78,6 +78,36 @@ while time.time() < t_end:
             if with_obs:
                 assert np.array_equal(pick("observation").cpu().numpy(), oo["obs"])
         assert np.array_equal(env.squares.cpu().numpy(), s)
+    # a trajectory with device-side policies (gbl_collect_policy): random sides, depths, opening plies, histories
+    if n <= 70000:
+        pol = tuple(int(x) for x in master.integers(0, 4, 2))
+        opening = int(master.choice([0, 0, 1, 2]))
+        T = int(master.integers(1, 7))
+        penv = G.BatchedGobblet(n, DEV, illegal_mode=illegal, auto_reset=True, with_observation=with_obs, seed=seed, env_base=base,
+                                track_turn=True)
+        penv.board.squares = t(s); penv.to_move.copy_(t(tm)); penv.done.zero_()
+        turn = master.integers(0, 4, n).astype(np.int32)
+        penv.turn.copy_(t(turn)); penv.refresh()
+        hist = master.integers(-1, 54, (n, 2, 3)).astype(np.int8)
+        penv.reset_policy_history(); penv.policy_hist.copy_(t(hist))
+        penv.ply = 5000
+        ps, ptm, pdn = s.copy(), tm.copy(), np.zeros(n, np.int8)
+        lay = str(master.choice(["time", "tile"]))
+        buf = penv.trajectory_buffers(T, layout=lay, placement="any", policy_outputs=True, candidates=True)
+        penv.collect(T, out=buf, policies=pol, opening_plies=opening, refresh=False)
+        torch.cuda.synchronize()
+        for tt in range(T):
+            oo = oracle.batch_policy_ply(ps, ptm, pdn, hist, turn, seed, base, 5000 + tt, pol, opening,
+                                         illegal_mode=0 if illegal == "noop" else 1, threads=8, want_obs=with_obs)
+            pick = (lambda k: buf[k][tt]) if lay == "time" else (lambda k: buf[k][:, tt].reshape((-1,) + tuple(buf[k].shape[3:]))[:n])
+            for key, exp in (("actions", oo["actions"]), ("how", oo["how"]), ("chosen", oo["chosen"]), ("candidates", oo["cands"]),
+                             ("winner", oo["winner"]), ("done", pdn), ("to_move", ptm), ("action_mask", oo["mask"])):
+                assert np.array_equal(pick(key).cpu().numpy(), exp), (key, tt, pol, opening)
+            if with_obs:
+                assert np.array_equal(pick("observation").cpu().numpy(), oo["obs"])
+        assert np.array_equal(penv.squares.cpu().numpy(), ps) and np.array_equal(penv.policy_hist.cpu().numpy(), hist)
+        assert np.array_equal(penv.turn.cpu().numpy(), turn)
+        del penv, buf
     ev = G.BatchedBoard(n, DEV, squares=t(s)).evaluate()
     assert np.array_equal(ev["winner"].cpu().numpy(), oracle.batch_winner(s)) and np.array_equal(ev["flat"].cpu().numpy(), oracle.batch_flatboard(s))
     assert np.array_equal(ev["mask1"].cpu().numpy(), oracle.batch_legal_mask(s, np.ones(n, np.int8)))
