@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import gobblet_rl_amd as G  # noqa: E402
 
 boards = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+nt = int(sys.argv[2]) if len(sys.argv) > 2 else (4 if 32768 < boards <= 131072 else 1)  # tiles per workgroup of the shape in use
 nat, L = G._native, G._native.lib()
 env = G.BatchedGobblet(boards, "cuda:0", auto_reset=True, seed=0)
 env.rollout(64)
@@ -23,10 +24,12 @@ for _ in range(3):
     nat.check(L.gbl_greedy(env.squares.data_ptr(), env.to_move.data_ptr(), None, None, 2, act.data_ptr(), cm.data_ptr(),
                            fb.data_ptr(), boards, None))
 torch.cuda.synchronize()
-ntiles = min(boards // 64, 1 << 17)
+ntiles = min(boards // 64, 1 << 17)  # (stamps are indexed by the TILE of the flushing thread: blocks of NT tiles leave gaps)
 buf = np.zeros((ntiles, 12), np.uint64)
 L.gbl_debug_stamps.argtypes = [C.c_void_p, C.c_int64]
 assert L.gbl_debug_stamps(buf.ctypes.data, ntiles) == 0
+buf = buf[::nt]  # (a block's stamps are flushed by its first owner, under its tile's index)
+ntiles = len(buf)
 t = buf[:, :6].astype(np.int64)
 d = np.diff(t, axis=1)
 names = ["owner: loads, planes, depth-1 walk, pair lists", "pooled cheap evaluations (4 waves)", "deferred exact evaluations",
