@@ -881,11 +881,11 @@ __device__ __forceinline__ void pool_fence()
 // ---- the greedy decision of a BLOCK of NT tiles (64 NT boards) by a workgroup of W wavefronts -----------------------------
 // Wavefronts 0 .. NT-1 each OWN a tile (lane = board: loads, depth-1 walk, replay, outputs); wavefronts NT .. 2 NT - 1 look at
 // the same tiles from the opponent's side while the owners walk depth 1; ALL W wavefronts lay out and evaluate the block's
-// depth-2 work, whoever owns it.  Shapes: <1, 8> a lone tile spread over eight wavefronts (small batches: the shortest
-// serial chain), <1, 4> the same over four (large batches: most wavefronts per CU), <4, 8>: as many owners as helpers --
-// every wavefront of the workgroup has work in every phase (with one owner among four wavefronts, three quarters of a CU's
-// wavefronts idle through the owner phases: the tiles of a CU run in step) -- for batches of one generation of tiles,
-// <1, 1>: depth 1 only, no shared phase, no barrier.
+// depth-2 work, whoever owns it (wavefronts beyond 2 NT do nothing else).  Shapes: <1, 16> / <1, 8> a lone tile spread over
+// many wavefronts (small batches: the shortest serial chain), <1, 4> the same over four (large batches: the smallest
+// workgroups), <2, 8> / <4, 8> / <4, 16>: blocks of tiles -- as many owners as helpers, so that fewer of a CU's wavefronts
+// idle through the owners' phases (the tiles of a CU run in step) -- for batches of one generation of tiles; <1, 1>: depth 1
+// only, no shared phase, no barrier.  greedy_shape() / policy_shape() hold the measurements behind the choice.
 template <int NT, int W>
 struct GreedyLds {
     static_assert(W == 1 || W >= 2 * NT, "a helper wavefront per owner");
@@ -1012,13 +1012,13 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
     GBL_TILE_STAMP(ts, 0);
     if (deep) {
         pool_fence<W>();
-        // (D) the work lists: wavefront w takes a stretch of the NT x 54 (tile, candidate) steps -- inside ONE tile -- and
-        // the last NT wavefronts a tile's NT x 6 (tile, rank) steps each
-        constexpr int kSteps = (NT * kActions + W - 1) / W;
-        static_assert(kActions % kSteps == 0 || NT == 1, "a wavefront's steps stay inside one tile");
+        // (D) the work lists: W / NT wavefronts share a tile's 54 candidate steps, and the last NT wavefronts take a tile's 6
+        // rank steps each
+        constexpr int kWavesPerTile = W / NT, kSteps = (kActions + kWavesPerTile - 1) / kWavesPerTile;
+        static_assert(W % NT == 0, "the same number of wavefronts lists every tile");
         {
-            const int first = wave * kSteps, g = first / kActions, c0 = first - g * kActions;
-            if (first < NT * kActions) {
+            const int g = wave / kWavesPerTile, c0 = (wave % kWavesPerTile) * kSteps;  // (a wavefront's steps stay inside one tile)
+            if (c0 < kActions) {
                 const unsigned long long wk = S.work[g * kTile + lane] >> c0;
                 list_append<kSteps>(S.pair, &S.npairs, ((uint32_t)(g * kTile + lane) << 8) + (uint32_t)c0, lane,
                                     [&](int j) { return c0 + j < kActions && ((wk >> j) & 1ull); });
@@ -1268,7 +1268,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
         // (one tile per workgroup: behind a call, see greedy_tile_call -- 12.6 -> 11.6 us per ply at 16 384 boards, 79 -> 71 at
         // 262 144; blocks of tiles run at two wavefronts per SIMD anyway and have the registers: inlined, 19.1 -> 18.8 at 65 536)
         GreedyResult g;
-        if constexpr (NT == 1 && W > 1)
+        if constexpr ((NT == 1 && W > 1) || W >= 16)
             g = greedy_tile_call<NT, W>(S, p, mover, gre ? legal : 0ull, pol, deep, prev3);
         else
             g = greedy_tile<NT, W>(S, p, mover, gre ? legal : 0ull, pol, deep, prev3, ts);
@@ -1359,6 +1359,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
 }
 
 int greedy_shape(int depth, int64_t n);  // (defined with the greedy entry points below)
+int policy_shape(int depth, int64_t n);
 
 }  // namespace
 
@@ -1795,7 +1796,7 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
         return fail(GBL_ERR_ALIGN, "counters must be 128-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int depth = policy0 > policy1 ? policy0 : policy1;
-    const int shape = greedy_shape(depth, n);
+    const int shape = policy_shape(depth, n);
 #define GBL_CP(NT, W)                                                                                                      \
     do {                                                                                                                   \
         const Geometry g = block_geometry(n, NT);                                                                          \
@@ -1804,7 +1805,10 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
                            reward_traj, done_traj, to_move_traj, mask_traj, obs_traj, chosen_traj, how_traj, cand_traj,    \
                            hist, policy0, policy1, opening_plies, illegal_mode, counters, turn);                           \
     } while (0)
-    if (shape == 48) GBL_CP(4, 8);
+    if (shape == 56) GBL_CP(4, 16);
+    else if (shape == 48) GBL_CP(4, 8);
+    else if (shape == 28) GBL_CP(2, 8);
+    else if (shape == 26) GBL_CP(1, 16);
     else if (shape == 18) GBL_CP(1, 8);
     else if (shape == 14) GBL_CP(1, 4);
     else GBL_CP(1, 1);
@@ -1898,21 +1902,44 @@ int gbl_validate(const int8_t *state, int8_t *flags, int64_t n, void *stream)
 }
 
 namespace {
-// The shape of the greedy kernels' workgroups (see GreedyLds): 10 * (tiles per workgroup) + wavefronts.
+// The shape of the greedy kernels' workgroups (see GreedyLds), as a code: 11 = <1,1>, 14 = <1,4>, 18 = <1,8>, 26 = <1,16>,
+// 28 = <2,8>, 48 = <4,8>, 56 = <4,16>.
 // Round 1 (one tile per workgroup; scripts/bench_greedy.py, 65 536 / 262 144 / 2^20 boards): 1 wavefront 49 / 155 / 518 us,
 // 2: 43 / 139 / 487, 4: 41 / 121 / 451, 8: 40 / 136 / 520, 16: 50 / 176 / 679.  Round 2 (scripts/ab_greedy.py, in-process):
 // eight wavefronts shorten a lone tile's serial chain -- 4 096 / 16 384 boards 11.2 / 11.4 -> 10.0 / 10.2 us -- and lose
-// 2-4 % beyond 131 072 boards.  Round 3 (ab_greedy.py / ab_policy_collect.py): blocks of four tiles with four owners and four
-// helpers (48) -- every wavefront busy in every phase, one workgroup per CU -- win where the batch is ONE generation of tiles
-// (65 536 boards: 15.9 -> 15.4 us, gbl_collect_policy 20.6 -> 18.8 us per ply), are level at 131 072 and lose beyond (2^20
-// boards: 182 -> 218 us: a CU then holds 8 wavefronts instead of 20); blocks of two tiles (24) lost everywhere.
+// 2-4 % beyond 131 072 boards.  Round 3 (ab_greedy.py / ab_policy_collect.py): what decides is how many
+// wavefronts a SIMD has to issue from WHILE THE PAIRS ARE EVALUATED (this code needs four to hide its own LDS round trips
+// and dependency chains) against how many sit idle through the owners' phases:
+//   gbl_greedy, us:        4 096   16 384   32 768   65 536   131 072   262 144    2^20
+//     <1,4>                 10.0      -       12.9     15.9      29.5      50.7     180
+//     <1,8>                  9.4     9.5      12.7     19.1      35.0      62.6     228
+//     <1,16>                 8.7     8.7      14.6       -         -         -        -
+//     <2,8>                 11.3    11.3      11.7     16.3      28.9        -        -
+//     <4,8>                 15.1      -       14.9     15.3      28.5      56.4     218
+//     <4,16>                  -       -       13.9     14.5      26.7      51.3     198
+// (<1,16>: one workgroup per CU up to 256 tiles; <4,16>: four owners, four helpers and eight more wavefronts that only
+// evaluate pairs -- 16 wavefronts per CU for ONE generation of tiles; beyond 131 072 boards the tiles are out of step
+// anyway and the smallest workgroups win.)
 int greedy_shape(int depth, int64_t n)
 {
-#ifdef GBL_FORCE_GREEDY_SHAPE  // 14, 18 or 48: A/B builds (scripts/build_variant.sh)
+#ifdef GBL_FORCE_GREEDY_SHAPE  // A/B builds (scripts/build_variant.sh)
     (void)n;
     return depth == 1 ? 11 : GBL_FORCE_GREEDY_SHAPE;
 #else
-    return depth == 1 ? 11 : n <= 32768 ? 18 : n <= 131072 ? 48 : 14;
+    return depth == 1 ? 11 : n <= 16384 ? 26 : n <= 32768 ? 28 : n <= 131072 ? 56 : 14;
+#endif
+}
+
+// ... and of gbl_collect_policy's, whose ply loop keeps more registers live: blocks of tiles only where they stay inlined
+// within the register file (<4,8>: 65 536 boards 18.2 us per ply against 19.6 for <1,4>, 20.5 for <4,16> behind a call;
+// 16 384 boards: <1,16> 11.0, <1,8> 11.5)
+int policy_shape(int depth, int64_t n)
+{
+#ifdef GBL_FORCE_GREEDY_SHAPE
+    (void)n;
+    return depth <= 1 ? 11 : GBL_FORCE_GREEDY_SHAPE;
+#else
+    return depth <= 1 ? 11 : n <= 16384 ? 26 : n <= 32768 ? 18 : n <= 131072 ? 48 : 14;
 #endif
 }
 
@@ -1928,7 +1955,10 @@ void launch_greedy(int shape, int64_t n, hipStream_t stream, const int8_t *state
                            action_out, cand_mask_out, fallback_out, n, g.ntiles, hist_rw, final_out, seed, env_base,   \
                            call, call_dev);                                                                            \
     } while (0)
-    if (shape == 48) GBL_GREEDY(4, 8);
+    if (shape == 56) GBL_GREEDY(4, 16);
+    else if (shape == 48) GBL_GREEDY(4, 8);
+    else if (shape == 28) GBL_GREEDY(2, 8);
+    else if (shape == 26) GBL_GREEDY(1, 16);
     else if (shape == 18) GBL_GREEDY(1, 8);
     else if (shape == 14) GBL_GREEDY(1, 4);
     else GBL_GREEDY(1, 1);
