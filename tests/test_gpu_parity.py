@@ -645,6 +645,28 @@ def test_out_of_bounds_canaries(G, n):
     torch.cuda.synchronize()
     for k, (buf, _) in bufs.items():
         assert intact(buf, sizes[k]), k
+    # the trajectory entry points (gbl_collect, gbl_collect_from, gbl_collect_policy) and gbl_greedy_act: arrays of exactly
+    # the cells the ABI addresses -- (T - 1) * ply_stride + n -- with the smallest legal slot (n rounded up to 16 boards)
+    T, slot = 3, -(-n // 16) * 16
+    cells = (T - 1) * slot + n
+    tsizes = {"act": 4 * cells, "win": cells, "rew": 2 * cells, "dn": cells, "tm": cells, "mask": 54 * cells, "obs": 117 * cells,
+              "chosen": 4 * cells, "how": cells, "cand": 54 * cells, "hist": 6 * n, "fin": 4 * n, "fb": n, "cm": 54 * n}
+    tb = {k: guarded(v) for k, v in tsizes.items()}
+    q = {k: tb[k][1].data_ptr() for k in tb}
+    tb["hist"][1].fill_(255)
+    for first in (None, ptr["act"]):
+        nat.check(L.gbl_collect_from(ptr["state"], ptr["tm"], ptr["dn"], first, q["act"], q["win"], q["rew"], q["dn"], q["tm"], q["mask"],
+                                     q["obs"], n, slot, 64, 7, 0, 11, None, T, 0, None, ptr["turn"], None))
+    for pol in ((2, 2), (1, 0), (0, 3)):
+        nat.check(L.gbl_collect_policy(ptr["state"], ptr["tm"], ptr["dn"], q["hist"], q["act"], q["win"], q["rew"], q["dn"], q["tm"],
+                                       q["mask"], q["obs"], q["chosen"], q["how"], q["cand"], n, slot, 64, 7, 0, 20, None, T, pol[0],
+                                       pol[1], 1, 0, None, ptr["turn"], None))
+    nat.check(L.gbl_greedy_act(ptr["state"], ptr["tm"], None, q["hist"], 2, 7, 0, 3, q["fin"], ptr["act"], q["cm"], q["fb"], n, None))
+    torch.cuda.synchronize()
+    for k, (buf, _) in tb.items():
+        assert intact(buf, tsizes[k]), k
+    for k in ("state", "tm", "dn", "turn", "act"):
+        assert intact(bufs[k][0], sizes[k]), k
 
 
 def test_c_abi_without_python(G, tmp_path):
