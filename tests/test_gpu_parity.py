@@ -646,8 +646,8 @@ def test_out_of_bounds_canaries(G, n):
     for k, (buf, _) in bufs.items():
         assert intact(buf, sizes[k]), k
     # the trajectory entry points (gbl_collect, gbl_collect_from, gbl_collect_policy) and gbl_greedy_act: arrays of exactly
-    # the cells the ABI addresses -- (T - 1) * ply_stride + n -- with the smallest legal slot (n rounded up to 16 boards)
-    T, slot = 3, -(-n // 16) * 16
+    # the cells the ABI addresses -- (T - 1) * ply_stride + n -- with the smallest legal slot (n rounded up to whole tiles)
+    T, slot = 3, -(-n // 64) * 64
     cells = (T - 1) * slot + n
     tsizes = {"act": 4 * cells, "win": cells, "rew": 2 * cells, "dn": cells, "tm": cells, "mask": 54 * cells, "obs": 117 * cells,
               "chosen": 4 * cells, "how": cells, "cand": 54 * cells, "hist": 6 * n, "fin": 4 * n, "fb": n, "cm": 54 * n}
