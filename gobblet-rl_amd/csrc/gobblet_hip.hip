@@ -1805,12 +1805,17 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
                            reward_traj, done_traj, to_move_traj, mask_traj, obs_traj, chosen_traj, how_traj, cand_traj,    \
                            hist, policy0, policy1, opening_plies, illegal_mode, counters, turn);                           \
     } while (0)
-    if (shape == 56) GBL_CP(4, 16);
-    else if (shape == 48) GBL_CP(4, 8);
-    else if (shape == 28) GBL_CP(2, 8);
+    // (the product build instantiates the shapes policy_shape() can return; an A/B build the one it forces as well)
+    if (shape == 48) GBL_CP(4, 8);
     else if (shape == 26) GBL_CP(1, 16);
     else if (shape == 18) GBL_CP(1, 8);
     else if (shape == 14) GBL_CP(1, 4);
+#if defined(GBL_FORCE_GREEDY_SHAPE) && GBL_FORCE_GREEDY_SHAPE == 56
+    else if (shape == 56) GBL_CP(4, 16);
+#endif
+#if defined(GBL_FORCE_GREEDY_SHAPE) && GBL_FORCE_GREEDY_SHAPE == 28
+    else if (shape == 28) GBL_CP(2, 8);
+#endif
     else GBL_CP(1, 1);
 #undef GBL_CP
     GBL_LAUNCHED("gbl_collect_policy");
@@ -1955,12 +1960,17 @@ void launch_greedy(int shape, int64_t n, hipStream_t stream, const int8_t *state
                            action_out, cand_mask_out, fallback_out, n, g.ntiles, hist_rw, final_out, seed, env_base,   \
                            call, call_dev);                                                                            \
     } while (0)
+    // (the product build instantiates the shapes greedy_shape() can return; an A/B build the one it forces as well)
     if (shape == 56) GBL_GREEDY(4, 16);
-    else if (shape == 48) GBL_GREEDY(4, 8);
     else if (shape == 28) GBL_GREEDY(2, 8);
     else if (shape == 26) GBL_GREEDY(1, 16);
-    else if (shape == 18) GBL_GREEDY(1, 8);
     else if (shape == 14) GBL_GREEDY(1, 4);
+#if defined(GBL_FORCE_GREEDY_SHAPE) && GBL_FORCE_GREEDY_SHAPE == 48
+    else if (shape == 48) GBL_GREEDY(4, 8);
+#endif
+#if defined(GBL_FORCE_GREEDY_SHAPE) && GBL_FORCE_GREEDY_SHAPE == 18
+    else if (shape == 18) GBL_GREEDY(1, 8);
+#endif
     else GBL_GREEDY(1, 1);
 #undef GBL_GREEDY
 }
