@@ -8,6 +8,7 @@ struct TileStamps {
 };
 #ifdef GBL_STAMPS
 __device__ unsigned long long g_stamps[1 << 17][12];
+__device__ unsigned long long g_wave_stamps[1024][16][8];  // per block and wavefront: phase stamps inside greedy_tile
 #define GBL_STAMP(i) unsigned long long st_##i = __builtin_amdgcn_s_memtime()
 #define GBL_STAMP_REAL(i) unsigned long long rt_##i = __builtin_amdgcn_s_memrealtime()
 #define GBL_STAMP_DECL(i) unsigned long long st_##i = 0
@@ -20,6 +21,9 @@ __device__ unsigned long long g_stamps[1 << 17][12];
 #define GBL_STAMP_DRAIN(i)                                   \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         \
     unsigned long long st_##i = __builtin_amdgcn_s_memtime()
+#define GBL_WAVE_STAMP(i)                                                                                   \
+    if ((threadIdx.x & 63u) == 0 && blockIdx.x < 1024)                                                      \
+        g_wave_stamps[blockIdx.x][threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime()
 #define GBL_STAMP_FLUSH(tile)                                                                              \
     if (threadIdx.x == 0 && (tile) < (1 << 17)) {                                                          \
         unsigned long long *o_ = g_stamps[tile];                                                           \
@@ -38,9 +42,14 @@ __device__ unsigned long long g_stamps[1 << 17][12];
 #define GBL_TILE_STAMP(ts, i)
 #define GBL_STAMP_DRAIN(i)
 #define GBL_STAMP_FLUSH(tile)
+#define GBL_WAVE_STAMP(i)
 #endif
 
 #ifdef GBL_STAMPS
+extern "C" int gbl_debug_wave_stamps(unsigned long long *host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wave_stamps), sizeof(unsigned long long) * 1024 * 16 * 8);
+}
 extern "C" int gbl_debug_stamps(unsigned long long *host_out, int64_t ntiles)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), (size_t)ntiles * 12 * sizeof(unsigned long long));

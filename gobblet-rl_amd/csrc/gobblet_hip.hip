@@ -916,26 +916,29 @@ struct GreedyLds {
     }
 };
 
-// One ballot per (candidate | rank) and group of 64 boards compacts the boards that have it into a list shared by the whole
-// block -- no per-lane loop, no divergence.  A wavefront counts its steps first, reserves its stretch of the list with ONE
-// atomic, then writes (the ballots are recomputed: two instructions each, against 2 x STEPS live scalar registers).
-template <int STEPS, typename Has>
-__device__ __forceinline__ void list_append(uint16_t *list, int *fill, uint32_t tag, int lane, Has has)
+// Compacts the (board, step) entries of a wavefront's lanes -- lane = board, `bits` = the steps (candidates / ranks) it has
+// -- into a list shared by the whole block.  The lanes' counts are prefix-summed BIT-SLICED: the count of the lanes below is
+// sum_k 2^k * mbcnt(ballot(bit k of the count)), one ballot per bit of the largest possible count, no cross-lane data
+// movement; the wavefront reserves its stretch of the list with ONE atomic, and a lane writes its few entries in a loop (as
+// long as the busiest lane's count: 4-6 of 14 steps).  Round 3's first form -- one ballot + mbcnt + store per STEP, in two
+// passes around the atomic -- cost a wavefront 2 400 cycles (per-wavefront stamps), five barriers' worth.
+template <int STEPS>
+__device__ __forceinline__ void list_append(uint16_t *list, int *fill, uint32_t tag, int lane, uint32_t bits)
 {
-    uint32_t mine = 0;
+    static_assert(STEPS <= 31, "the steps of a lane fit a 32-bit set");
+    constexpr int kBits = STEPS < 2 ? 1 : STEPS < 4 ? 2 : STEPS < 8 ? 3 : STEPS < 16 ? 4 : 5;
+    const uint32_t cnt = (uint32_t)__popc(bits);
+    uint32_t below = 0, total = 0;
 #pragma unroll
-    for (int j = 0; j < STEPS; ++j) mine += (uint32_t)__popcll(__ballot(has(j)));
-    uint32_t base = 0;
-    if (lane == 0 && mine) base = (uint32_t)atomicAdd(fill, (int)mine);
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-#pragma unroll
-    for (int j = 0; j < STEPS; ++j) {
-        const bool h = has(j);
-        const unsigned long long m = __ballot(h);
-        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
-        if (h) list[at] = (uint16_t)(tag + (uint32_t)j);
-        base += (uint32_t)__popcll(m);
+    for (int k = 0; k < kBits; ++k) {
+        const unsigned long long m = __ballot((cnt >> k) & 1u);
+        below += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << k;
+        total += (uint32_t)__popcll(m) << k;
     }
+    uint32_t base = 0;
+    if (lane == 0 && total) base = (uint32_t)atomicAdd(fill, (int)total);
+    uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + below;
+    for (uint32_t rest = bits; rest; rest &= rest - 1u) list[at++] = (uint16_t)(tag + (uint32_t)__builtin_ctz(rest));
 }
 
 // One decision per board of the block, by ALL 64 W threads of the workgroup (every thread calls, the barriers are inside).
@@ -1011,26 +1014,33 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
     }
     GBL_TILE_STAMP(ts, 0);
     if (deep) {
+        GBL_WAVE_STAMP(0);
         pool_fence<W>();
-        // (D) the work lists: W / NT wavefronts share a tile's 54 candidate steps, and the last NT wavefronts take a tile's 6
-        // rank steps each
+        GBL_WAVE_STAMP(1);
+        // (D) the work lists: W / NT wavefronts share a tile's 54 candidate steps, and the owners take their tile's 6 rank
+        // steps on top
         constexpr int kWavesPerTile = W / NT, kSteps = (kActions + kWavesPerTile - 1) / kWavesPerTile;
         static_assert(W % NT == 0, "the same number of wavefronts lists every tile");
         {
             const int g = wave / kWavesPerTile, c0 = (wave % kWavesPerTile) * kSteps;  // (a wavefront's steps stay inside one tile)
             if (c0 < kActions) {
-                const unsigned long long wk = S.work[g * kTile + lane] >> c0;
-                list_append<kSteps>(S.pair, &S.npairs, ((uint32_t)(g * kTile + lane) << 8) + (uint32_t)c0, lane,
-                                    [&](int j) { return c0 + j < kActions && ((wk >> j) & 1ull); });
+                const int steps = kActions - c0 < kSteps ? kActions - c0 : kSteps;
+                const uint32_t wk = (uint32_t)(S.work[g * kTile + lane] >> c0) & ((1u << steps) - 1u);
+                list_append<kSteps>(S.pair, &S.npairs, ((uint32_t)(g * kTile + lane) << 8) + (uint32_t)c0, lane, wk);
             }
         }
-        if (wave >= W - NT) {
-            const int g = W - 1 - wave;
+        GBL_WAVE_STAMP(6);
+        // (blocks of tiles: by the owners -- the oldest wavefronts on their SIMDs win the issue arbitration and are through
+        // first; a lone tile: by its helper, the owner's own path being the longest there)
+        constexpr int kItemWave0 = NT == 1 ? 1 : 0;
+        if (wave >= kItemWave0 && wave < kItemWave0 + NT) {
+            const int g = wave - kItemWave0;
             const uint32_t nr = (uint32_t)__popcll(S.replies[g * kTile + lane]);
-            list_append<kRootItems>(S.item, &S.nitems, (uint32_t)(g * kTile + lane) << 8, lane,
-                                    [&](int j) { return (uint32_t)j < nr; });
+            list_append<kRootItems>(S.item, &S.nitems, (uint32_t)(g * kTile + lane) << 8, lane, (1u << nr) - 1u);
         }
+        GBL_WAVE_STAMP(7);
         pool_fence<W>();
+        GBL_WAVE_STAMP(2);
         // (E) the pairs, from the first wavefront up ...
         const int total = S.npairs;
         auto record = [&](uint32_t o, uint32_t a, uint32_t sum) {
@@ -1048,16 +1058,20 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
             const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
             record(o, a, greedy_reply(q, (int)(S.board[o][3] & 1u), S.legal[o], a));
         }
-        // ... and the items, from the last wavefront down (it has the fewest pairs)
+        GBL_WAVE_STAMP(3);
+        // ... and the items, also from the first wavefront up: the oldest wavefronts of a SIMD are through their pairs
+        // thousands of cycles before the youngest (issue arbitration is oldest first), the items fit into that slack
         const int nitems = S.nitems;
-        for (int g = (W - 1 - wave) * kTile + lane; g < nitems; g += kTile * W) {
+        for (int g = ((wave + W - kItemWave0) % W) * kTile + lane; g < nitems; g += kTile * W) {
             const uint32_t it = S.item[g], o = it >> 8, j = it & 0xFFu;
             const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
             const uint32_t a2 = kth_bit64(S.replies[o], j);
             S.undef[o][j] = greedy_undefused(q, (int)(S.board[o][3] & 1u), a2);
         }
         GBL_TILE_STAMP(ts, 1);
+        GBL_WAVE_STAMP(4);
         pool_fence<W>();
+        GBL_WAVE_STAMP(5);
     }
     GBL_TILE_STAMP(ts, 2);
     if (!owner) return GreedyResult{-1, 0ull, false};

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Diagnostic (-DGBL_STAMPS build): per WAVEFRONT of a greedy workgroup, when does it pass the phases of greedy_tile?
+Stamps (shader cycles after the block's first): 0 at barrier C, 1 past it, 2 past barrier D (lists built), 3 pairs done,
+4 items done, 5 past barrier E.  Means over the blocks of one launch, one row per wavefront index."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import gobblet_rl_amd as G  # noqa: E402
+
+boards = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+nat, L = G._native, G._native.lib()
+env = G.BatchedGobblet(boards, "cuda:0", auto_reset=True, seed=0)
+env.rollout(64)
+act = torch.empty(boards, dtype=torch.int32, device="cuda:0")
+cm = torch.empty((boards, 54), dtype=torch.int8, device="cuda:0")
+fb = torch.empty(boards, dtype=torch.int8, device="cuda:0")
+for _ in range(3):
+    nat.check(L.gbl_greedy(env.squares.data_ptr(), env.to_move.data_ptr(), None, None, 2, act.data_ptr(), cm.data_ptr(),
+                           fb.data_ptr(), boards, None))
+torch.cuda.synchronize()
+buf = np.zeros((1024, 16, 8), np.uint64)
+L.gbl_debug_wave_stamps.argtypes = [C.c_void_p]
+assert L.gbl_debug_wave_stamps(buf.ctypes.data) == 0
+t = buf.astype(np.int64)
+used = t[:, 0, 0] > 0
+t = t[used]
+waves = int((t[0, :, 0] > 0).sum())
+base = t[:, :waves, 0].min(axis=1)[:, None, None]
+rel = t[:, :waves, :8] - base
+print(f"boards {boards}: {len(t)} blocks of {waves} wavefronts; mean shader cycles after the block's first wavefront reaches barrier C")
+print("wave   at C   past C   past D(lists)  pairs done  items done  past E   | pairs phase  items  wait at E")
+for w in range(waves):
+    m = rel[:, w].mean(axis=0)
+    print(f"{w:4d} {m[0]:7.0f} {m[1]:7.0f} {m[2]:10.0f} {m[3]:12.0f} {m[4]:11.0f} {m[5]:8.0f}   | {m[3]-m[2]:9.0f} {m[4]-m[3]:7.0f} {m[5]-m[4]:9.0f}"
+          f"   | pair list built at {m[6]:6.0f}, item list at {m[7]:6.0f}")
