@@ -148,3 +148,13 @@ def greedy_stats():
     square, held placements evaluated after all) since the library was loaded."""
     o = np.zeros(5, np.int64)
     lib().emu_greedy_stats(_p(o)); return tuple(int(x) for x in o)
+
+
+def greedy_vroot_rule(state, to_move, mask=None, cap=6):
+    """The virtual-root rule for moves of placed pieces (tests/emu/greedy_root_rule.h) against the exact evaluation:
+    (boards, pairs evaluated today, of them moves of placed pieces, virtual roots used, candidates settled, candidates left,
+    items dealt out, MISMATCHES)."""
+    o = np.zeros(8, np.int64)
+    lib().emu_greedy_vroot_rule(_p(np.ascontiguousarray(state)), _p(np.ascontiguousarray(to_move)),
+                                _p(np.ascontiguousarray(mask)) if mask is not None else None, len(state), int(cap), _p(o))
+    return tuple(int(x) for x in o)

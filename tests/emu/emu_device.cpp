@@ -402,6 +402,62 @@ void emu_greedy_root_rule(const int8_t *state, const int8_t *to_move, const int8
     }
 }
 
+// The virtual-root rule (greedy_root_rule.h) against the exact evaluation, on every move of a placed piece it would settle.
+// out: boards, pairs the kernel evaluates today, of them moves of placed pieces, virtual roots used (pieces with a settled
+// candidate; at most `cap` per board, largest piece first), candidates they settle, candidates left to the evaluation, items
+// they deal out, MISMATCHES (must be 0)
+void emu_greedy_vroot_rule(const int8_t *state, const int8_t *to_move, const int8_t *mask_in, int64_t n, int cap, int64_t *out)
+{
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    for (int64_t b = 0; b < n; ++b) {
+        uint32_t r[7] = {0, 0, 0, 0, 0, 0, 0};
+        memcpy(r, state + b * kCells, kCells);
+        const Planes p = make_planes(r);
+        const int me = to_move[b] != 0;
+        uint64_t mask = legal54(p, me);
+        if (mask_in) {
+            mask = 0;
+            for (int a = 0; a < kActions; ++a) mask |= (uint64_t)(mask_in[b * kActions + a] != 0) << a;
+        }
+        const GreedyHead h = greedy_head(p, me, mask, 2);
+        const GreedyRootPlan plan = greedy_root_plan(h, p, me, greedy_root(p, me));
+        const uint64_t placed_moves = plan.eval & ~greedy_from_hand(p, me);
+        out[0]++;
+        out[1] += __builtin_popcountll(plan.eval);
+        out[2] += __builtin_popcountll(placed_moves);
+        int used = 0;
+        for (int pi = 5; pi >= 0; --pi) {
+            const uint32_t cand = (uint32_t)(placed_moves >> (9 * pi)) & 0x1FFu;
+            if (!cand) continue;
+            const Planes v = greedy_lifted(p, me, (uint32_t)pi);
+            const GreedyRoot g = greedy_root(v, me);
+            const int nr = __builtin_popcountll(g.replies);
+            const uint32_t settled = cand & ~g.risky;
+            if (used >= cap || nr > kRootItems || !settled) {
+                out[5] += __builtin_popcount(cand);
+                continue;
+            }
+            ++used;
+            out[3]++;
+            out[4] += __builtin_popcount(settled);
+            out[5] += __builtin_popcount(cand & g.risky);
+            out[6] += nr;
+            uint64_t und[kRootItems] = {0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < nr; ++j) und[j] = greedy_undefused(v, me, kth_bit64(g.replies, (uint32_t)j));
+            const GreedyHandSets hs = greedy_hand_merge(g.replies, h.legal_me, und);
+            for (uint32_t it = settled; it; it &= it - 1) {
+                const uint32_t a = 9u * (uint32_t)pi + (uint32_t)__builtin_ctz(it);
+                const uint32_t want = greedy_reply(p, me, h.legal_me, a);
+                const uint32_t got = nr ? greedy_hand_lookup(g.replies, h.legal_me, und, a) : 0u;
+                const bool fl = (want & 1u) && ((h.legal_me >> ((want >> 1) & 63u)) & 1ull);
+                if (want != got || ((hs.threat >> a) & 1ull) != (want & 1u) || ((hs.second >> a) & 1ull) != ((want >> 7) & 1u) ||
+                    ((hs.block >> a) & 1ull) != ((want >> 8) & 1u) || ((hs.flegal >> a) & 1ull) != (fl ? 1u : 0u))
+                    out[7]++;
+            }
+        }
+    }
+}
+
 void emu_greedy_stats(int64_t *out)
 {
     out[0] = g_pairs;

@@ -284,3 +284,18 @@ def test_greedy_root_rule(boards):
     assert bad == 0 and n_boards == len(state) and settled > 8 * n_boards and threatened > 0.2 * settled and left > 0
     m = np.ascontiguousarray((oracle.batch_legal_mask(state, tm) * (rng.random((len(state), 54)) < 0.6)).astype(np.int8))
     assert emu.greedy_root_rule(state, tm, mask=m)[4] == 0
+
+
+def test_greedy_virtual_root_rule(boards):
+    """The root rule applied to moves of PLACED pieces through a virtual root (the position with the piece lifted; proven and
+    measured in round 3, not shipped: tests/emu/greedy_root_rule.h): every candidate it settles equals the exact evaluation."""
+    state, tm, dn, rng = selfplay_states(6000, 30, seed=12)
+    live = oracle.batch_winner(state) == 0
+    dense = boards["squares"][boards["winner"] == 0]
+    state = np.ascontiguousarray(np.concatenate([state[live], dense, dense]))
+    tm = np.ascontiguousarray(np.concatenate([tm[live], np.zeros(len(dense), np.int8), np.ones(len(dense), np.int8)]))
+    for cap in (1, 6):
+        n_boards, pairs, placed, roots, settled, left, items, bad = emu.greedy_vroot_rule(state, tm, cap=cap)
+        assert bad == 0 and n_boards == len(state) and 0 < settled <= placed <= pairs and roots > 0, cap
+    m = np.ascontiguousarray((oracle.batch_legal_mask(state, tm) * (rng.random((len(state), 54)) < 0.6)).astype(np.int8))
+    assert emu.greedy_vroot_rule(state, tm, mask=m)[7] == 0
