@@ -882,6 +882,121 @@ __device__ __forceinline__ void outcomes54(const Planes &p, int mover, uint64_t 
     }
 }
 
+// ---- the depth-2 pair evaluation's FAST form ---------------------------------------------------------------------------------
+// On a position where nobody holds a line (a depth-1 result with value 0), a reply of `mover` can leave the OTHER side a
+// complete line only by lifting a piece that lies directly on one of theirs, on the third square of a line they otherwise hold
+// (their tops before the lift hold no line, and a lift adds exactly the square it exposes).  reply_is_plain() says that no TOP
+// piece of the mover stands like that; then every line complete after a reply is the mover's, the order in which the
+// reference walks the lines is irrelevant, nobody but the mover can win (`lose` = 0), and the mover's winning moves are the
+// THREAT SQUARES of its tops after the lift -- squares whose two partners on some line it tops (wins54_plain: per direction
+// two shifts of the tops onto the square and a mask, 12 terms, SWAR over three pieces, instead of outcomes54's eight ordered
+// line steps: 119 instead of 280 instructions).  The test is conservative in one respect only: a line with two exposable squares
+// counts, though one reply lifts one piece.  tests/emu checks the fast form against outcomes54 on every pair it is used for.
+__device__ __forceinline__ bool reply_is_plain(const Planes &p, int mover)
+{
+    uint32_t mine = mover ? (p.nz & p.neg) : (p.nz & ~p.neg);
+    uint32_t othr = mover ? (p.nz & ~p.neg) : (p.nz & p.neg);
+    uint32_t m1 = (mine >> 9) & 0x1FFu, m2 = (mine >> 18) & 0x1FFu;
+    uint32_t t0 = othr & 0x1FFu, t1 = (othr >> 9) & 0x1FFu, t2 = (othr >> 18) & 0x1FFu;
+    uint32_t o1 = m1 | t1, o2 = m2 | t2;
+    uint32_t To = t2 | (~o2 & (t1 | (~o1 & t0)));                    // the other side's tops
+    uint32_t X = (m2 & (t1 | (~o1 & t0))) | (m1 & ~o2 & t0);         // theirs directly below a TOP piece of the mover
+    uint32_t have = To | X;
+    uint32_t nh = ~(have | (have << 10) | (have << 20));
+    constexpr uint32_t LOW3 = 0x00100401u, G3 = LOW3 << 9, F3 = LOW3 * 0x1FFu;
+    constexpr uint32_t LA = 0x007u | (0x038u << 10) | (0x1C0u << 20), LB = 0x049u | (0x092u << 10) | (0x124u << 20);
+    constexpr uint32_t LC = 0x111u | (0x054u << 10) | (0x1FFu << 20);  // third field: a "line" nobody can hold
+    // guard bit of a field stays clear iff none of the line's squares is missing from `have`
+    uint32_t full = (G3 & ~((LA & nh) + F3)) | (G3 & ~((LB & nh) + F3)) | (G3 & ~(((LC & nh) | (1u << 20)) + F3));
+    return full == 0;
+}
+
+// THREAT SQUARES, three boards at a time (10-bit fields of a word, bit 9 of each unused): the squares whose two partners on
+// some line are both in T.  The partners are shifted onto the square (rows: neighbours at distance 1, columns 3, diagonal 4,
+// anti-diagonal 2); the masks pick the squares for which that pair of shifts IS the line, which also keeps every term inside
+// its field.
+__device__ __forceinline__ uint32_t threat3(uint32_t T)
+{
+    constexpr uint32_t LOW3 = 0x00100401u;
+    constexpr uint32_t M0 = 0x049u * LOW3, M1 = 0x092u * LOW3, M2 = 0x124u * LOW3;  // column 0 / 1 / 2 of the board, per field
+    constexpr uint32_t R0 = 0x007u * LOW3, R1 = 0x038u * LOW3, R2 = 0x1C0u * LOW3;  // row 0 / 1 / 2
+    constexpr uint32_t B0 = 0x001u * LOW3, B2 = 0x004u * LOW3, B4 = 0x010u * LOW3, B6 = 0x040u * LOW3, B8 = 0x100u * LOW3;
+    return ((T >> 1) & (T >> 2) & M0) | ((T << 1) & (T >> 1) & M1) | ((T << 1) & (T << 2) & M2)    // (0,1,2) (3,4,5) (6,7,8)
+         | ((T >> 3) & (T >> 6) & R0) | ((T << 3) & (T >> 3) & R1) | ((T << 3) & (T << 6) & R2)    // (0,3,6) (1,4,7) (2,5,8)
+         | ((T >> 4) & (T >> 8) & B0) | ((T << 4) & (T >> 4) & B4) | ((T << 4) & (T << 8) & B8)    // (0,4,8)
+         | ((T >> 2) & (T >> 4) & B2) | ((T << 2) & (T >> 2) & B4) | ((T << 2) & (T << 4) & B6);   // (2,4,6)
+}
+
+// the mover's winning moves on a quiet position whose replies are plain (see above); bit a as in outcomes54's `win`
+__device__ __forceinline__ uint64_t wins54_plain(const Planes &p, int mover)
+{
+    uint32_t mine = mover ? (p.nz & p.neg) : (p.nz & ~p.neg);
+    uint32_t othr = mover ? (p.nz & ~p.neg) : (p.nz & p.neg);
+    uint32_t m0 = mine & 0x1FFu, m1 = (mine >> 9) & 0x1FFu, m2 = (mine >> 18) & 0x1FFu;
+    uint32_t t1 = (othr >> 9) & 0x1FFu, t2 = (othr >> 18) & 0x1FFu;
+    uint32_t o1 = m1 | t1, o2 = m2 | t2;
+    uint32_t Tm = m2 | (~o2 & (m1 | (~o1 & m0)));  // squares whose top piece is the mover's
+    uint32_t um[3] = {0u, m0, m1 | (~o1 & m0)};    // the mover's highest piece strictly below level k
+    uint32_t TmR = Tm | (Tm << 10) | (Tm << 20);
+    uint64_t win = 0;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {  // word w: pieces 3w, 3w+1, 3w+2 in 10-bit fields
+        uint32_t lost = 0;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            int pi = 3 * w + f, k = pi >> 1;
+            uint32_t src = ((mine & ((pi & 1) ? ~p.odd : p.odd)) >> (9 * k)) & 0x1FFu;  // where the piece stands (0: in hand)
+            lost |= (src & ~um[k]) << (10 * f);  // the mover's top that leaves with the lift
+        }
+        const uint32_t W = threat3(TmR & ~lost);
+#pragma unroll
+        for (int f = 0; f < 3; ++f) win |= (uint64_t)((W >> (10 * f)) & 0x1FFu) << (9 * (3 * w + f));
+    }
+    return win;
+}
+
+// reply_is_plain(moved(p, me, a), 1 - me) for ALL moves a of `me` at once: bit a SET = NOT plain, the pair (p, a) takes the
+// ordered form of the evaluation.  With H = our tops and the squares where a TOP piece of the opponent lies directly on one of
+// ours -- the set reply_is_plain looks for a full line in -- a move of our piece i from s (nowhere: in hand) to q changes H in
+// two squares only: q joins it (our piece is the top there now, whatever lay there), and s stays iff what the lift leaves on
+// top of s is ours, or the opponent's lying directly on a piece of ours (the set C below); every other stack is as it was.
+// So per piece B_i = (H - s) + (C & s), and the pair is not plain iff B_i + q holds a full line: iff B_i does already, or q is
+// a threat square of B_i -- the threat squares of six 9-bit sets in two words.  One wavefront that idles through the depth-1
+// walk does this for a whole tile; the work lists are then split by it.  tests/emu checks every candidate's bit against
+// reply_is_plain on the moved board.
+__device__ __forceinline__ uint64_t greedy_nonplain(const Planes &p, int me)
+{
+    const uint32_t mine = me ? (p.nz & p.neg) : (p.nz & ~p.neg);
+    const uint32_t othr = me ? (p.nz & ~p.neg) : (p.nz & p.neg);
+    const uint32_t m0 = mine & 0x1FFu, m1 = (mine >> 9) & 0x1FFu, m2 = (mine >> 18) & 0x1FFu;
+    const uint32_t t0 = othr & 0x1FFu, t1 = (othr >> 9) & 0x1FFu, t2 = (othr >> 18) & 0x1FFu;
+    const uint32_t o1 = m1 | t1, o2 = m2 | t2;
+    const uint32_t below2 = m1 | (~o1 & m0);                      // our piece is the highest one strictly below level 2
+    const uint32_t Tm = m2 | (~o2 & below2);                      // our tops
+    const uint32_t X = (t2 & below2) | (t1 & ~o2 & m0);           // ours directly below a TOP piece of the opponent
+    const uint32_t H = Tm | X;
+    const uint32_t C = (m2 & (below2 | (t1 & m0))) | (m1 & ~o2 & m0);  // squares of H that stay when our top piece leaves
+    const uint32_t HR = H | (H << 10) | (H << 20), CR = C | (C << 10) | (C << 20);
+    constexpr uint32_t LOW3 = 0x00100401u, G3 = LOW3 << 9, F3 = LOW3 * 0x1FFu;
+    uint64_t np = 0;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        uint32_t src = 0;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const int pi = 3 * w + f, k = pi >> 1;
+            src |= (((mine & ((pi & 1) ? ~p.odd : p.odd)) >> (9 * k)) & 0x1FFu) << (10 * f);  // where the piece stands
+        }
+        const uint32_t B = (HR & ~src) | (CR & src);
+        const uint32_t th = threat3(B);
+        const uint32_t fg = (((th & B) + F3) & G3);  // a full line inside B itself: guard bit of the field
+        const uint32_t N = th | (fg - (fg >> 9));
+#pragma unroll
+        for (int f = 0; f < 3; ++f) np |= (uint64_t)((N >> (10 * f)) & 0x1FFu) << (9 * (3 * w + f));
+    }
+    return np;
+}
+
 __device__ __forceinline__ uint64_t below_eq(int b) { return (2ull << b) - 1ull; }  // bits 0..b, b < 63
 
 // One decision for the agent `me` on board p, in four per-board pieces so that a kernel can spread
@@ -1116,13 +1231,26 @@ __device__ __forceinline__ GreedyRootPlan greedy_root_plan(const GreedyHead &h, 
 //   bit 8      some winning reply is a legal move of ours on the root position (:141)
 //   bits 9-14  the first such reply
 //   bit 15     every reply wins the game for us            (all(), :146-149; implies bit 0 clear)
+// PLAIN: the caller has checked greedy_pair_is_plain(p, me, a) -- the fast form (threat squares; nobody but the opponent
+// can win, so "every reply wins for us" holds only if the opponent cannot move at all); otherwise outcomes54's ordered line steps.
+__device__ __forceinline__ bool greedy_pair_is_plain(const Planes &p, int me, uint32_t a)
+{
+    return reply_is_plain(moved(p, me, a), 1 - me);
+}
+
+template <bool PLAIN = false>
 __device__ __forceinline__ uint32_t greedy_reply(const Planes &p, int me, uint64_t legal_me, uint32_t a)
 {
     const int opp = 1 - me;
     Planes d1 = moved(p, me, a);         // :107-109
     uint64_t legal2 = legal54(d1, opp);  // :112-116
     uint64_t ow, mw;                     // the opponent wins / we win after reply a2, :120-126
-    outcomes54<true>(d1, opp, ow, mw);   // (a is a depth-1 result with value 0: nobody holds a line on d1)
+    if (PLAIN) {
+        ow = wins54_plain(d1, opp);
+        mw = 0;
+    } else {
+        outcomes54<true>(d1, opp, ow, mw);  // (a is a depth-1 result with value 0: nobody holds a line on d1)
+    }
     ow &= legal2;
     mw &= legal2;
     uint64_t block = ow & legal_me;

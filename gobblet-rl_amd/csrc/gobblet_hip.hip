@@ -891,7 +891,8 @@ struct GreedyLds {
     static_assert(W == 1 || W >= 2 * NT, "a helper wavefront per owner");
     static constexpr int kBoards = kTile * NT;
     static_assert(kBoards <= 256, "(board << 8) | candidate fits 16 bits");
-    alignas(16) uint16_t pair[kBoards * kActions];    // (board << 8) | candidate of every depth-2 evaluation of the block
+    alignas(16) uint16_t pair[kBoards * kActions];    // (board << 8) | candidate of every depth-2 evaluation of the block: those that
+                                                      // take the fast form from the front, the ORDERED form (greedy_nonplain) from the back
     unsigned long long undef[kBoards][kRootItems];    // per board and member j of the root's replies: greedy_undefused
     uint16_t item[kBoards * kRootItems];              // (board << 8) | j of every member of a root's replies that is dealt out
     uint32_t board[kBoards][4];            // planes nz, neg, odd; bit 0: the agent to move, bit 1: the board wants depth 2
@@ -899,13 +900,16 @@ struct GreedyLds {
     unsigned long long work[kBoards];      // the candidates of a board that are evaluated
     unsigned long long replies[kBoards];   // the opponent's winning moves on the root (greedy_root); after the plan: those dealt out
     uint32_t risky[kBoards];               // 9 bits: squares where a placement from hand has to be evaluated (greedy_root)
-    int npairs, nitems;
+    int npairs, nitems;                    // npairs: fast pairs in the low, ordered pairs in the high 16 bits
     uint16_t reply[kBoards][kActions];     // greedy_reply() of (board, candidate), where bit 0 is set
     unsigned long long threat[kBoards];    // candidates whose summary has bit 0 / bit 15 / bit 7 / bit 8,
     unsigned long long allwin[kBoards];    // and those whose first winning reply is a legal move of ours
     unsigned long long second[kBoards];    // (the sets greedy_replay_closed works on)
     unsigned long long block[kBoards];
     unsigned long long flegal[kBoards];
+    unsigned long long workx[kBoards];     // the candidates of a board that are evaluated in the ordered form (work: in the fast form)
+    unsigned long long nonplain[kBoards];  // greedy_nonplain of the board
+    int job;                               // the next chunk of 64 pairs / items to hand out
     // The pair list and the table are dead between two decisions (written after the first barriers of greedy_tile, read
     // before it returns): a kernel that decides in a loop stages its owners' output rows through them in between.
     static constexpr int kScratchBytes = (int)(sizeof(uint16_t) * kBoards * kActions + sizeof(unsigned long long) * kBoards * kRootItems);
@@ -939,6 +943,38 @@ __device__ __forceinline__ void list_append(uint16_t *list, int *fill, uint32_t 
     if (lane == 0 && total) base = (uint32_t)atomicAdd(fill, (int)total);
     uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + below;
     for (uint32_t rest = bits; rest; rest &= rest - 1u) list[at++] = (uint16_t)(tag + (uint32_t)__builtin_ctz(rest));
+}
+
+// list_append for two lists at once -- entries of `bits` go to `list` upwards, those of `bitsx` (few lanes have any) from
+// `listx` DOWNWARDS (the two share one array) -- whose fill counts share one word (low / high 16 bits): still one atomic per
+// wavefront.
+template <int STEPS>
+__device__ __forceinline__ void list_append2(uint16_t *list, uint16_t *listx, int *fill, uint32_t tag, int lane, uint32_t bits, uint32_t bitsx)
+{
+    static_assert(STEPS <= 31, "the steps of a lane fit a 32-bit set");
+    constexpr int kBits = STEPS < 2 ? 1 : STEPS < 4 ? 2 : STEPS < 8 ? 3 : STEPS < 16 ? 4 : 5;
+    const uint32_t cnt = (uint32_t)__popc(bits), cntx = (uint32_t)__popc(bitsx);
+    uint32_t below = 0, total = 0, belowx = 0, totalx = 0;
+#pragma unroll
+    for (int k = 0; k < kBits; ++k) {
+        const unsigned long long m = __ballot((cnt >> k) & 1u);
+        below += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << k;
+        total += (uint32_t)__popcll(m) << k;
+    }
+    if (__ballot(bitsx != 0u)) {  // (wavefront-uniform)
+#pragma unroll
+        for (int k = 0; k < kBits; ++k) {
+            const unsigned long long m = __ballot((cntx >> k) & 1u);
+            belowx += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << k;
+            totalx += (uint32_t)__popcll(m) << k;
+        }
+    }
+    uint32_t base = 0;
+    if (lane == 0 && (total | totalx)) base = (uint32_t)atomicAdd(fill, (int)(total | (totalx << 16)));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    uint32_t at = (base & 0xFFFFu) + below, atx = (base >> 16) + belowx;
+    for (uint32_t rest = bits; rest; rest &= rest - 1u) list[at++] = (uint16_t)(tag + (uint32_t)__builtin_ctz(rest));
+    for (uint32_t rest = bitsx; rest; rest &= rest - 1u) listx[-(int)(atx++)] = (uint16_t)(tag + (uint32_t)__builtin_ctz(rest));
 }
 
 // One decision per board of the block, by ALL 64 W threads of the workgroup (every thread calls, the barriers are inside).
@@ -980,6 +1016,7 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
         if (threadIdx.x == 0) {
             S.npairs = 0;
             S.nitems = 0;
+            S.job = 0;
         }
     }
     if (deep) {
@@ -990,6 +1027,14 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
             const GreedyRoot g = greedy_root(q, (int)(S.board[bi][3] & 1u));
             S.replies[bi] = g.replies;
             S.risky[bi] = g.risky;
+        }
+        // ... and a wavefront that would idle (blocks without one: the helpers, on top) finds the moves of ours after which
+        // a reply could expose a line of ours: those pairs take the ordered form of the evaluation, all others the fast one
+        constexpr int kPlainWave0 = W >= 3 * NT ? 2 * NT : NT;
+        if (wave >= kPlainWave0 && wave < kPlainWave0 + NT) {
+            const int bn = (wave - kPlainWave0) * kTile + lane;
+            if (S.board[bn][3] & 2u)
+                S.nonplain[bn] = greedy_nonplain(Planes{S.board[bn][0], S.board[bn][1], S.board[bn][2]}, (int)(S.board[bn][3] & 1u));
         }
     }
     if (owner) {
@@ -1008,7 +1053,9 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
         if (owner) {
             // (C) twin placements are not evaluated a second time; placements from hand on non-risky squares not at all
             if (two) plan = greedy_root_plan(h, p, me, GreedyRoot{S.replies[bi], S.risky[bi]});
-            S.work[bi] = plan.eval;
+            const unsigned long long slow = two ? S.nonplain[bi] : 0ull;
+            S.work[bi] = plan.eval & ~slow;
+            S.workx[bi] = plan.eval & slow;
             S.replies[bi] = plan.items;
         }
     }
@@ -1026,7 +1073,8 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
             if (c0 < kActions) {
                 const int steps = kActions - c0 < kSteps ? kActions - c0 : kSteps;
                 const uint32_t wk = (uint32_t)(S.work[g * kTile + lane] >> c0) & ((1u << steps) - 1u);
-                list_append<kSteps>(S.pair, &S.npairs, ((uint32_t)(g * kTile + lane) << 8) + (uint32_t)c0, lane, wk);
+                const uint32_t wx = (uint32_t)(S.workx[g * kTile + lane] >> c0) & ((1u << steps) - 1u);
+                list_append2<kSteps>(S.pair, S.pair + (GreedyLds<NT, W>::kBoards * kActions - 1), &S.npairs, ((uint32_t)(g * kTile + lane) << 8) + (uint32_t)c0, lane, wk, wx);
             }
         }
         GBL_WAVE_STAMP(6);
@@ -1041,8 +1089,11 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
         GBL_WAVE_STAMP(7);
         pool_fence<W>();
         GBL_WAVE_STAMP(2);
-        // (E) the pairs, from the first wavefront up ...
-        const int total = S.npairs;
+        // (E) the work in chunks of 64, handed out through a counter -- the ordered pairs first (an ordered evaluation is
+        // twice a fast one), then the fast pairs, then the items: whoever is through takes the next chunk, so the oldest
+        // wavefronts of a SIMD, which win the issue arbitration, simply take more
+        const int nfast = S.npairs & 0xFFFF, nslow = (int)((uint32_t)S.npairs >> 16), nitems = S.nitems;
+        const int jslow = (nslow + kTile - 1) / kTile, jfast = (nfast + kTile - 1) / kTile, jitem = (nitems + kTile - 1) / kTile;
         auto record = [&](uint32_t o, uint32_t a, uint32_t sum) {
             if (sum & 1u) {
                 S.reply[o][a] = (uint16_t)sum;
@@ -1053,21 +1104,36 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
             }
             if (sum >> 15) atomicOr(&S.allwin[o], 1ull << a);
         };
-        for (int g = (int)threadIdx.x; g < total; g += kTile * W) {
-            const uint32_t pair = S.pair[g], o = pair >> 8, a = pair & 0xFFu;
-            const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
-            record(o, a, greedy_reply(q, (int)(S.board[o][3] & 1u), S.legal[o], a));
+        for (;;) {
+            int j = 0;
+            if (lane == 0) j = atomicAdd(&S.job, 1);
+            j = __builtin_amdgcn_readfirstlane(j);
+            if (j >= jslow + jfast + jitem) break;
+            if (j < jslow) {
+                const int g = j * kTile + lane;
+                if (g < nslow) {
+                    const uint32_t pair = S.pair[GreedyLds<NT, W>::kBoards * kActions - 1 - g], o = pair >> 8, a = pair & 0xFFu;
+                    const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
+                    record(o, a, greedy_reply<false>(q, (int)(S.board[o][3] & 1u), S.legal[o], a));
+                }
+            } else if (j < jslow + jfast) {
+                const int g = (j - jslow) * kTile + lane;
+                if (g < nfast) {
+                    const uint32_t pair = S.pair[g], o = pair >> 8, a = pair & 0xFFu;
+                    const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
+                    record(o, a, greedy_reply<true>(q, (int)(S.board[o][3] & 1u), S.legal[o], a));
+                }
+            } else {
+                const int g = (j - jslow - jfast) * kTile + lane;
+                if (g < nitems) {
+                    const uint32_t it = S.item[g], o = it >> 8, jr = it & 0xFFu;
+                    const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
+                    const uint32_t a2 = kth_bit64(S.replies[o], jr);
+                    S.undef[o][jr] = greedy_undefused(q, (int)(S.board[o][3] & 1u), a2);
+                }
+            }
         }
         GBL_WAVE_STAMP(3);
-        // ... and the items, also from the first wavefront up: the oldest wavefronts of a SIMD are through their pairs
-        // thousands of cycles before the youngest (issue arbitration is oldest first), the items fit into that slack
-        const int nitems = S.nitems;
-        for (int g = ((wave + W - kItemWave0) % W) * kTile + lane; g < nitems; g += kTile * W) {
-            const uint32_t it = S.item[g], o = it >> 8, j = it & 0xFFu;
-            const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
-            const uint32_t a2 = kth_bit64(S.replies[o], j);
-            S.undef[o][j] = greedy_undefused(q, (int)(S.board[o][3] & 1u), a2);
-        }
         GBL_TILE_STAMP(ts, 1);
         GBL_WAVE_STAMP(4);
         pool_fence<W>();

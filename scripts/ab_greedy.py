@@ -40,7 +40,10 @@ for i in range(len(libs)):
     run(i)
 torch.cuda.synchronize()
 for i in range(1, len(libs)):
-    assert all(torch.equal(x, y) for x, y in zip(outs[0], outs[i])), paths[i]
+    if os.environ.get("AB_ALLOW_DIFF"):  # (timing experiments with an inexact variant)
+        print(paths[i], "boards with another decision:", int((outs[0][0] != outs[i][0]).sum()), flush=True)
+    else:
+        assert all(torch.equal(x, y) for x, y in zip(outs[0], outs[i])), paths[i]
 res = [[] for _ in libs]
 for rnd in range(7):
     for i in range(len(libs)):

@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void k(const uint32_t *__restrict__ planes, ui
         if (WHAT == 1) { uint64_t w, l; outcomes54<true>(p, me, w, l); acc += (uint32_t)w ^ (uint32_t)(l >> 7); p.odd ^= acc & 1u; }
         if (WHAT == 2) acc += (uint32_t)greedy_undefused(p, me, a);
         if (WHAT == 3) { uint64_t w, l; outcomes54<false>(p, me, w, l); acc += (uint32_t)w ^ (uint32_t)(l >> 7); p.odd ^= acc & 1u; }
+        if (WHAT == 4) acc += greedy_reply<true>(p, me, legal, a) + (greedy_pair_is_plain(p, me, a) ? 1u : 0u);
         a = a + 7 + (acc & 1u);
         a = a >= 54 ? a - 54 : a;
     }
@@ -43,9 +44,10 @@ int main()
     (void)hipMemcpy(dp, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    const char *names[4] = {"greedy_reply (pair evaluation)", "outcomes54<QUIET>", "greedy_undefused (item)", "outcomes54 (general)"};
+    const char *names[5] = {"greedy_reply (ordered form)", "outcomes54<QUIET>", "greedy_undefused (item)", "outcomes54 (general)",
+                            "greedy_reply (fast form + test)"};
     const int iters = 200;
-    for (int what = 0; what < 4; ++what)
+    for (int what = 0; what < 5; ++what)
         for (int wps = 1; wps <= 8; wps *= 2) {  // wavefronts per SIMD
             const int grid = cus * wps;
             auto launch = [&] {
@@ -53,6 +55,7 @@ int main()
                 if (what == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, dp, dout, iters);
                 if (what == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, dp, dout, iters);
                 if (what == 3) hipLaunchKernelGGL(k<3>, dim3(grid), dim3(256), 0, 0, dp, dout, iters);
+                if (what == 4) hipLaunchKernelGGL(k<4>, dim3(grid), dim3(256), 0, 0, dp, dout, iters);
             };
             launch(); launch();
             (void)hipEventRecord(e0, 0);

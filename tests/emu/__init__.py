@@ -143,9 +143,10 @@ def greedy_root_rule(state, to_move, mask=None):
 
 
 def greedy_stats():
-    """(pairs evaluated, pairs deferred to the exact evaluation, cross-check failures -- cheap != exact, closed form !=
-    loop form, a held placement with a non-zero summary --, placements held back behind a smaller one on the same
-    square, held placements evaluated after all) since the library was loaded."""
+    """(pairs evaluated, of them pairs for which reply_is_plain does not hold -- the ordered line steps --, cross-check
+    failures -- fast form != ordered form of a pair, closed form != loop form of the depth-2 loop, a settled placement whose
+    table summary differs from its evaluation --, placements settled from the root's replies, items dealt out) since the
+    library was loaded."""
     o = np.zeros(5, np.int64)
     lib().emu_greedy_stats(_p(o)); return tuple(int(x) for x in o)
 

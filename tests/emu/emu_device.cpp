@@ -539,8 +539,15 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
         };
         for (int g = 0; g < total; ++g) {
             const uint32_t o = pair[g] >> 8, a = pair[g] & 0xFFu;
-            const uint32_t sum = greedy_reply(P[o], ME[o], H[o].legal_me, a);
+            // the kernel's choice: the fast form of the pair evaluation (threat squares) where the board's greedy_nonplain set
+            // says the pair is plain -- the set's bit checked against reply_is_plain on the moved board, the fast form against
+            // the ordered line steps, on every pair --, the ordered form elsewhere
+            const bool plain = !((greedy_nonplain(P[o], ME[o]) >> a) & 1ull);
+            if (plain != greedy_pair_is_plain(P[o], ME[o], a)) g_fast_mismatch++;
+            const uint32_t sum = plain ? greedy_reply<true>(P[o], ME[o], H[o].legal_me, a) : greedy_reply<false>(P[o], ME[o], H[o].legal_me, a);
             g_pairs++;
+            if (!plain) g_deferred++;
+            if (plain && sum != greedy_reply<false>(P[o], ME[o], H[o].legal_me, a)) g_fast_mismatch++;
             record(o, a, sum);
         }
         uint64_t UND[64][kRootItems];

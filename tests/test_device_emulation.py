@@ -170,8 +170,12 @@ def test_greedy_vs_oracle_selfplay(boards):
     #  loop form, greedy_replay_sets, on every board; and EVERY placement from hand that the root rule settles without an
     #  evaluation -- its summary looked up in the board's table and its bits in the merged candidate sets -- against its
     #  exact evaluation)
-    pairs, deferred, bad, settled, items = emu.greedy_stats()
+    #  exact evaluation; and the FAST form of the pair evaluation -- threat squares, where reply_is_plain holds -- against the
+    #  ordered line steps on every pair)
+    pairs, not_plain, bad, settled, items = emu.greedy_stats()
     assert bad == 0
+    print(f"pairs {pairs}, of them not plain {not_plain} ({not_plain / pairs:.4f})")
+    assert 0.02 * pairs < not_plain < 0.2 * pairs  # both forms are exercised
     assert settled > 1.2 * pairs and 0 < items < pairs  # the rule settles most candidates, from a few items per board
     # the per-board composition (greedy_decide) next to the kernel's pooled one
     for kw in ({"hist": hist}, {"mask": m}):
