@@ -8,7 +8,7 @@ struct TileStamps {
 };
 #ifdef GBL_STAMPS
 __device__ unsigned long long g_stamps[1 << 17][12];
-__device__ unsigned long long g_wave_stamps[1024][16][8];  // per block and wavefront: phase stamps inside greedy_tile
+__device__ unsigned long long g_wave_stamps[1024][16][12];  // per block and wavefront: phase stamps inside greedy_tile
 #define GBL_STAMP(i) unsigned long long st_##i = __builtin_amdgcn_s_memtime()
 #define GBL_STAMP_REAL(i) unsigned long long rt_##i = __builtin_amdgcn_s_memrealtime()
 #define GBL_STAMP_DECL(i) unsigned long long st_##i = 0
@@ -48,7 +48,7 @@ __device__ unsigned long long g_wave_stamps[1024][16][8];  // per block and wave
 #ifdef GBL_STAMPS
 extern "C" int gbl_debug_wave_stamps(unsigned long long *host_out)
 {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wave_stamps), sizeof(unsigned long long) * 1024 * 16 * 8);
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wave_stamps), sizeof(unsigned long long) * 1024 * 16 * 12);
 }
 extern "C" int gbl_debug_stamps(unsigned long long *host_out, int64_t ntiles)
 {

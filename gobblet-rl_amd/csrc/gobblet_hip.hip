@@ -949,11 +949,12 @@ __device__ __forceinline__ void list_append(uint16_t *list, int *fill, uint32_t 
 // `listx` DOWNWARDS (the two share one array) -- whose fill counts share one word (low / high 16 bits): still one atomic per
 // wavefront.
 template <int STEPS>
-__device__ __forceinline__ void list_append2(uint16_t *list, uint16_t *listx, int *fill, uint32_t tag, int lane, uint32_t bits, uint32_t bitsx)
+__device__ __forceinline__ void list_append2(uint16_t *list, uint16_t *listx, int *fill, uint32_t tag, int lane, uint64_t bits, uint64_t bitsx)
 {
-    static_assert(STEPS <= 31, "the steps of a lane fit a 32-bit set");
-    constexpr int kBits = STEPS < 2 ? 1 : STEPS < 4 ? 2 : STEPS < 8 ? 3 : STEPS < 16 ? 4 : 5;
-    const uint32_t cnt = (uint32_t)__popc(bits), cntx = (uint32_t)__popc(bitsx);
+    static_assert(STEPS <= 63, "the steps of a lane fit a 64-bit set");
+    constexpr int kBits = STEPS < 2 ? 1 : STEPS < 4 ? 2 : STEPS < 8 ? 3 : STEPS < 16 ? 4 : STEPS < 32 ? 5 : 6;
+    const uint32_t cnt = STEPS < 32 ? (uint32_t)__popc((uint32_t)bits) : (uint32_t)__popcll(bits);
+    const uint32_t cntx = STEPS < 32 ? (uint32_t)__popc((uint32_t)bitsx) : (uint32_t)__popcll(bitsx);
     uint32_t below = 0, total = 0, belowx = 0, totalx = 0;
 #pragma unroll
     for (int k = 0; k < kBits; ++k) {
@@ -961,7 +962,7 @@ __device__ __forceinline__ void list_append2(uint16_t *list, uint16_t *listx, in
         below += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << k;
         total += (uint32_t)__popcll(m) << k;
     }
-    if (__ballot(bitsx != 0u)) {  // (wavefront-uniform)
+    if (__ballot(bitsx != 0ull)) {  // (wavefront-uniform)
 #pragma unroll
         for (int k = 0; k < kBits; ++k) {
             const unsigned long long m = __ballot((cntx >> k) & 1u);
@@ -973,8 +974,13 @@ __device__ __forceinline__ void list_append2(uint16_t *list, uint16_t *listx, in
     if (lane == 0 && (total | totalx)) base = (uint32_t)atomicAdd(fill, (int)(total | (totalx << 16)));
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     uint32_t at = (base & 0xFFFFu) + below, atx = (base >> 16) + belowx;
-    for (uint32_t rest = bits; rest; rest &= rest - 1u) list[at++] = (uint16_t)(tag + (uint32_t)__builtin_ctz(rest));
-    for (uint32_t rest = bitsx; rest; rest &= rest - 1u) listx[-(int)(atx++)] = (uint16_t)(tag + (uint32_t)__builtin_ctz(rest));
+    if (STEPS < 32) {
+        for (uint32_t rest = (uint32_t)bits; rest; rest &= rest - 1u) list[at++] = (uint16_t)(tag + (uint32_t)__builtin_ctz(rest));
+        for (uint32_t rest = (uint32_t)bitsx; rest; rest &= rest - 1u) listx[-(int)(atx++)] = (uint16_t)(tag + (uint32_t)__builtin_ctz(rest));
+    } else {
+        for (uint64_t rest = bits; rest; rest &= rest - 1ull) list[at++] = (uint16_t)(tag + (uint32_t)__builtin_ctzll(rest));
+        for (uint64_t rest = bitsx; rest; rest &= rest - 1ull) listx[-(int)(atx++)] = (uint16_t)(tag + (uint32_t)__builtin_ctzll(rest));
+    }
 }
 
 // One decision per board of the block, by ALL 64 W threads of the workgroup (every thread calls, the barriers are inside).
@@ -1020,7 +1026,9 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
         }
     }
     if (deep) {
+        GBL_WAVE_STAMP(8);
         pool_fence<W>();
+        GBL_WAVE_STAMP(9);
         // (B) the helpers look at the root from the OPPONENT's side (as expensive as the depth-1 walk itself)
         if (wave >= NT && wave < 2 * NT && (S.board[bi][3] & 2u)) {
             const Planes q{S.board[bi][0], S.board[bi][1], S.board[bi][2]};
@@ -1049,6 +1057,7 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
         }
     }
     if (deep) {
+        GBL_WAVE_STAMP(10);
         pool_fence<W>();  // the helpers' findings are in
         if (owner) {
             // (C) twin placements are not evaluated a second time; placements from hand on non-risky squares not at all
@@ -1066,21 +1075,25 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
         GBL_WAVE_STAMP(1);
         // (D) the work lists: W / NT wavefronts share a tile's 54 candidate steps, and the owners take their tile's 6 rank
         // steps on top
-        constexpr int kWavesPerTile = W / NT, kSteps = (kActions + kWavesPerTile - 1) / kWavesPerTile;
-        static_assert(W % NT == 0, "the same number of wavefronts lists every tile");
-        {
-            const int g = wave / kWavesPerTile, c0 = (wave % kWavesPerTile) * kSteps;  // (a wavefront's steps stay inside one tile)
+        // (fewer listers with longer per-lane loops lose: two per tile +2 %, one per tile +12 % at 65 536 boards)
+#ifndef GBL_X_LISTERS
+#define GBL_X_LISTERS 64
+#endif
+        constexpr int kWavesPerTile = W / NT < GBL_X_LISTERS ? W / NT : GBL_X_LISTERS, kSteps = (kActions + kWavesPerTile - 1) / kWavesPerTile;
+        if (const int lw = wave - (W - NT * kWavesPerTile); lw >= 0) {  // (the last wavefronts: the owners come out of the plan last)
+            const int g = lw / kWavesPerTile, c0 = (lw % kWavesPerTile) * kSteps;  // (a wavefront's steps stay inside one tile)
             if (c0 < kActions) {
                 const int steps = kActions - c0 < kSteps ? kActions - c0 : kSteps;
-                const uint32_t wk = (uint32_t)(S.work[g * kTile + lane] >> c0) & ((1u << steps) - 1u);
-                const uint32_t wx = (uint32_t)(S.workx[g * kTile + lane] >> c0) & ((1u << steps) - 1u);
-                list_append2<kSteps>(S.pair, S.pair + (GreedyLds<NT, W>::kBoards * kActions - 1), &S.npairs, ((uint32_t)(g * kTile + lane) << 8) + (uint32_t)c0, lane, wk, wx);
+                const uint64_t wk = (S.work[g * kTile + lane] >> c0) & ((1ull << steps) - 1ull);
+                const uint64_t wx = (S.workx[g * kTile + lane] >> c0) & ((1ull << steps) - 1ull);
+                list_append2<kSteps>(S.pair, S.pair + (GreedyLds<NT, W>::kBoards * kActions - 1), &S.npairs,
+                                     ((uint32_t)(g * kTile + lane) << 8) + (uint32_t)c0, lane, wk, wx);
             }
         }
         GBL_WAVE_STAMP(6);
         // (blocks of tiles: by the owners -- the oldest wavefronts on their SIMDs win the issue arbitration and are through
         // first; a lone tile: by its helper, the owner's own path being the longest there)
-        constexpr int kItemWave0 = NT == 1 ? 1 : 0;
+        constexpr int kItemWave0 = NT * kWavesPerTile < W ? 0 : NT == 1 ? 1 : 0;  // (wavefronts that list no pairs, if any)
         if (wave >= kItemWave0 && wave < kItemWave0 + NT) {
             const int g = wave - kItemWave0;
             const uint32_t nr = (uint32_t)__popcll(S.replies[g * kTile + lane]);
@@ -1253,7 +1266,16 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
             prev3 = hist_prev3(h0, h1, h2, me);
     }
     TileStamps ts{};
+#ifdef GBL_X_TWICE  // (diagnostic: the decision twice through the SAME code, the stamps are the second pass's -- what do cold instruction fetches cost?)
+    GreedyResult g{-1, 0ull, false};
+#pragma nounroll
+    for (int rep = 0; rep < 2; ++rep) {
+        g = greedy_tile<NT, W>(S, p, me, mask, depth, depth > 1, prev3, ts);
+        pool_fence<W>();
+    }
+#else
     const GreedyResult g = greedy_tile<NT, W>(S, p, me, mask, depth, depth > 1, prev3, ts);
+#endif
     GBL_STAMP_VAL(1, ts.t[0]);
     GBL_STAMP_VAL(2, ts.t[1]);
     GBL_STAMP_VAL(3, ts.t[2]);
@@ -1279,6 +1301,7 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
         }
     }
     GBL_STAMP(4);
+    GBL_WAVE_STAMP(11);
     GBL_STAMP_DRAIN(5);
     GBL_STAMP_FLUSH(L.tile);
 }
@@ -1888,13 +1911,13 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
     // (the product build instantiates the shapes policy_shape() can return; an A/B build the one it forces as well)
     if (shape == 48) GBL_CP(4, 8);
     else if (shape == 26) GBL_CP(1, 16);
-    else if (shape == 18) GBL_CP(1, 8);
+    else if (shape == 28) GBL_CP(2, 8);
     else if (shape == 14) GBL_CP(1, 4);
 #if defined(GBL_FORCE_GREEDY_SHAPE) && GBL_FORCE_GREEDY_SHAPE == 56
     else if (shape == 56) GBL_CP(4, 16);
 #endif
-#if defined(GBL_FORCE_GREEDY_SHAPE) && GBL_FORCE_GREEDY_SHAPE == 28
-    else if (shape == 28) GBL_CP(2, 8);
+#if defined(GBL_FORCE_GREEDY_SHAPE) && GBL_FORCE_GREEDY_SHAPE == 18
+    else if (shape == 18) GBL_CP(1, 8);
 #endif
     else GBL_CP(1, 1);
 #undef GBL_CP
@@ -1995,36 +2018,49 @@ namespace {
 // 2-4 % beyond 131 072 boards.  Round 3 (ab_greedy.py / ab_policy_collect.py): what decides is how many
 // wavefronts a SIMD has to issue from WHILE THE PAIRS ARE EVALUATED (this code needs four to hide its own LDS round trips
 // and dependency chains) against how many sit idle through the owners' phases:
-//   gbl_greedy, us:        4 096   16 384   32 768   65 536   131 072   262 144    2^20
-//     <1,4>                 10.0      -       12.9     15.9      29.5      50.7     180
-//     <1,8>                  9.4     9.5      12.7     19.1      35.0      62.6     228
-//     <1,16>                 8.7     8.7      14.6       -         -         -        -
-//     <2,8>                 11.3    11.3      11.7     16.3      28.9        -        -
-//     <4,8>                 15.1      -       14.9     15.3      28.5      56.4     218
-//     <4,16>                  -       -       13.9     14.5      26.7      51.3     198
-// (<1,16>: one workgroup per CU up to 256 tiles; <4,16>: four owners, four helpers and eight more wavefronts that only
-// evaluate pairs -- 16 wavefronts per CU for ONE generation of tiles; beyond 131 072 boards the tiles are out of step
-// anyway and the smallest workgroups win.)
+//   gbl_greedy, us (with the two-form pair evaluation, r03 shapes sweep):
+//                          4 096   16 384   32 768   49 152   65 536   98 304   131 072   196 608   262 144    2^20
+//     <1,4>                  9.4     9.4      11.5     13.0     14.4     20.5      25.8      34.7      43.6     152
+//     <1,8>                  8.7     8.9      11.2     13.0     17.3     24.4      31.2      43.3      55.0     201
+//     <1,16>                 8.9     9.0      14.8     20.6     26.2       -         -         -         -        -
+//     <2,8>                 10.1    10.0      10.2     13.8     13.9     20.4      24.6      35.1      45.5     167
+//     <4,8>                 12.7    12.8      12.9     13.1     13.2     24.1      25.1      36.4      48.1     182
+//     <4,16>                11.7    11.5      11.5     11.9     12.0     21.8      22.7      32.8      43.1     165
+// (<1,16>: one workgroup per CU up to 256 tiles; <4,16>: four owners, four helpers, four wavefronts for the nonplain sets and
+// four more that only evaluate -- 16 wavefronts per CU for one GENERATION of tiles, 65 536 boards; a launch of 1.5 generations
+// takes as long as one of two, so between generations the smallest workgroups take over, and beyond four they win anyway.)
+[[maybe_unused]] static bool whole_generations(int64_t n)  // the last generation of 65 536-board blocks is at least 80 % full
+{
+    const int64_t gens = (n + 65535) / 65536;
+    return n * 5 >= gens * 65536 * 4;
+}
+
 int greedy_shape(int depth, int64_t n)
 {
 #ifdef GBL_FORCE_GREEDY_SHAPE  // A/B builds (scripts/build_variant.sh)
     (void)n;
     return depth == 1 ? 11 : GBL_FORCE_GREEDY_SHAPE;
 #else
-    return depth == 1 ? 11 : n <= 16384 ? 26 : n <= 32768 ? 28 : n <= 131072 ? 56 : 14;
+    return depth == 1 ? 11 : n <= 16384 ? 26 : n <= 32768 ? 28 : n <= 65536 ? 56 : n <= 262144 && whole_generations(n) ? 56 : 14;
 #endif
 }
 
 // ... and of gbl_collect_policy's, whose ply loop keeps more registers live: blocks of tiles only where they stay inlined
-// within the register file (<4,8>: 65 536 boards 18.2 us per ply against 19.6 for <1,4>, 20.5 for <4,16> behind a call;
-// 16 384 boards: <1,16> 11.0, <1,8> 11.5)
+// within the register file.  us per self-play ply (r03 shapes sweep):
+//                          4 096   16 384   32 768   65 536   131 072   262 144
+//     <1,4>                 11.5    11.7      13.8     17.2      32.7      62.4
+//     <1,8>                 10.6    10.8      13.3     25.3      49.4      96.7
+//     <1,16>                10.6    10.7      21.0     41.8        -         -
+//     <2,8>                 11.2    11.0      11.2     22.4      44.2      87.8
+//     <4,8>                 15.0    14.9      15.0     15.5      30.5      60.4
+//     <4,16> (behind a call) 16.5   16.7      16.7     16.9      33.3      66.2
 int policy_shape(int depth, int64_t n)
 {
 #ifdef GBL_FORCE_GREEDY_SHAPE
     (void)n;
     return depth <= 1 ? 11 : GBL_FORCE_GREEDY_SHAPE;
 #else
-    return depth <= 1 ? 11 : n <= 16384 ? 26 : n <= 32768 ? 18 : n <= 131072 ? 48 : 14;
+    return depth <= 1 ? 11 : n <= 16384 ? 26 : n <= 32768 ? 28 : n <= 65536 ? 48 : n <= 262144 && whole_generations(n) ? 48 : 14;
 #endif
 }
 

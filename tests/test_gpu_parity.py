@@ -786,6 +786,29 @@ def test_greedy_config5_full_size(G):
         assert h is None or 0 < int(o[2].sum()) < n  # with histories both outcomes of the fallback test occur
 
 
+@pytest.mark.parametrize("n", [20000, 98304, 300000])
+def test_greedy_every_launch_shape(G, n):
+    """gbl_greedy picks its workgroup shape by batch size (greedy_shape): <1,16> up to 16 384 boards (the golden and
+    self-play tests), <2,8> up to 32 768, <4,16> for whole generations of 65 536 boards up to 262 144 (config 5's test),
+    <1,4> in between and beyond.  The other three, each against the oracle on the masked-random mix with random histories
+    (a ragged last tile included)."""
+    from gobblet_rl_amd import _native as nat
+    n = n + 37
+    env = G.BatchedGobblet(n, DEV, auto_reset=True, seed=n)
+    env.rollout(48)
+    torch.cuda.synchronize()
+    state, tm = npy(env.squares), npy(env.to_move)
+    hist = np.random.default_rng(n).integers(-1, 54, (n, 2, 3)).astype(np.int8)
+    act = torch.empty(n, dtype=torch.int32, device=DEV); cm = torch.empty((n, 54), dtype=torch.int8, device=DEV)
+    fb = torch.empty(n, dtype=torch.int8, device=DEV)
+    nat.check(nat.lib().gbl_greedy(env.squares.data_ptr(), env.to_move.data_ptr(), None, t(hist).data_ptr(), 2, act.data_ptr(),
+                                   cm.data_ptr(), fb.data_ptr(), n, nat.current_stream(torch.device(DEV))), "gbl_greedy")
+    torch.cuda.synchronize()
+    o = oracle.batch_greedy(state, tm, hist=hist, depth=2, threads=16)
+    assert np.array_equal(npy(act), o[0]) and np.array_equal(npy(cm), o[1]) and np.array_equal(npy(fb), o[2])
+    assert 0 < int(o[2].sum()) < n
+
+
 def test_winner_exhaustive_on_gpu(G):
     """gbl_winner over every pattern of tops (3^9, at each level) and 100 000 random stacks (the packed line
     arithmetic of winner_of against the oracle's walk over the 8 lines), and the same boards through the fused

@@ -91,7 +91,9 @@ def run_and_check(G, n, T, policies, opening, seed=5, base=0, warm=6, with_obs=T
     (2000, 12, ("greedy1", "greedy1"), 1, {"warm": 0}),                                 # no pooled rounds: the one-wavefront kernel
     (400, 8, ("greedy3", "random"), 0, {"candidates": False}),
     (1000, 8, ("random", "random"), 0, {}),
-    (40000, 6, ("greedy", "greedy"), 0, {"base": 7_000_000_000}),                       # four wavefronts per tile
+    (40000, 6, ("greedy", "greedy"), 0, {"base": 7_000_000_000}),                       # <4,8> blocks (one generation)
+    (20037, 5, ("greedy", "greedy"), 0, {"warm": 6}),                                   # <2,8> blocks
+    (98341, 3, ("greedy", "greedy"), 0, {"warm": 6, "candidates": False}),              # <1,4>: between two generations
 ])
 def test_policy_collect_vs_oracle(G, n, T, policies, opening, kw):
     seen, _ = run_and_check(G, n, T, policies, opening, **kw)
