@@ -346,10 +346,7 @@ class raw_env(_AECBase):  # noqa: N801  (reference spelling, gobblet.py:123)
     metadata = {
         "render_modes": ["text", "text_full"],  # pygame modes ("human", "rgb_array") are out of scope
         "name": "gobblet_v1",
-        # the reference says True (gobblet.py:127) but parallel_env is the AEC->parallel conversion of a strictly
-        # turn-based game: upstream skips its own test of it (tests/test_gobblet_env.py:37-43), and it is not
-        # offered here (use BatchedGobblet for lockstep stepping), so the metadata does not claim it
-        "is_parallelizable": False,
+        "is_parallelizable": True,  # gobblet.py:127 (parallel_env below is PettingZoo's conversion of the AEC environment)
         "render_fps": 60,
         "has_manual_policy": False,
     }
@@ -553,5 +550,69 @@ def env(render_mode=None, args=None, device="cuda:0"):  # gobblet.py:110-117
     return _EnvWrappers(e)
 
 
-def parallel_env(*a, **k):  # gobblet.py:120; skipped upstream too (tests/test_gobblet_env.py:37-43)
-    raise NotImplementedError("gobblet is an AEC environment; use BatchedGobblet for lockstep stepping")
+class _AecToParallel:
+    """``parallel_env = parallel_wrapper_fn(env)`` (gobblet.py:120): PettingZoo's AEC -> parallel conversion, restated from
+    pettingzoo.utils.conversions.aec_to_parallel_wrapper (1.22.3; third-party, not under the reference tree and not installed
+    here -- PARITY UNPINNED, like the wrappers of ``env()``; upstream skips its own test of it, tests/test_gobblet_env.py:37-43).
+    One ``step(actions)`` lets every live agent move once, in turn order, and sums the rewards of the cycle.  What the
+    conversion does to a strictly turn-based game is kept as it is: when the first mover ends the game, the second agent's
+    action is handed to an agent that is already dead and the AEC environment raises -- pass ``None`` for it."""
+
+    def __init__(self, aec_env):
+        assert aec_env.metadata.get("is_parallelizable", False), \
+            "Converting from an AEC environment to a parallel environment with the to_parallel wrapper is not generally safe"
+        self.aec_env = aec_env
+        self.possible_agents = aec_env.possible_agents
+        self.metadata = aec_env.metadata
+        self.agents = []
+
+    @property
+    def unwrapped(self):
+        return self.aec_env.unwrapped
+
+    def observation_space(self, agent):
+        return self.aec_env.observation_space(agent)
+
+    def action_space(self, agent):
+        return self.aec_env.action_space(agent)
+
+    def reset(self, seed=None, return_info=False, options=None):
+        e = self.aec_env
+        e.reset(seed=seed, options=options)
+        self.agents = e.agents[:]
+        observations = {a: e.observe(a) for a in e.agents if not (e.terminations[a] or e.truncations[a])}
+        return (observations, dict(**e.infos)) if return_info else observations
+
+    def step(self, actions):
+        e = self.aec_env
+        rewards = {}
+        for agent in list(e.agents):
+            if agent != e.agent_selection:
+                if e.terminations[agent] or e.truncations[agent]:
+                    raise AssertionError(f"expected agent {agent} got termination or truncation agent {e.agent_selection}. "
+                                         "Parallel environment wrapper expects all agent death to happen only at the end of a cycle.")
+                raise AssertionError(f"expected agent {agent} got agent {e.agent_selection}, "
+                                     "Parallel environment wrapper expects agents to step in a cycle.")
+            e.last()
+            e.step(actions[agent])
+            for a in e.agents:
+                rewards[a] = rewards.get(a, 0) + e.rewards[a]
+        terminations, truncations, infos = dict(**e.terminations), dict(**e.truncations), dict(**e.infos)
+        observations = {a: e.observe(a) for a in e.agents}
+        while e.agents and (e.terminations[e.agent_selection] or e.truncations[e.agent_selection]):
+            e.step(None)
+        self.agents = e.agents
+        return observations, rewards, terminations, truncations, infos
+
+    def render(self):
+        return self.aec_env.render()
+
+    def close(self):
+        return self.aec_env.close()
+
+
+def parallel_env(render_mode=None, args=None, device="cuda:0"):  # gobblet.py:120
+    if _HAVE_PZ:  # pragma: no cover
+        from pettingzoo.utils.conversions import aec_to_parallel_wrapper
+        return aec_to_parallel_wrapper(env(render_mode=render_mode, args=args, device=device))
+    return _AecToParallel(env(render_mode=render_mode, args=args, device=device))
