@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
     Planes p{0u, 0u, 0u};
     int mover = 0, dn = 0, tabs = 0;
     uint32_t hp0 = 0x00FFFFFFu, hp1 = 0x00FFFFFFu;  // the two agents' last three actions, one per byte (0xFF = none)
-    Draw4 block{{0u, 0u, 0u, 0u}};
+    Draw4 block{{0u, 0u, 0u, 0u}}, fblock{{0u, 0u, 0u, 0u}};  // generator blocks of the environment's and the fallback draws' streams
     const ImageRow row{reinterpret_cast<uint8_t *>(s_state) + L.lane * kCells};
     uint64_t legal = 0;
     uint32_t games = 0, w1 = 0, w2 = 0;
@@ -1356,7 +1356,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
             hp1 = hist_prev3(h0, h1, h2, 1);
         }
         uint32_t r[7];
-        load_state(state, s_state, L, r, [&] { block = draw_block(seed, env_base + (uint64_t)L.b, ply0); });
+        load_state(state, s_state, L, r, [&] {
+            block = draw_block(seed, env_base + (uint64_t)L.b, ply0);
+            if (deep || policy0 > 0 || policy1 > 0) fblock = draw_block(seed, env_base + (uint64_t)L.b, ply0, kStreamGreedy);
+        });
         mover = L.valid && tm != 0;
         p = planes_of(L, r);
         legal = legal54(p, mover);
@@ -1379,9 +1382,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
         int action;
         {
             // :211-217 with the library's sampler on generator stream 1 (as gbl_greedy_act, keyed by the ply index)
-            uint32_t r = 0;
-            if (__ballot(gre && g.fallback)) r = draw32(seed, env_base + (uint64_t)L.b, ply, kStreamGreedy);
-            const int greedy_action = g.fallback ? pick54(g.cands, r) : g.chosen;
+            // (draw32(seed, board, ply, kStreamGreedy) is word ply & 3 of the stream's block for plies 4 * (ply >> 2) ...: one
+            // generator call per four plies, like the environment's)
+            const int greedy_action = g.fallback ? pick54(g.cands, draw_word(fblock, ply)) : g.chosen;
             const int random_action = pick54(legal, draw_word(block, ply));
             action = gre ? greedy_action : random_action;
             if (gre) {  // :219: the acting agent's history takes the returned action
@@ -1390,7 +1393,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
                 hp1 = mover ? np3 : hp1;
             }
         }
-        if (t + 1 < plies && ((ply + 1) & 3u) == 0) block = draw_block(seed, env_base + (uint64_t)L.b, ply + 1);
+        if (t + 1 < plies && ((ply + 1) & 3u) == 0) {
+            block = draw_block(seed, env_base + (uint64_t)L.b, ply + 1);
+            if (deep || policy0 > 0 || policy1 > 0) fblock = draw_block(seed, env_base + (uint64_t)L.b, ply + 1, kStreamGreedy);
+        }
         const Ply y = play_ply(p, row, mover, legal, action, illegal_mode);
         dn = y.terminal ? 1 : 0;
         if (y.terminal) {  // raw_env.reset, gobblet.py:275-290
