@@ -482,9 +482,11 @@ def greedy_run(G, torch, dev, boards=65536, iters=50):
                                       "HIP events around back-to-back eager launches / count")}
 
 
-VALU_CYCLES_NOMINAL, VALU_CYCLES_MIX = 4.0, 2.9  # SIMD cycles per wave64 VALU instruction: the architectural figure, and
-# what the instructions these kernels are made of (v_bfe, v_lshlrev, v_bcnt, 3-operand logic, v_cmp + v_cndmask, SGPR
-# operands) measure at full occupancy (scripts/microbench/valu_rates.hip, profiles/r02/valu_rates.txt)
+VALU_CYCLES_NOMINAL, VALU_CYCLES_MIX = 4.0, 3.6  # SIMD cycles (of the nominal 2.4 GHz) per wave64 VALU instruction: the
+# architectural figure, and what THIS code measures with every SIMD full -- scripts/microbench/reply_rate.hip times the greedy pair
+# evaluation itself (436 VALU instructions) at 1 436 cycles of a 2.2 GHz clock per evaluation and SIMD with eight wavefronts per
+# SIMD (profiles/r03/reply_rate.txt).  Round 2 quoted 2.9 from single-instruction streams timed per wavefront
+# (valu_rates.txt); mixed streams timed per launch do not reach that (profiles/r03/valu_mix.txt).
 
 
 def valu_roofline(counter_key, kernel, launch_s, launches, timing):
@@ -497,8 +499,8 @@ def valu_roofline(counter_key, kernel, launch_s, launches, timing):
             "launches_timed": launches, "timing": timing, "valu_instructions_per_launch": insts,
             "valu_instructions_source": src,
             "note": "frac = executed VALU instructions x 4 cycles / (1024 SIMDs x launch time x 2.4 GHz); "
-                    "frac_of_measured_issue_rate = the same with 2.9 cycles per instruction, the rate this instruction mix "
-                    "issues at with every SIMD full (valu_rates.txt); HBM traffic is ~150-330 B per decision: irrelevant"}
+                    "frac_of_measured_issue_rate = the same with 3.6 cycles per instruction, the rate the pair evaluation itself "
+                    "issues at with every SIMD full (profiles/r03/reply_rate.txt); HBM traffic is ~150-330 B per decision: irrelevant"}
     if insts:
         roof["achieved"] = insts / launch_s
         roof["frac"] = roof["achieved"] / peak

@@ -72,7 +72,8 @@ def main():
                  "bench_c4_shard_131072", "greedy_65536", "greedy_1048576", "greedy_policy", "playouts"):
         shutil.copy(os.path.join(SRC, name + ".json"), os.path.join(dst, name + ".json"))
     for name in ("facade.txt", "valu_rates.txt", "winner_lanes.txt", "write_classes.txt", "placement_probe_check.txt",
-                 "placement_ab.txt", "soak_parity.txt", "wave_placement.txt"):
+                 "placement_ab.txt", "soak_parity.txt", "wave_placement.txt", "valu_mix.txt", "reply_rate.txt",
+                 "greedy_wave_stamps.txt", "greedy_icache.counters.csv"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
     for run in ("collect", "single", "step", "greedy", "policy", "driver"):
