@@ -2,12 +2,13 @@
 # Everything the numbers in README.md / DESIGN.md / profiles/ come from, in one GPU call:
 #   gpurun -- 'scripts/profile_round.sh'      then      python scripts/profile_collect.py r02
 # Writes bench lines and rocprofv3 databases under gpurun_out/final/.
-#   (two calls when one does not fit gpurun's time limit:  scripts/profile_round.sh a   then   scripts/profile_round.sh b)
+#   (two calls when one does not fit gpurun's time limit:  scripts/profile_round.sh a   then   scripts/profile_round.sh b;
+#    after a kernel change a third, scripts/profile_round.sh c, re-takes the bench lines against the fresh counters)
 set -e -o pipefail
 export TMPDIR=/tmp
 STAGE=${1:-all}
 O=gpurun_out/final
-[ "$STAGE" = b ] || rm -rf $O
+[ "$STAGE" = b ] || [ "$STAGE" = c ] || rm -rf $O
 mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build_$STAGE.log 2>&1   # (no compiler may run under the profiler's preload)
 for m in valu_rates valu_mix winner_lanes write_classes wave_placement; do   # the microbenchmarks this script runs
@@ -15,14 +16,24 @@ for m in valu_rates valu_mix winner_lanes write_classes wave_placement; do   # t
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gobblet-rl_amd/csrc -o scripts/microbench/reply_rate scripts/microbench/reply_rate.hip >> $O/build_$STAGE.log 2>&1
 [ "$STAGE" = b ] || scripts/build_variant.sh stamps -DGBL_STAMPS >> $O/build_$STAGE.log 2>&1   # (diagnostic build for the phase stamps)
-if [ "$STAGE" != b ]; then
-# ---- bench lines --------------------------------------------------------------------------------------------
+bench_lines() {
 python bench.py > $O/bench_default.json
 python bench.py --gpus 1 --steps 20 --warmup 5 --no-configs --no-cpu-baseline > $O/bench_driver_cmd.json
 python bench.py --mode fused --no-configs --no-cpu-baseline > $O/bench_single_ply.json
 python bench.py --mode step --no-configs --no-cpu-baseline > $O/bench_stepmode.json
 python bench.py --no-obs --no-configs --no-cpu-baseline > $O/bench_maskonly.json
 python bench.py --boards 131072 --no-configs --no-cpu-baseline > $O/bench_c4_shard_131072.json
+}
+if [ "$STAGE" = c ]; then
+# the bench lines once more, AFTER scripts/profile_collect.py has written profiles/pmc_traffic.json for these kernel sources
+# (a line taken before stage b's counters exist says "traffic": null with the reason); then profile_collect.py again
+bench_lines
+ls $O/bench_*.json
+exit 0
+fi
+if [ "$STAGE" != b ]; then
+# ---- bench lines --------------------------------------------------------------------------------------------
+bench_lines
 python scripts/bench_greedy.py > $O/greedy_65536.json
 python scripts/bench_greedy.py --boards 1048576 > $O/greedy_1048576.json
 python scripts/bench_greedy_policy.py > $O/greedy_policy.json 2> /dev/null
