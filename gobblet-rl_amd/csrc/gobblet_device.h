@@ -882,6 +882,26 @@ __device__ __forceinline__ void outcomes54(const Planes &p, int mover, uint64_t 
     }
 }
 
+// true iff the predicate holds on ANY active lane of the wavefront (host emulation: lanes run one by one)
+__device__ __forceinline__ bool wave_any(bool x)
+{
+#ifndef GBL_HOST_EMU
+    return __any(x) != 0;
+#else
+    return x;
+#endif
+}
+
+// outcomes54 of a ROOT position: the policy is asked about positions on which nobody holds a line (the game would be over), and
+// then the QUIET form does (80 instructions less); a wavefront with a board that does hold one takes the general form.
+__device__ __forceinline__ void outcomes54_root(const Planes &p, int mover, uint64_t &win, uint64_t &lose)
+{
+    if (wave_any(winner_of(p) != 0))
+        outcomes54<false>(p, mover, win, lose);
+    else
+        outcomes54<true>(p, mover, win, lose);
+}
+
 // ---- the depth-2 pair evaluation's FAST form ---------------------------------------------------------------------------------
 // On a position where nobody holds a line (a depth-1 result with value 0), a reply of `mover` can leave the OTHER side a
 // complete line only by lifting a piece that lies directly on one of theirs, on the third square of a line they otherwise hold
@@ -1024,7 +1044,7 @@ __device__ __forceinline__ GreedyHead greedy_head(const Planes &p, int me, uint6
     h.legal_me = legal54(p, me);
     uint64_t tried = mask & h.legal_me;  // actions the depth-1 loop evaluates, ascending
     uint64_t win1, lose1;
-    outcomes54(p, me, win1, lose1);
+    outcomes54_root(p, me, win1, lose1);
     win1 &= tried;
     lose1 &= tried;
     // walk the decisive results in order; everything before the stop is in `results`
@@ -1129,7 +1149,7 @@ __device__ __forceinline__ uint64_t spread9(uint32_t squares)  // a 9-bit set of
 __device__ __forceinline__ GreedyRoot greedy_root(const Planes &p, int me)
 {
     uint64_t ow, ol;
-    outcomes54(p, 1 - me, ow, ol);  // (the general form: the root itself need not be free of lines)
+    outcomes54_root(p, 1 - me, ow, ol);  // (the root itself need not be free of lines)
     return GreedyRoot{ow & legal54(p, 1 - me), greedy_risky_squares(p, me)};
 }
 

@@ -809,6 +809,29 @@ def test_greedy_every_launch_shape(G, n):
     assert 0 < int(o[2].sum()) < n
 
 
+def test_greedy_on_terminal_roots(G, golden_dir):
+    """gbl_greedy on roots that already hold a line (the wavefront-uniform fallback of the root analysis to the general form of
+    outcomes54), mixed with live positions so that wavefronts of both kinds occur, against the oracle."""
+    from gobblet_rl_amd import _native as nat
+    from tests.test_device_emulation import terminal_roots
+    term = terminal_roots(np.load(os.path.join(golden_dir, "board_functions.npz")))
+    env = G.BatchedGobblet(8192, DEV, auto_reset=True, seed=2)
+    env.rollout(40)
+    torch.cuda.synchronize()
+    state = np.ascontiguousarray(np.concatenate([npy(env.squares)[:4096], term, npy(env.squares)[4096:]]))
+    n = len(state)
+    tm = (np.arange(n) % 2).astype(np.int8)
+    act = torch.empty(n, dtype=torch.int32, device=DEV); cm = torch.empty((n, 54), dtype=torch.int8, device=DEV)
+    fb = torch.empty(n, dtype=torch.int8, device=DEV)
+    st_d, tm_d = t(state), t(tm)
+    for depth in (1, 2):
+        nat.check(nat.lib().gbl_greedy(st_d.data_ptr(), tm_d.data_ptr(), None, None, depth, act.data_ptr(), cm.data_ptr(),
+                                       fb.data_ptr(), n, nat.current_stream(torch.device(DEV))), "gbl_greedy")
+        torch.cuda.synchronize()
+        o = oracle.batch_greedy(state, tm, depth=depth, threads=16)
+        assert np.array_equal(npy(act), o[0]) and np.array_equal(npy(cm), o[1]) and np.array_equal(npy(fb), o[2]), depth
+
+
 def test_winner_exhaustive_on_gpu(G):
     """gbl_winner over every pattern of tops (3^9, at each level) and 100 000 random stacks (the packed line
     arithmetic of winner_of against the oracle's walk over the 8 lines), and the same boards through the fused
