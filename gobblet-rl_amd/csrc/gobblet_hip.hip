@@ -991,12 +991,15 @@ __device__ __forceinline__ void list_append2(uint16_t *list, uint16_t *listx, in
 // it decides whether the shared phases and their barriers exist at all; W == 1 has none).
 //
 // Depth 2 in five steps between barriers:  (A) the owners publish their boards;  (B) they walk depth 1 (greedy_head) while
-// their helpers find the opponent's winning moves on the root and the risky squares (greedy_root);  (C) the owners split
-// their candidates (greedy_root_plan): placements from hand on non-risky squares are settled from the root's replies R,
-// everything else is evaluated;  (D) all wavefronts lay out the work -- the (board, candidate) pairs and the (board,
-// member of R) items;  (E) all lanes take pairs (one moved + legal54 + outcomes54 each: every reply's result at once) and
-// items (greedy_undefused) whoever owns them, leaving 16-bit summaries, candidate-set bits and table rows in LDS; then the
-// owners replay the reference's depth-2 loop in closed form over the sets (greedy_replay_closed).
+// their helpers find the opponent's winning moves on the root and the risky squares (greedy_root) and a third wavefront per
+// tile the moves of ours after which a reply could expose a line of ours (greedy_nonplain);  (C) the owners split their
+// candidates (greedy_root_plan): placements from hand on non-risky squares are settled from the root's replies R, everything
+// else is evaluated -- in the FAST form (threat squares) unless greedy_nonplain says otherwise;  (D) all wavefronts lay out the
+// work -- the (board, candidate) pairs, fast ones from the front of the list and ordered ones from its back, and the (board,
+// member of R) items;  (E) the work goes out in chunks of 64 through a counter -- ordered pairs, fast pairs (one moved +
+// legal54 + wins54_plain / outcomes54 each: every reply's result at once), items (greedy_undefused) -- to whichever wavefront
+// is free, leaving 16-bit summaries, candidate-set bits and table rows in LDS; then the owners replay the reference's depth-2
+// loop in closed form over the sets (greedy_replay_closed).
 // Safe to call in a loop: what the owners read last (replay) and write first (heads) is their own wavefront's business,
 // and everybody else's reads of an iteration lie before its last barrier.
 template <int NT, int W>
