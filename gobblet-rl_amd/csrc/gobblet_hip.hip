@@ -1269,16 +1269,7 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
             prev3 = hist_prev3(h0, h1, h2, me);
     }
     TileStamps ts{};
-#ifdef GBL_X_TWICE  // (diagnostic: the decision twice through the SAME code, the stamps are the second pass's -- what do cold instruction fetches cost?)
-    GreedyResult g{-1, 0ull, false};
-#pragma nounroll
-    for (int rep = 0; rep < 2; ++rep) {
-        g = greedy_tile<NT, W>(S, p, me, mask, depth, depth > 1, prev3, ts);
-        pool_fence<W>();
-    }
-#else
     const GreedyResult g = greedy_tile<NT, W>(S, p, me, mask, depth, depth > 1, prev3, ts);
-#endif
     GBL_STAMP_VAL(1, ts.t[0]);
     GBL_STAMP_VAL(2, ts.t[1]);
     GBL_STAMP_VAL(3, ts.t[2]);

@@ -73,7 +73,7 @@ def main():
         shutil.copy(os.path.join(SRC, name + ".json"), os.path.join(dst, name + ".json"))
     for name in ("facade.txt", "valu_rates.txt", "winner_lanes.txt", "write_classes.txt", "placement_probe_check.txt",
                  "placement_ab.txt", "soak_parity.txt", "wave_placement.txt", "valu_mix.txt", "reply_rate.txt",
-                 "greedy_wave_stamps.txt", "greedy_icache.counters.csv"):
+                 "greedy_wave_stamps.txt", "greedy_icache.counters.csv", "icache_cold.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
     for run in ("collect", "single", "step", "greedy", "policy", "driver"):
