@@ -73,9 +73,18 @@ def main():
         shutil.copy(os.path.join(SRC, name + ".json"), os.path.join(dst, name + ".json"))
     for name in ("facade.txt", "valu_rates.txt", "winner_lanes.txt", "write_classes.txt", "placement_probe_check.txt",
                  "placement_ab.txt", "soak_parity.txt", "wave_placement.txt", "valu_mix.txt", "reply_rate.txt",
-                 "greedy_wave_stamps.txt", "greedy_icache.counters.csv", "icache_cold.txt"):
+                 "greedy_wave_stamps.txt", "icache_cold.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
+    # instruction-cache counters of k_greedy at 65 536 and 2^20 boards: the kernel's rows only
+    rows_ic = []
+    for f in ("greedy_icache.counters.csv", "greedy_icache_1m.counters.csv", "icache_1048576.counters.csv"):
+        if os.path.exists(os.path.join(SRC, f)):
+            rows_ic += [ln for ln in open(os.path.join(SRC, f)).read().splitlines() if ln.startswith('"k_greedy') and ln not in rows_ic]
+    if rows_ic:
+        open(os.path.join(dst, "greedy_icache.counters.csv"), "w").write(
+            "# rocprofv3 --pmc, gbl_greedy depth 2 (scripts/run_eager.py greedy): 65 536 boards (k_greedy<4, 16>) and 2^20 boards (k_greedy<1, 4>)\n"
+            "kernel,counter,dispatches,mean_value,mean_without_first_dispatch\n" + "\n".join(rows_ic) + "\n")
     for run in ("collect", "single", "step", "greedy", "policy", "driver"):
         src = os.path.join(SRC, f"{run}_stats.kernel_stats.csv")
         if os.path.exists(src):

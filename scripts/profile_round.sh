@@ -122,6 +122,7 @@ rocprofv3 --pmc $SQ2 -d $O/policy_sq2 -o p -- python3 scripts/run_eager.py polic
 # instruction cache counters of the greedy kernel (~2 000 misses per launch whatever the batch, at no measurable cost)
 IC="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"
 rocprofv3 --pmc $IC -d $O/greedy_icache -o p -- python3 scripts/run_eager.py greedy 65536 20 > $O/greedy_icache.log 2>&1
+rocprofv3 --pmc $IC -d $O/greedy_icache_1m -o p -- python3 scripts/run_eager.py greedy 1048576 10 > $O/greedy_icache_1m.log 2>&1
 echo "counters done"
 fi
 python scripts/profile_reduce.py   # (databases -> small summaries: gpurun copies at most 64 MiB back)
