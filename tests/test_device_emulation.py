@@ -9,6 +9,7 @@ import pytest
 
 import oracle
 from tests import emu
+from tests.positions import terminal_roots
 
 
 def selfplay_states(n, plies, seed, p_illegal=0.05):
@@ -303,23 +304,6 @@ def test_greedy_virtual_root_rule(boards):
         assert bad == 0 and n_boards == len(state) and 0 < settled <= placed <= pairs and roots > 0, cap
     m = np.ascontiguousarray((oracle.batch_legal_mask(state, tm) * (rng.random((len(state), 54)) < 0.6)).astype(np.int8))
     assert emu.greedy_vroot_rule(state, tm, mask=m)[7] == 0
-
-
-def terminal_roots(boards, n_random=20000, seed=4):
-    """Positions on which somebody holds a line already (the reference's policy is never asked about them in a game, but
-    the entry points take any board): the golden set's, plus random stacks."""
-    rng = np.random.default_rng(seed)
-    st = np.zeros((n_random, 27), np.int8)
-    for lvl, vals in enumerate(((1, 2), (3, 4), (5, 6))):  # one piece of each number per colour at most: a valid board
-        for v in vals:
-            for sign in (1, -1):
-                put = rng.random(n_random) < 0.55
-                pos = rng.integers(0, 9, n_random)
-                free = st[np.arange(n_random), 9 * lvl + pos] == 0
-                ok = put & free
-                st[np.flatnonzero(ok), 9 * lvl + pos[ok]] = sign * v
-    st = st[oracle.batch_winner(st) != 0]
-    return np.ascontiguousarray(np.concatenate([boards["squares"][boards["winner"] != 0], st]))
 
 
 def test_greedy_on_terminal_roots(boards):

@@ -813,7 +813,7 @@ def test_greedy_on_terminal_roots(G, golden_dir):
     """gbl_greedy on roots that already hold a line (the wavefront-uniform fallback of the root analysis to the general form of
     outcomes54), mixed with live positions so that wavefronts of both kinds occur, against the oracle."""
     from gobblet_rl_amd import _native as nat
-    from tests.test_device_emulation import terminal_roots
+    from tests.positions import terminal_roots
     term = terminal_roots(np.load(os.path.join(golden_dir, "board_functions.npz")))
     env = G.BatchedGobblet(8192, DEV, auto_reset=True, seed=2)
     env.rollout(40)
