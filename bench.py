@@ -24,16 +24,20 @@ By default the K timed plies are replayed as one hipGraph whose kernel nodes tak
 device-resident counter (gbl_rollout_at + gbl_counter_add), so the graph is replayed once UNTIMED first (its
 first launch carries one-off costs) and the timed replay still plays K fresh plies; --graph 0 launches eagerly.
 
-Prints ONE JSON line on rank 0 (see the task's bench contract) including
+Rank 0 prints ONE compact JSON line (< 4 kB; the task's bench contract) as the LAST line of stdout:
+    the contract keys, `config` (a workload string + scalars), and two flat objects
     roofline     -- dominant kernel: algorithmic bytes per launch / mean launch duration from HIP events on the
                     launch stream, vs 8 TB/s HBM peak.  Bytes per env-step: 234 for k_rollout / k_step (SURVEY.md
                     8d: reads 33 + writes 201); for k_collect the same per-ply outputs (mask 54 + obs 117 + action 4 +
-                    winner 1 + done 1 + to_move 1 = 178) and the state only once per launch (57 B per board)
+                    winner 1 + done 1 + to_move 1 = 178) and the state only once per launch (57 B per board);
+                    `traffic` = HBM bytes per launch from the committed PMC passes of the same launch shape
     cpu_baseline -- the CPU oracle (a C port of the reference algorithm; kind "port") doing the same pipeline
                     on the host cores, on a bounded sample (rank 0, N=1 only)
+The FULL record goes to --configs-out (default gpurun_out/bench_configs.json, named in config.configs_file) and to stderr:
     configs      -- (N=1 only) the other sizes BASELINE.json names, each a short run with its own roofline:
                     4 096 and 262 144 boards, the 131 072-board shard of C4 at 8 GPUs, 2^22 boards (beyond the
-                    Infinity Cache), MASK_ONLY at 2^20, and config 5 (65 536 boards x depth-2 greedy).
+                    Infinity Cache), MASK_ONLY at 2^20, and config 5 (65 536 boards x depth-2 greedy)
+    detail       -- per-rank kernel times and trajectory placements; cpu_baseline's greedy extras.
 """
 import argparse
 import hashlib
@@ -94,6 +98,9 @@ def parse():
                          "mask arrays in different 96 GiB classes of HBM, found with a probe; any = as the allocator hands them out")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the sub-records of the other BASELINE configs")
+    ap.add_argument("--configs-out", default="gpurun_out/bench_configs.json",
+                    help="where the FULL record goes (the sub-records of the other configs, per-rank lists); relative to the "
+                         "repo root; '' = stderr only.  stdout carries the compact contract line only")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the multi-rank path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
@@ -482,28 +489,30 @@ def greedy_run(G, torch, dev, boards=65536, iters=50):
                                       "HIP events around back-to-back eager launches / count")}
 
 
-VALU_CYCLES_NOMINAL, VALU_CYCLES_MIX = 4.0, 3.6  # SIMD cycles (of the nominal 2.4 GHz) per wave64 VALU instruction: the
-# architectural figure, and what THIS code measures with every SIMD full -- scripts/microbench/reply_rate.hip times the greedy pair
-# evaluation itself (436 VALU instructions) at 1 436 cycles of a 2.2 GHz clock per evaluation and SIMD with eight wavefronts per
-# SIMD (profiles/r03/reply_rate.txt).  Round 2 quoted 2.9 from single-instruction streams timed per wavefront
-# (valu_rates.txt); mixed streams timed per launch do not reach that (profiles/r03/valu_mix.txt).
+VALU_CYCLES_PEAK, VALU_CYCLES_ONE_WAVE, VALU_CYCLES_MIX = 2.0, 4.0, 3.6
+# SIMD cycles (of the nominal 2.4 GHz) per wave64 VALU instruction.  PEAK: a CDNA4 SIMD is 32 lanes wide and issues a wave64
+# instruction over two cycles (MI355X_MICROARCH.md: 4 is one wavefront alone on its SIMD) -- the yardstick of `frac`.  MIX: what
+# THIS code measures with every SIMD full -- scripts/microbench/reply_rate.hip times the greedy pair evaluation itself
+# (profiles/r03/reply_rate.txt: 3.3-3.6); ONE_WAVE: rounds 1-3 quoted their fraction against it.  Both are named extras.
 
 
 def valu_roofline(counter_key, kernel, launch_s, launches, timing):
     """Roofline of an integer-VALU-bound kernel: executed wave64 VALU instructions per launch (rocprofv3 SQ_INSTS_VALU of a
-    committed profile of the same launch) against what 1024 SIMDs can issue in the launch's time -- by two yardsticks."""
+    committed profile of the same launch) against what 1024 SIMDs can issue in the launch's time at 2 cycles per instruction."""
     insts, src = committed_counter(counter_key, "SQ_INSTS_VALU")
-    peak = SIMDS * CLOCK_GHZ * 1e9 / VALU_CYCLES_NOMINAL
+    peak = SIMDS * CLOCK_GHZ * 1e9 / VALU_CYCLES_PEAK
     roof = {"bound": "valu", "unit": "wave64 VALU instructions/s", "peak": peak, "achieved": None, "frac": None,
-            "frac_of_measured_issue_rate": None, "kernel": kernel, "mean_launch_us": launch_s * 1e6,
-            "launches_timed": launches, "timing": timing, "valu_instructions_per_launch": insts,
-            "valu_instructions_source": src,
-            "note": "frac = executed VALU instructions x 4 cycles / (1024 SIMDs x launch time x 2.4 GHz); "
-                    "frac_of_measured_issue_rate = the same with 3.6 cycles per instruction, the rate the pair evaluation itself "
-                    "issues at with every SIMD full (profiles/r03/reply_rate.txt); HBM traffic is ~150-330 B per decision: irrelevant"}
+            "frac_of_one_wave_per_simd_rate": None, "frac_of_measured_issue_rate": None, "kernel": kernel,
+            "mean_launch_us": launch_s * 1e6, "launches_timed": launches, "timing": timing,
+            "valu_instructions_per_launch": insts, "valu_instructions_source": src,
+            "note": "frac = executed VALU instructions x 2 cycles / (1024 SIMDs x launch time x 2.4 GHz): the SIMD-32 issue peak; "
+                    "frac_of_one_wave_per_simd_rate = the same with 4 cycles (rounds 1-3's yardstick); frac_of_measured_issue_rate = "
+                    "with 3.6 cycles, the rate the pair evaluation itself issues at with every SIMD full "
+                    "(profiles/r03/reply_rate.txt); HBM traffic is ~150-330 B per decision: irrelevant"}
     if insts:
         roof["achieved"] = insts / launch_s
         roof["frac"] = roof["achieved"] / peak
+        roof["frac_of_one_wave_per_simd_rate"] = roof["achieved"] / (SIMDS * CLOCK_GHZ * 1e9 / VALU_CYCLES_ONE_WAVE)
         roof["frac_of_measured_issue_rate"] = roof["achieved"] / (SIMDS * CLOCK_GHZ * 1e9 / VALU_CYCLES_MIX)
     return roof
 
@@ -536,6 +545,96 @@ def greedy_collect_run(G, torch, dev, boards=65536, T=16, launches=8, policies=(
                                      "HIP events around back-to-back eager launches / count"),
            "trajectory_placement": buf["_placement"]}
     return rec
+
+
+COMPACT_LIMIT = 4096  # bytes: the driver keeps the tail of stdout only; the contract line must fit it with room to spare
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel",
+                 "algorithmic_bytes_per_env_step", "algorithmic_bytes_per_launch", "mean_launch_us", "launches_timed", "timing")
+CPU_BASELINE_KEYS = ("value", "unit", "cores", "kind", "sample", "value_1core")
+
+
+def contract_record(args, p, roof, total, boards, world, K, W, elapsed, local_elapsed, nlaunch, graphed, per_rank_us,
+                    per_rank_placement, distributed):
+    """The whole record of the headline run: the contract's keys, a `config` of one workload string and scalars (per-rank
+    lists are kept under `detail`, which only the configs file and stderr carry), and the dominant kernel's roofline."""
+    variant = "MASK_ONLY" if args.no_obs else "FULL"
+    ratios = [pl["ratio"] for pl in per_rank_placement if pl and pl.get("ratio") is not None]
+    return {
+        "metric": "env-steps/sec at 2^20 parallel boards, 1/2/4/8 MI355X; bit-exact mask/winner",
+        "value": total * K / elapsed,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak" if args.boards_per_gpu else "strong",
+        "vs_baseline": None,
+        "dtype": "int8",
+        "data": "synthetic",
+        "config": {"workload": f"{total} boards in total = {boards} per GPU x {world} GPU(s) (BASELINE.md C4), masked-random "
+                               f"actions, auto-reset, {variant} outputs (state+mask{'' if args.no_obs else '+obs'}"
+                               f"+winner+reward+done) every ply, no collective on the step path",
+                   "boards_per_gpu": boards, "total_boards": total, "mode": args.mode,
+                   "plies_per_launch": args.traj if args.mode == "collect" else 1,
+                   "launches_timed": nlaunch * (2 if args.mode == "step" else 1),
+                   "launch": "hipGraph replay" if graphed else "eager",
+                   # the dominant kernel's mean launch duration on the slowest / fastest rank (HIP events)
+                   "kernel_us_max": max(per_rank_us), "kernel_us_min": min(per_rank_us),
+                   # MAX over ranks of (barrier, sync, K plies, sync) -- i.e. `ms_per_step` without the trailing barrier's own
+                   # latency, which at N > 1 is a collective of tens of microseconds on a timed region that is 72 us of
+                   # kernel time at 8 GPUs x 20 plies; `value` / `ms_per_step` keep it in, as the contract says
+                   "ms_per_step_before_trailing_barrier": local_elapsed / K * 1e3,
+                   # ranks that took part in the barriers / reductions over RCCL (0: none, or a gloo rehearsal)
+                   "rccl_ranks": world if (distributed and args.dist_backend == "nccl") else 0,
+                   "dist_backend": (args.dist_backend if distributed else None),
+                   # where the observation / mask trajectory arrays lie (gobblet-rl_amd/placement.py): probe ratio
+                   # both / (obs alone + mask alone), ~1.0 = same 96 GiB class of HBM, ~0.8 = different classes
+                   "placement_ratio_min": min(ratios) if ratios else None,
+                   "placement_ratio_max": max(ratios) if ratios else None},
+        "roofline": roof,
+        "detail": {"kernel_us_per_rank": per_rank_us, "trajectory_placement_per_rank": per_rank_placement,
+                   "sharding": f"contiguous board ranges, {world} shard(s), no collective on the step path",
+                   "launch": ("hipGraph replay of the K plies' launches (device-resident ply index; one untimed warm replay of "
+                              "the same graph = K more untimed plies before the timed one)") if graphed else "eager"},
+    }
+
+
+def compact_line(full, configs_path):
+    """The ONE line of stdout: the contract's keys, flat `roofline` and `cpu_baseline`, nothing nested deeper and no lists."""
+    line = {k: v for k, v in full.items() if k not in ("configs", "cpu_baseline", "roofline", "detail", "config")}
+    line["config"] = dict(full["config"])
+    if "configs" in full:
+        line["config"]["configs_file"] = configs_path
+        line["config"]["configs_recorded"] = len(full["configs"])
+    line["roofline"] = {k: full["roofline"].get(k) for k in ROOFLINE_KEYS}
+    if "cpu_baseline" in full:
+        line["cpu_baseline"] = {k: full["cpu_baseline"].get(k) for k in CPU_BASELINE_KEYS}
+    text = json.dumps(line)
+    if len(text.encode()) > COMPACT_LIMIT:  # never print a line the driver's tail would cut: drop the prose first
+        for k in ("timing", "sample"):
+            line["roofline"].pop(k, None)
+            line.get("cpu_baseline", {}).pop(k, None)
+        text = json.dumps(line)
+    assert len(text.encode()) <= COMPACT_LIMIT, "bench.py: the contract line outgrew the driver's tail"
+    return text
+
+
+def emit(full, configs_out):
+    """Full record (sub-records of the other BASELINE configs, per-rank lists, the CPU baseline's extras) -> a file and stderr;
+    the compact contract line -> the LAST line of stdout."""
+    path = None
+    if configs_out:
+        path = configs_out if os.path.isabs(configs_out) else os.path.join(ROOT, configs_out)
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
+        except OSError as e:  # a read-only checkout: stderr still carries the record
+            print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+            path = None
+    print(json.dumps(full), file=sys.stderr, flush=True)
+    print(compact_line(full, os.path.relpath(path, ROOT) if path else None), flush=True)
 
 
 def spawn_ranks(n):
@@ -666,43 +765,8 @@ def main():
         roof = p.kernel_roofline(kernel_s, plies_timed, launches, timing)
         # (the counters were taken on launches of exactly T plies; the timed launches may end with a shorter one)
         attach_traffic(roof, p, min(args.traj, K) if args.mode == "collect" else 1)
-        variant = "MASK_ONLY" if args.no_obs else "FULL"
-        out = {
-            "metric": "env-steps/sec at 2^20 parallel boards, 1/2/4/8 MI355X; bit-exact mask/winner",
-            "value": total * K / elapsed,
-            "unit": "env-steps/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": W,
-            "ms_per_step": elapsed / K * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak" if args.boards_per_gpu else "strong",
-            "vs_baseline": None,
-            "dtype": "int8",
-            "data": "synthetic",
-            "config": {"workload": f"{total} boards in total = {boards} per GPU x {world} GPU(s) (BASELINE.md C4), masked-random "
-                                   f"actions, auto-reset, {variant} outputs (state+mask{'' if args.no_obs else '+obs'}"
-                                   f"+winner+reward+done) every ply",
-                       "boards_per_gpu": boards, "total_boards": total, "mode": args.mode,
-                       "plies_per_launch": args.traj if args.mode == "collect" else 1,
-                       "launches_timed": nlaunch * (2 if args.mode == "step" else 1),
-                       "sharding": f"contiguous board ranges, {world} shard(s), no collective on the step path",
-                       "launch": ("hipGraph replay of the K plies' launches (device-resident ply index; one untimed warm "
-                                  "replay of the same graph = K more untimed plies before the timed one)") if graph is not None else "eager",
-                       "kernel_us_per_rank": per_rank_us, "kernel_us_max": max(per_rank_us),
-                       # MAX over ranks of (barrier, sync, K plies, sync) -- i.e. `ms_per_step` without the trailing barrier's
-                       # own latency, which at N > 1 is an RCCL collective of tens of microseconds on a timed region that
-                       # is 72 us of kernel time at 8 GPUs x 20 plies; `value` / `ms_per_step` keep it in, as the contract says
-                       "ms_per_step_before_trailing_barrier": local_elapsed / K * 1e3,
-                       # ranks that took part in the barriers / reductions, and the backend that carried them
-                       "rccl_ranks": world if (dist is not None and args.dist_backend == "nccl") else 0,
-                       "dist_backend": (args.dist_backend if dist is not None else None),
-                       "trajectory_placement_per_rank": per_rank_placement,
-                       # where the observation / mask trajectory arrays lie (gobblet-rl_amd/placement.py): probe ratios
-                       # both / (obs alone + mask alone), ~1.0 = same 96 GiB class of HBM, ~0.8 = different classes
-                       "trajectory_placement": p.traj["_placement"] if p.traj is not None else None},
-            "roofline": roof,
-        }
+        full = contract_record(args, p, roof, total, boards, world, K, W, elapsed, local_elapsed, nlaunch, graph is not None,
+                               per_rank_us, per_rank_placement, dist is not None)
         if world == 1 and not args.no_configs:
             cfg = {}
             for name, (n, k, noobs, mode) in CONFIG_RECORDS.items():
@@ -714,19 +778,19 @@ def main():
                 cfg[f"step_reply_{n}"] = step_reply_run(G, torch, dev, n, 200, W)
             cfg["c5_greedy_65536"] = greedy_run(G, torch, dev)
             cfg["greedy_collect_65536"] = greedy_collect_run(G, torch, dev)
-            out["configs"] = cfg
+            full["configs"] = cfg
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(boards, W, args.cpu_seconds)
-            ref = out["cpu_baseline"].get("greedy_depth2")
-            if ref and "configs" in out:
+            full["cpu_baseline"] = cpu_baseline(boards, W, args.cpu_seconds)
+            ref = full["cpu_baseline"].get("greedy_depth2")
+            if ref and "configs" in full:
                 # the reference's work per decision (counted by the CPU restatement on the same
                 # stationary mix) x the measured decisions/s
-                c5 = out["configs"]["c5_greedy_65536"]
+                c5 = full["configs"]["c5_greedy_65536"]
                 c5["reference_work_per_decision"] = {k: ref[k] for k in ("legality_tests_per_decision", "leaf_evaluations_per_decision")}
                 c5["legality_tests_per_s_equivalent"] = c5["value"] * ref["legality_tests_per_decision"]
                 c5["leaf_evaluations_per_s_equivalent"] = c5["value"] * ref["leaf_evaluations_per_decision"]
                 c5["cpu_port_decisions_per_s_1core"] = ref["decisions_per_s_1core"]
-        print(json.dumps(out), flush=True)
+        emit(full, args.configs_out)
     if dist is not None:
         dist.destroy_process_group()
 

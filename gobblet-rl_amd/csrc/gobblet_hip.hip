@@ -105,6 +105,18 @@ inline int collect_variant(int64_t n, uint32_t plies, bool with_mask, bool with_
 template <int ROWB>
 constexpr int image_words() { return kTile * ROWB / 4 + 4; }
 
+// A wavefront's index in its workgroup, as a SCALAR: threadIdx.x >> 6 is the same on all lanes, but the compiler does not know it
+// and keeps everything derived from it -- the tile index, every tile base address, the role tests -- in vector registers (in
+// gbl_collect_policy: 64-bit per-lane addresses of seven output arrays, hoisted out of the ply loop and spilled to scratch).
+__device__ __forceinline__ int wave_index()
+{
+#ifndef GBL_HOST_EMU
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+    return (int)(threadIdx.x >> 6);
+#endif
+}
+
 // -------------------------------------------------------------------------------------------
 // Per-lane state of one board inside a kernel.
 struct Lane {
@@ -671,7 +683,7 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
     __shared__ uint32_t s_mask[WITH_MASK ? image_words<kActions>() : 4];
     __shared__ uint32_t s_small[kTile][2];  // per board: the action; winner | reward << 8 | done << 24 | to_move << 25
     if (DEV_PLY) ply0 += *ply_dev;
-    const int role = threadIdx.x >> 6;
+    const int role = wave_index();
     Lane L;
     L.tile = (int64_t)blockIdx.x;
     L.lane = threadIdx.x & 63;
@@ -891,8 +903,13 @@ struct GreedyLds {
     static_assert(W == 1 || W >= 2 * NT, "a helper wavefront per owner");
     static constexpr int kBoards = kTile * NT;
     static_assert(kBoards <= 256, "(board << 8) | candidate fits 16 bits");
-    alignas(16) uint16_t pair[kBoards * kActions];    // (board << 8) | candidate of every depth-2 evaluation of the block: those that
+    // An owner's output image of gbl_collect_policy (scratch(), below) is staged in the pair list, which is padded so that NT images fit it
+    static constexpr int kImageBytes = 4 * image_words<kObs>();
+    static constexpr int kPairSlots = kBoards * kActions;
+    static constexpr int kPairPad = NT * kImageBytes > 2 * kPairSlots ? (NT * kImageBytes - 2 * kPairSlots) / 2 : 0;
+    alignas(16) uint16_t pair[kPairSlots + kPairPad]; // (board << 8) | candidate of every depth-2 evaluation of the block: those that
                                                       // take the fast form from the front, the ORDERED form (greedy_nonplain) from the back
+                                                      // (the back = slot kPairSlots - 1; the padding behind it is scratch only)
     unsigned long long undef[kBoards][kRootItems];    // per board and member j of the root's replies: greedy_undefused
     uint16_t item[kBoards * kRootItems];              // (board << 8) | j of every member of a root's replies that is dealt out
     uint32_t board[kBoards][4];            // planes nz, neg, odd; bit 0: the agent to move, bit 1: the board wants depth 2
@@ -910,13 +927,15 @@ struct GreedyLds {
     unsigned long long workx[kBoards];     // the candidates of a board that are evaluated in the ordered form (work: in the fast form)
     unsigned long long nonplain[kBoards];  // greedy_nonplain of the board
     int job;                               // the next chunk of 64 pairs / items to hand out
-    // The pair list and the table are dead between two decisions (written after the first barriers of greedy_tile, read
-    // before it returns): a kernel that decides in a loop stages its owners' output rows through them in between.
-    static constexpr int kScratchBytes = (int)(sizeof(uint16_t) * kBoards * kActions + sizeof(unsigned long long) * kBoards * kRootItems);
-    static_assert(sizeof(uint16_t) * kBoards * kActions % 16 == 0, "the table follows the pair list without padding");
+    // The pair list is dead between two decisions (written after the third barrier of greedy_tile, read before its last one): a
+    // kernel that decides in a loop stages its owners' output rows through it in between, owner w through bytes
+    // [w, w + 1) * kImageBytes of it.  ONLY the pair list: the table `undef` is still read by every owner after the last
+    // barrier (greedy_hand_merge), so an image laid over it -- round 3's layout: the list and the table as one region cut
+    // in NT equal slices -- let a fast owner's next image overwrite a slower owner's rows (no barrier orders the two).
+    static_assert(kImageBytes % 16 == 0 && NT * kImageBytes <= (int)sizeof(pair), "NT output images fit the (padded) pair list");
     __device__ __forceinline__ uint32_t *scratch(int owner_wave)
     {
-        return reinterpret_cast<uint32_t *>(pair) + owner_wave * (kScratchBytes / 4 / NT / 4 * 4);
+        return reinterpret_cast<uint32_t *>(pair) + owner_wave * (kImageBytes / 4);
     }
 };
 
@@ -1006,7 +1025,7 @@ template <int NT, int W>
 __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const Planes &p, int me, uint64_t mask, int depth,
                                                     bool deep, uint32_t prev3, TileStamps &ts)
 {
-    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const int lane = (int)(threadIdx.x & 63u), wave = wave_index();
     const bool owner = wave < NT;
     const int bi = (owner ? wave : wave - NT) * kTile + lane;  // the board this thread owns, or helps with (wave < 2 NT)
     GreedyHead h{0ull, 0ull, 0ull, 0ull, 0, -1};
@@ -1201,7 +1220,7 @@ __device__ __forceinline__ uint32_t hist_prev3(uint32_t h0, uint32_t h1, uint32_
 template <int NT>
 __device__ __forceinline__ bool block_lane_setup(Lane &L, int64_t n, int64_t ntiles)
 {
-    const int wave = (int)(threadIdx.x >> 6);
+    const int wave = wave_index();
     if ((int64_t)blockIdx.x * NT >= ntiles) return false;
     L.tile = (int64_t)blockIdx.x * NT + (wave < NT ? wave : 0);
     L.lane = (int)(threadIdx.x & 63u);
@@ -1234,7 +1253,7 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
     GBL_STAMP_REAL(0);
     Lane L;
     if (!block_lane_setup<NT>(L, n, ntiles)) return;  // the same for every thread of the workgroup
-    const int wave = (int)(threadIdx.x >> 6);
+    const int wave = wave_index();
     const bool owner = wave < NT;
     uint32_t *const s_state = s_states[owner ? wave : 0], *const s_mask = s_masks[owner ? wave : 0];
     Planes p{0u, 0u, 0u};
@@ -1324,11 +1343,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
 {
     __shared__ uint32_t s_states[NT][image_words<kCells>()];
     __shared__ GreedyLds<NT, W> S;
-    static_assert(GreedyLds<NT, W>::kScratchBytes / NT / 16 * 16 >= 4 * image_words<kObs>(), "an owner's output image fits its share of the idle lists");
     if (ply_dev) ply0 += *ply_dev;
     Lane L;
     if (!block_lane_setup<NT>(L, n, ntiles)) return;  // the same for every thread of the workgroup
-    const int wave = (int)(threadIdx.x >> 6);
+    const int wave = wave_index();
     const bool owner = wave < NT, active = owner && L.rows > 0;
     uint32_t *const s_state = s_states[owner ? wave : 0], *const s_out = S.scratch(owner ? wave : 0);
     const bool deep = policy0 > 1 || policy1 > 1;
@@ -1416,22 +1434,30 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
             if (how_t) how_t[at] = (int8_t)(gre ? (g.fallback ? GBL_HOW_FALLBACK : GBL_HOW_GREEDY) : GBL_HOW_RANDOM);
         }
         constexpr int kPolicy = kStoreStreamDrop;
+        // The lane index the output rows are staged and stored with is made opaque once per ply: everything derived from it (image
+        // offsets, the `lane < REM` predicates, buffer offsets of up to eight vectors per tile) is loop-invariant, and hoisted out of
+        // the ply loop it stayed live across the decision -- under the 128-VGPR budget of the <1, W> shapes that was 22 spilled
+        // registers (96 B of scratch per lane and ply); recomputing it costs a few shifts and adds per ply.
+        int ol = L.lane;
+#ifndef GBL_HOST_EMU
+        asm volatile("" : "+v"(ol));
+#endif
         auto mask_rows = [&](uint64_t bits, int8_t *__restrict__ dst) {  // (store_mask / store_obs with few registers)
             uint32_t d[14];
             mask_row(bits, d);
-            row_stage<kActions>(s_out, L.lane, d);
+            row_stage<kActions>(s_out, ol, d);
             wave_lds_fence();
-            tile_out_narrow<kActions, kPolicy, 2>(dst, s_out, L.lane, L.rows);
+            tile_out_narrow<kActions, kPolicy, 2>(dst, s_out, ol, L.rows);
             wave_lds_fence();
         };
         wave_lds_fence();
         if (cand_t) mask_rows(gre ? g.cands : 0ull, cand_t + cell * kActions);
         if (obs_t) {
-            obs_image_zero(s_out, L.lane);
+            obs_image_zero(s_out, ol);
             wave_lds_fence();
-            obs_scatter(s_out, L.lane, p, mover);
+            obs_scatter(s_out, ol, p, mover);
             wave_lds_fence();
-            tile_out_narrow<kObs, kPolicy, 2>(obs_t + cell * kObs, s_out, L.lane, L.rows);
+            tile_out_narrow<kObs, kPolicy, 2>(obs_t + cell * kObs, s_out, ol, L.rows);
             wave_lds_fence();
         }
         legal = legal54(p, mover);  // the next mover's: stored now, the next ply's policy is handed it

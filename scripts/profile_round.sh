@@ -12,7 +12,7 @@ O=gpurun_out/final
 mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build_$STAGE.log 2>&1   # (no compiler may run under the profiler's preload)
 for m in valu_rates valu_mix icache_cold winner_lanes write_classes wave_placement; do   # the microbenchmarks this script runs
-  [ scripts/microbench/$m -nt scripts/microbench/$m.hip ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scripts/microbench/$m scripts/microbench/$m.hip >> $O/build_$STAGE.log 2>&1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scripts/microbench/$m scripts/microbench/$m.hip >> $O/build_$STAGE.log 2>&1   # always rebuilt: a stale binary must never publish numbers
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gobblet-rl_amd/csrc -o scripts/microbench/reply_rate scripts/microbench/reply_rate.hip >> $O/build_$STAGE.log 2>&1
 [ "$STAGE" = b ] || scripts/build_variant.sh stamps -DGBL_STAMPS >> $O/build_$STAGE.log 2>&1   # (diagnostic build for the phase stamps)

@@ -26,6 +26,44 @@ def test_header_symbols_all_exported():
         assert getattr(L, name) is not None
 
 
+def kernel_metadata(lib_path=None):
+    """{kernel symbol: {field: value}} from the AMDGPU metadata note of the gfx950 code object embedded in the library."""
+    import shutil
+    import subprocess
+    import tempfile
+    tools = "/opt/rocm/lib/llvm/bin"
+    lib_path = lib_path or nat.build()
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copy(lib_path, os.path.join(tmp, "lib.so"))
+        subprocess.run([os.path.join(tools, "llvm-objdump"), "--offloading", "lib.so"], cwd=tmp, check=True, capture_output=True)
+        objs = [f for f in os.listdir(tmp) if "gfx950" in f]
+        assert len(objs) == 1, objs
+        notes = subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", objs[0]], cwd=tmp, check=True,
+                               capture_output=True, text=True).stdout
+    out = {}
+    for blk in re.findall(r"- \.agpr_count:.*?(?=\n  - \.agpr_count:|\namdhsa\.target)", notes, re.S):
+        fields = dict(re.findall(r"\.(\w+):\s+(\S+)", blk))
+        out[fields["name"]] = fields
+    return out
+
+
+def test_no_kernel_uses_scratch():
+    """No instantiation of any kernel may spill: a spilled register is a scratch (HBM-backed) round trip per use inside
+    the hot loop.  Round 3's k_collect_policy<1, 4> / <1, 16> spilled 22 VGPRs (96 B of scratch per lane) and nothing noticed."""
+    meta = kernel_metadata()
+    kernels = {k: v for k, v in meta.items() if re.search(r"\dk_[a-z_0-9]+", k)}
+    assert len(kernels) > 80 and any("k_collect_policy" in k for k in kernels) and any("k_greedy" in k for k in kernels)
+    bad = {k: (v["private_segment_fixed_size"], v["vgpr_spill_count"], v["sgpr_spill_count"]) for k, v in kernels.items()
+           if int(v["private_segment_fixed_size"]) or int(v["vgpr_spill_count"])}
+    assert not bad, bad
+    # wave64 everywhere, and every workgroup shape fits a CU (<= 512 VGPRs per SIMD lane-slice, 160 KB of LDS)
+    for k, v in kernels.items():
+        assert v["wavefront_size"] == "64", k
+        waves_per_simd = -(-int(v["max_flat_workgroup_size"]) // 64 // 4)
+        assert waves_per_simd * (-(-int(v["vgpr_count"]) // 8) * 8) <= 512, (k, v["vgpr_count"], v["max_flat_workgroup_size"])
+        assert int(v["group_segment_fixed_size"]) <= 160 * 1024, k
+
+
 def test_layout_info_and_host_side_argument_errors():
     L = nat.lib()
     info = (C.c_int32 * 6)()

@@ -1023,66 +1023,135 @@ def test_collect_vs_oracle_and_graph_replay(G):
     assert all(np.array_equal(npy(buf["observation"][t_]), last[t_]["obs"]) for t_ in range(T))
 
 
+def _bench(args, env=None, timeout=600, launcher_ranks=0):
+    """Run bench.py (optionally under torch.distributed.run) with the full record sent to a temporary file; returns
+    (stdout lines that are JSON, the full record, stderr)."""
+    import socket
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        full_path = os.path.join(tmp, "full.json")
+        cmd = [os.path.join(root, "bench.py"), *args, "--configs-out", full_path]
+        if launcher_ranks:
+            with socket.socket() as sock:  # a free port for the rendezvous
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            cmd = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(launcher_ranks), "--master-addr",
+                   "127.0.0.1", "--master-port", str(port)] + cmd
+        out = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=timeout, cwd=root,
+                             env=env if env is not None else dict(os.environ, MASTER_ADDR="127.0.0.1"))
+        assert out.returncode == 0, out.stderr[-3000:]
+        full = json.load(open(full_path))
+    return [ln for ln in out.stdout.splitlines() if ln.startswith("{")], full, out
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline")
+
+
 def test_bench_script_runs_and_reports(G):
     """bench.py's contract line on a small shard, in each mode: one JSON line with the contract's keys, a roofline
     whose achieved rate is consistent with the reported time, and the sub-records it promises."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for extra in (["--mode", "collect"], ["--mode", "fused"], ["--mode", "step"], ["--mode", "collect", "--no-obs", "--graph", "0"]):
-        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--boards", "16384", "--steps", "20", "--warmup", "5",
-                              "--no-configs", "--no-cpu-baseline", *extra], capture_output=True, text=True, timeout=300, cwd=root)
-        assert out.returncode == 0, out.stderr[-2000:]
-        d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                  "vs_baseline", "dtype", "data", "config", "roofline"):
+        lines, full, out = _bench(["--boards", "16384", "--steps", "20", "--warmup", "5", "--no-configs", "--no-cpu-baseline", *extra])
+        assert len(lines) == 1 and out.stdout.rstrip().splitlines()[-1] == lines[0]
+        d = json.loads(lines[0])
+        for k in CONTRACT_KEYS:
             assert k in d, k
         assert d["steps"] == 20 and d["n_gpus"] == 1 and d["config"]["total_boards"] == 16384 and d["scaling"] == "strong"
+        assert all(not isinstance(v, (list, dict)) for v in d["config"].values())     # a workload string + scalars
         r = d["roofline"]
         assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
         assert abs(d["value"] - 16384 * 20 / (d["ms_per_step"] * 20 / 1e3)) / d["value"] < 1e-6
+        assert full["value"] == d["value"] and full["roofline"]["frac"] == r["frac"]
     # the RCCL path of an N > 1 run -- process group on the device, barriers around the timed region, MAX-reduce of the elapsed
     # time, all-gather of the per-rank numbers -- rehearsed at world size 1 (an 8-GPU node is the driver's to launch)
     env = dict(os.environ, GBL_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1",
                LOCAL_RANK="0")
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--boards", "262144", "--steps", "20", "--warmup", "5",
-                          "--no-configs", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=root, env=env)
-    assert out.returncode == 0, out.stderr[-2000:]
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert d["config"]["rccl_ranks"] == 1 and d["config"]["dist_backend"] == "nccl" and len(d["config"]["kernel_us_per_rank"]) == 1
-    assert d["config"]["trajectory_placement_per_rank"][0]["probes"]
+    lines, full, _ = _bench(["--boards", "262144", "--steps", "20", "--warmup", "5", "--no-configs", "--no-cpu-baseline"], env=env)
+    d = json.loads(lines[-1])
+    assert d["config"]["rccl_ranks"] == 1 and d["config"]["dist_backend"] == "nccl" and len(full["detail"]["kernel_us_per_rank"]) == 1
+    assert full["detail"]["trajectory_placement_per_rank"][0]["probes"]
+    assert d["config"]["kernel_us_max"] == full["detail"]["kernel_us_per_rank"][0] and d["config"]["ms_per_step_before_trailing_barrier"] > 0
+
+
+def test_bench_driver_command_prints_a_compact_line(G):
+    """The driver's EXACT command -- python3 bench.py --gpus 1 --steps 20 --warmup 5, sub-records and CPU baseline ON -- must
+    end stdout with ONE compact line (< 4 096 bytes: the driver keeps only the tail of stdout; round 3's 20 kB line came back
+    `parsed: null`) that carries the contract's keys, a flat roofline with `frac` and `traffic`, and a flat cpu_baseline; the 18
+    sub-records are in the file config.configs_file names.  And: the same command under a launcher with WORLD_SIZE=1 (how a
+    SCALE run's N = 1 leg is started) reports the same workload and kernel."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5"], capture_output=True,
+                         text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    last = out.stdout.rstrip("\n").splitlines()[-1]
+    assert len(last.encode()) < 4096, len(last)
+    d = json.loads(last)
+    for k in CONTRACT_KEYS + ("cpu_baseline",):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["config"]["total_boards"] == 1 << 20
+    assert all(not isinstance(v, (list, dict)) for sub in ("config", "roofline", "cpu_baseline") for v in d[sub].values())
+    r, c = d["roofline"], d["cpu_baseline"]
+    assert r["bound"] == "hbm" and 0.3 < r["frac"] < 1 and "traffic" in r and "traffic_over_algorithmic" in r
+    if r["traffic"] is not None:   # (null only while the committed counters are older than the kernel sources)
+        assert 0.9 < r["traffic_over_algorithmic"] < 1.5
+    assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] == "port" and c["unit"] == "env-steps/s" and c["value_1core"] > 0
+    assert abs(d["value"] - (1 << 20) * 20 / (d["ms_per_step"] * 20 / 1e3)) / d["value"] < 1e-6
+    full = json.load(open(os.path.join(root, d["config"]["configs_file"])))
+    assert set(full["configs"]) == set(bench.CONFIG_RECORDS) | set(bench.EXTRA_RECORDS)
+    assert d["config"]["configs_recorded"] == len(full["configs"]) and full["value"] == d["value"]
+    assert all("roofline" in rec and rec["value"] > 0 for rec in full["configs"].values())
+    # N = 1 under a launcher: same workload string, same kernel
+    lines, _, _ = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-configs", "--no-cpu-baseline"], launcher_ranks=1)
+    e = json.loads(lines[-1])
+    assert e["config"]["workload"] == d["config"]["workload"] and e["roofline"]["kernel"] == d["roofline"]["kernel"]
+    assert e["config"]["plies_per_launch"] == d["config"]["plies_per_launch"] and e["n_gpus"] == 1
+    assert e["config"]["rccl_ranks"] == 0 and e["config"]["dist_backend"] is None  # (world 1: no process group, as in the bare form)
 
 
 def test_bench_script_two_ranks_rehearsal(G):
     """The N > 1 path of bench.py (one rank per GPU under torch.distributed.run: barriers around the timed region,
     MAX-reduce of the elapsed time, all-gather of the per-rank kernel times, strong-scaling shards) rehearsed with two
     ranks that share this box's one GPU over gloo."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    import socket
-    with socket.socket() as sock:  # a free port for the rendezvous
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
-           "--boards", "32768", "--dist-backend", "gloo", "--share-device"]
-    bare = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
-            "--boards", "32768", "--dist-backend", "gloo", "--share-device"]
+    args = ["--gpus", "2", "--steps", "20", "--warmup", "5", "--boards", "32768", "--dist-backend", "gloo", "--share-device"]
     clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     # under the launcher (the driver's form), and bare: bench.py then starts its two ranks itself
-    for command, environ in ((cmd, env), (bare, clean)):
-        out = subprocess.run(command, capture_output=True, text=True, timeout=600, cwd=root, env=environ)
-        assert out.returncode == 0, out.stderr[-3000:]
-        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    for ranks, environ in ((2, None), (0, clean)):
+        lines, full, _ = _bench(args, env=environ, launcher_ranks=ranks)
         assert len(lines) == 1  # rank 0 only
         d = json.loads(lines[0])
         assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_boards"] == 32768
-        assert d["config"]["boards_per_gpu"] == 16384 and len(d["config"]["kernel_us_per_rank"]) == 2
-        assert len(d["config"]["trajectory_placement_per_rank"]) == 2 and d["config"]["dist_backend"] == "gloo"
+        assert d["config"]["boards_per_gpu"] == 16384 and len(full["detail"]["kernel_us_per_rank"]) == 2
+        assert len(full["detail"]["trajectory_placement_per_rank"]) == 2 and d["config"]["dist_backend"] == "gloo"
         assert d["config"]["rccl_ranks"] == 0                   # (gloo rehearsal; under RCCL this is the world size)
-        assert "configs" not in d and "cpu_baseline" not in d  # N = 1 only
+        assert d["config"]["kernel_us_max"] == max(full["detail"]["kernel_us_per_rank"])
+        assert "configs" not in full and "cpu_baseline" not in d  # N = 1 only
+
+
+def test_bench_script_c4_shape_rehearsal(G):
+    """BASELINE C4's shape -- 131 072 boards per rank (k_collect2, 20 plies in one launch) -- with as many ranks as one
+    box allows on its card: FOUR ranks sharing the GPU over gloo (gpurun's process guard allows six processes on the card
+    and this test process holds it too; the eight-rank run is the driver's).  Catches what one or two ranks do not: the
+    N-way lock around the library build / load, the rendezvous, N placement searches on one device (each capped by what
+    is free: they must fall back quietly), the all-gather of per-rank numbers."""
+    ranks = 4
+    lines, full, out = _bench(["--gpus", str(ranks), "--steps", "20", "--warmup", "5", "--boards", str(131072 * ranks),
+                               "--dist-backend", "gloo", "--share-device"], launcher_ranks=ranks, timeout=900)
+    assert len(lines) == 1 and len(lines[0].encode()) < 4096
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["config"]["boards_per_gpu"] == 131072 and d["config"]["plies_per_launch"] == 20
+    assert d["roofline"]["kernel"].startswith("k_collect2 (20 plies per launch)"), d["roofline"]["kernel"]
+    assert len(full["detail"]["kernel_us_per_rank"]) == ranks and all(u > 0 for u in full["detail"]["kernel_us_per_rank"])
+    assert d["config"]["kernel_us_max"] >= d["config"]["kernel_us_min"] > 0
+    assert d["config"]["ms_per_step_before_trailing_barrier"] <= d["ms_per_step"] * 1.0001
+    assert all(pl is not None and pl.get("ratio", 0) > 0 for pl in full["detail"]["trajectory_placement_per_rank"])
 
 
 def test_collect_beyond_4gib(G):
