@@ -267,6 +267,85 @@ __device__ __forceinline__ void tile_store(int8_t *__restrict__ g, const uint4 (
     if (REM && lane < REM) store16<P>(&gv[lane + 64 * FULL], v[FULL]);
 }
 
+// ---- sub-tiles: 16 boards per wavefront, FOUR lanes per board (small batches) -------------------------------------------
+// A batch of a few thousand boards is a few dozen 64-board tiles: most CUs idle and a launch lasts as long as ONE wavefront's
+// serial path.  The small-batch kernels cut a tile in four: lane = 4 * board + j, the four lanes of a board compute the game
+// (sample, move, winner, legal mask) REDUNDANTLY -- no cross-lane traffic at all -- and share the per-row work: lane j builds
+// bytes [16 j, 16 j + 16) of the board's mask row and drops every fourth byte of its observation row, and a sub-tile's images
+// are a quarter of a tile's (16 x 117 B = 117 vectors: two store instructions instead of eight).  Sub-tile s of an array of
+// ROWB-byte rows starts at byte 16 s ROWB, a multiple of 16 like a tile.
+constexpr int kSub = 16;
+
+template <int ROWB, typename Between = NoWork>
+__device__ __forceinline__ void sub_in(const int8_t *__restrict__ g, uint32_t *lds, int lane, int rows, Between between = Between())
+{
+    constexpr int NV = kSub * ROWB / 16;  // = ROWB vectors of 16 bytes
+    static_assert(NV <= 128, "at most two vectors per lane");
+    if (rows == kSub) {
+        const uint4 *gv = reinterpret_cast<const uint4 *>(g);
+        uint4 *lv = reinterpret_cast<uint4 *>(lds);
+        uint4 v[2];
+        v[0] = gv[lane < NV ? lane : NV - 1];  // branch-free, like tile_in
+        v[1] = gv[NV > 64 && lane + 64 < NV ? lane + 64 : NV - 1];
+        between();
+#ifndef GBL_HOST_EMU
+        pin_loads<2>(v);
+#endif
+        if (lane < NV) lv[lane] = v[0];
+        if (NV > 64 && lane + 64 < NV) lv[lane + 64] = v[1];
+    } else {  // ragged last sub-tile: byte granular
+        between();
+        const int bytes = rows * ROWB;
+        int8_t *lb = reinterpret_cast<int8_t *>(lds);
+        for (int i = lane; i < bytes; i += 64) lb[i] = g[i];
+    }
+}
+
+template <int ROWB, int NT>
+__device__ __forceinline__ void sub_out(int8_t *__restrict__ g, const uint32_t *lds, int lane, int rows)
+{
+    constexpr int NV = kSub * ROWB / 16;
+    static_assert(NV <= 128, "at most two vectors per lane");
+    if (rows == kSub) {
+        const uint4 *lv = reinterpret_cast<const uint4 *>(lds);
+        uint4 v[2];
+        v[0] = lv[lane < NV ? lane : NV - 1];
+        if (NV > 64) v[1] = lv[lane + 64 < NV ? lane + 64 : NV - 1];
+#ifndef GBL_HOST_EMU
+        if constexpr (NT == kStoreStreamDrop) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g, 0, kSub * ROWB, 0x00020000);
+            if (lane < NV) {
+                vec4u t = {v[0].x, v[0].y, v[0].z, v[0].w};
+                __builtin_amdgcn_raw_buffer_store_b128(t, rs, lane * 16, 0, 2 | 16);
+            }
+            if (NV > 64 && lane + 64 < NV) {
+                vec4u t = {v[1].x, v[1].y, v[1].z, v[1].w};
+                __builtin_amdgcn_raw_buffer_store_b128(t, rs, (lane + 64) * 16, 0, 2 | 16);
+            }
+            return;
+        }
+#endif
+        constexpr int P = NT == kStoreStreamDrop ? kStoreStream : NT;
+        uint4 *gv = reinterpret_cast<uint4 *>(g);
+        if (lane < NV) store16<P>(&gv[lane], v[0]);
+        if (NV > 64 && lane + 64 < NV) store16<P>(&gv[lane + 64], v[1]);
+    } else {
+        const int bytes = rows * ROWB;
+        const int8_t *lb = reinterpret_cast<const int8_t *>(lds);
+        for (int i = lane; i < bytes; i += 64) g[i] = lb[i];
+    }
+}
+
+// zero image of a sub-tile's 16 observation rows (117 vectors)
+__device__ __forceinline__ void sub_obs_zero(uint32_t *img, int lane)
+{
+    constexpr int NV = kSub * kObs / 16;
+    uint4 *lv = reinterpret_cast<uint4 *>(img);
+    const uint4 z = {0u, 0u, 0u, 0u};
+    lv[lane] = z;
+    if (lane + 64 < NV) lv[lane + 64] = z;
+}
+
 // Orders this wave's LDS accesses across lanes.  A workgroup is ONE wavefront, whose LDS
 // instructions execute in issue order, so no s_barrier and no vmcnt drain is needed (a
 // __syncthreads() would also wait for every outstanding global store); the fence only keeps the
@@ -547,6 +626,46 @@ __device__ __forceinline__ void obs_scatter_row(uint8_t *row, const Planes &p, i
 #pragma unroll
         for (int q = 0; q < 9; ++q) row[13 * q + 12] = (uint8_t)one;
     }
+}
+
+// Lane j (of the four of a board) drops channels j, j + 4, j + 8 and channel-12 bytes of squares j, j + 4 (, 8) of the board's
+// observation row (zero on entry): obs_scatter_row dealt over a quad.
+__device__ __forceinline__ void obs_scatter_quad(uint8_t *row, const Planes &p, int observer, int j)
+{
+    const uint32_t pos = p.nz & ~p.neg, ngv = p.nz & p.neg;
+    const uint32_t own = observer ? ngv : pos, opp = observer ? pos : ngv;
+    // channel ch = j + 4 i: side = ch / 6, level = (ch % 6) / 2, parity = ch & 1 = j & 1
+    const uint32_t oddsel = (j & 1) ? ~p.odd : p.odd;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ch = j + 4 * i;                    // 0..11
+        const uint32_t side = ch >= 6 ? opp : own;
+        const int k = (ch >= 6 ? ch - 6 : ch) >> 1;
+        const uint32_t grp = ((side & oddsel) >> (9 * k)) & 0x1FFu;
+        if (grp) row[13 * __builtin_ctz(grp) + ch] = 1;
+    }
+    if (observer) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int q = j + 4 * i;
+            if (q < 9) row[13 * q + 12] = 1;
+        }
+    }
+}
+
+// Lane j writes bytes [16 j, 16 j + 16) (j = 3: the last 6) of the board's 54-byte mask row at `row` (2-byte aligned: unaligned
+// LDS stores, like ImageRow::reset).
+__device__ __forceinline__ void mask_row_quad(uint8_t *row, uint64_t m, int j)
+{
+    const uint32_t bits = (uint32_t)(m >> (16 * j)) & 0xFFFFu;
+    uint32_t d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = __umul24((bits >> (4 * k)) & 0xFu, 0x00204081u) & 0x01010101u;
+    uint8_t *dst = row + 16 * j;
+    if (j < 3)
+        __builtin_memcpy(dst, d, 16);
+    else
+        __builtin_memcpy(dst, d, 6);
 }
 
 // Board.get_flatboard, board.py:159-177: signed piece number of the top piece per

@@ -304,10 +304,14 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
  * their records with it instead of re-deriving the library's dispatch rule.
  *   GBL_COLLECT_STREAM  k_collect,  one wavefront per tile of 64 boards, trajectory rows stored non-temporally
  *   GBL_COLLECT_CACHED  k_collect with plain stores (does not exist in the product build: A/B builds only)
- *   GBL_COLLECT_PAIR    k_collect2, two wavefronts per tile (one plays, one stores): grids of up to 2048 tiles */
+ *   GBL_COLLECT_PAIR    k_collect2, two wavefronts per tile (one plays, one stores): grids of up to 2048 tiles
+ *   GBL_COLLECT_SMALL   k_collect_small, 16 boards per wavefront and four lanes per board, the game played redundantly by
+ *                       the wavefront that stores the observation rows and the one that stores the mask rows and scalars:
+ *                       small batches (a few thousand boards), whose launch lasts as long as one wavefront's serial path */
 #define GBL_COLLECT_STREAM 0
 #define GBL_COLLECT_CACHED 1
 #define GBL_COLLECT_PAIR 2
+#define GBL_COLLECT_SMALL 3
 int gbl_collect_variant(int64_t n, uint32_t plies, int with_mask, int with_obs);
 /* gbl_collect whose FIRST ply plays caller-supplied actions (first_actions int32[n]; NULL = gbl_collect): the collector
  * step of a policy that lives outside the library against masked-random replies -- the loops of the reference's trainers

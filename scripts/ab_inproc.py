@@ -4,7 +4,7 @@ dlopen'ed side by side and launched on the SAME buffers in turn (A B C A B C ...
 box are the same for all of them -- the run-to-run scatter of the trajectory stream is larger than
 most kernel variants' effect.
 
-    python scripts/ab_inproc.py BOARDS T STREAMS lib1.so lib2.so ...      STREAMS: all | rows | obs | mask | ply | plymask
+    python scripts/ab_inproc.py BOARDS T STREAMS lib1.so lib2.so ...      STREAMS: all | rows | obs | mask | none | scalars | maskscalars | obsscalars | ply | plymask
 (ply / plymask: the one-ply pipeline instead, gbl_rollout_at with plies = 1, FULL / MASK_ONLY outputs; T is ignored)"""
 import ctypes as C
 import os
@@ -33,7 +33,9 @@ f = buf["_full"]
 one_ply = streams in ("ply", "plymask")
 if one_ply:
     T = 1
+scalars = ("actions", "winner", "rewards", "done", "to_move")
 keys = {"all": tuple(f), "rows": ("action_mask", "observation"), "obs": ("observation",), "mask": ("action_mask",),
+        "none": (), "scalars": scalars, "maskscalars": scalars + ("action_mask",), "obsscalars": scalars + ("observation",),
         "ply": (), "plymask": ()}[streams]
 P = {k: (v.data_ptr() if k in keys else None) for k, v in f.items()}
 ctr = torch.zeros(1, dtype=torch.int32, device="cuda:0")

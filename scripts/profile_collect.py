@@ -98,7 +98,7 @@ def main():
     rows = ["kernel,counter,dispatches,mean_value_KB"]
     # run name (scripts/profile_round.sh: pmc_runs.txt) -> (key bench.py looks up, kernel name substring)
     runs = {"collect_T8": ("collect:1048576:T8", "k_collect<true, true"), "collect_T20": ("collect:1048576:T20", "k_collect<true, true"),
-            "collect_4096_T32": ("collect:4096:T32", "k_collect2<true, true"),
+            "collect_4096_T32": ("collect:4096:T32", "k_collect_small<true, true"),
             "collect_131072_T32": ("collect:131072:T32", "k_collect2<true, true"),
             "collect_131072_T20": ("collect:131072:T20", "k_collect2<true, true"),
             "collect_262144_T16": ("collect:262144:T16", "k_collect<true, true"),

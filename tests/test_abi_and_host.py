@@ -56,6 +56,7 @@ def test_no_kernel_uses_scratch():
     bad = {k: (v["private_segment_fixed_size"], v["vgpr_spill_count"], v["sgpr_spill_count"]) for k, v in kernels.items()
            if int(v["private_segment_fixed_size"]) or int(v["vgpr_spill_count"])}
     assert not bad, bad
+    assert not [k for k, v in kernels.items() if v.get("uses_dynamic_stack") == "true"]  # (a real call into unknown code: scratch)
     # wave64 everywhere, and every workgroup shape fits a CU (<= 512 VGPRs per SIMD lane-slice, 160 KB of LDS)
     for k, v in kernels.items():
         assert v["wavefront_size"] == "64", k

@@ -6,7 +6,7 @@ instantiation each one reaches.  Bit-exact (integer / byte work).
     bench record                  entry point (as bench.py calls it)        kernel instantiation
     ----------------------------  ----------------------------------------  -------------------------------------------
     headline (2^20, collect)      gbl_collect, ply index on the device      k_collect<mask, obs, DEV_PLY, NT>, 8 and 20 plies per launch
-    c2_4096                       gbl_collect                               k_collect2<mask, obs, DEV_PLY>  (<= 2048 tiles)
+    c2_4096                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY>  (<= 8 192 boards)
     c3_262144                     gbl_collect                               k_collect<mask, obs, DEV_PLY, NT>
     c4_shard_131072               gbl_collect                               k_collect2<mask, obs, DEV_PLY>  (2048 tiles)
     large_4194304                 gbl_collect                               k_collect<mask, obs, DEV_PLY, NT>, identity tile map
@@ -262,6 +262,75 @@ def test_collect_from_external_first_ply_vs_oracle(G, n, T, illegal, with_obs):
     assert env.ply == warm + 3 * T
     with pytest.raises(ValueError):
         env.collect(T, out=tr, first_actions=torch.zeros(n, dtype=torch.int32, device=DEV), policies=("random", "random"))
+
+
+# ---- the small-batch kernel (k_collect_small: sub-tiles of 16 boards, four lanes per board) --------------------------------
+SMALL_SIZES = [1, 15, 16, 17, 63, 65, 4096, 4099, 8192]
+
+
+@pytest.mark.parametrize("with_obs", [True, False], ids=["full", "maskonly"])
+@pytest.mark.parametrize("n", SMALL_SIZES)
+def test_small_batch_collect_vs_oracle(G, n, with_obs):
+    """gbl_collect on small batches (up to 8 192 boards: GBL_COLLECT_SMALL) directly against the oracle, FULL and MASK_ONLY,
+    time- and tile-major slots, both illegal modes, ply index by value and on the device, tallies and turn counters; ragged
+    last sub-tiles (1, 15, 17, 63, 65, 4 099 boards) and whole ones (16, 4 096, 8 192)."""
+    assert G._native.lib().gbl_collect_variant(n, 7, 1, int(with_obs)) == 3  # GBL_COLLECT_SMALL
+    T, seed, base, warm = 7, 29, 123_456_789_012, 6
+    for layout, illegal, device_ply in (("time", "noop", True), ("tile", "terminate", False)):
+        env, s, tm, dn = warm_pair(G, n, seed, base, warm, with_observation=with_obs, illegal_mode=illegal, track_turn=True)
+        turn = npy(env.turn).copy()
+        if device_ply:
+            env.device_ply()
+        tr = env.trajectory_buffers(T, layout=layout, placement="any")
+        before = env.counters.clone()
+        env.collect(T, out=tr, refresh=False, count=True)
+        env.advance_ply()
+        torch.cuda.synchronize()
+        ended = check_trajectory(env, tr, T, warm, s, tm, dn, 0 if illegal == "noop" else 1, with_obs=with_obs)
+        delta = npy(env.counters - before)
+        assert delta[0] == n * T and delta[1] == ended and delta[2] + delta[3] == ended
+        # raw_env.turn: plies since the board's last reset (the masked-random sampler never plays an illegal action)
+        games_per_board = sum(npy(slot(tr, "done", t_, n)).astype(np.int64) for t_ in range(T))
+        last_end = np.full(n, -1)
+        for t_ in range(T):
+            last_end = np.where(npy(slot(tr, "done", t_, n)) != 0, t_, last_end)
+        exp_turn = np.where(games_per_board > 0, T - 1 - last_end, turn + T)
+        assert np.array_equal(npy(env.turn), exp_turn)
+        if layout == "time":  # the padding boards of a slot are never written
+            pad = tr["_full"]["action_mask"][:, n:]
+            assert pad.numel() == 0 or int(pad.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 4096, 4099])
+def test_small_batch_one_ply_entry_points_vs_oracle(G, n):
+    """The one-ply entry points on small batches (k_rollout / k_step: routing them to the sub-tile kernel gained nothing and was
+    taken out again): gbl_rollout(plies = 1) and gbl_sample + gbl_step with auto-reset, FULL and MASK_ONLY, both illegal modes,
+    with wild (illegal / out-of-range) actions thrown at gbl_step; every output against the oracle."""
+    seed, base, warm = 31, 7, 9
+    rng = np.random.default_rng(n)
+    for with_obs, illegal in ((True, "noop"), (False, "terminate")):
+        im = 0 if illegal == "noop" else 1
+        env, s, tm, dn = warm_pair(G, n, seed, base, warm, with_observation=with_obs, illegal_mode=illegal, track_turn=True)
+        for k in range(4):
+            obs, rew, done, win = env.rollout(1)
+            o = oracle.batch_rollout(s, tm, dn, seed, base, warm + k, 1, illegal_mode=im, threads=THREADS, want_obs=with_obs)
+            assert np.array_equal(npy(env.squares), s) and np.array_equal(npy(env.to_move), tm) and np.array_equal(npy(done), dn)
+            assert np.array_equal(npy(env.actions), o["actions"]) and np.array_equal(npy(win), o["winner"])
+            assert np.array_equal(npy(rew), o["reward"]) and np.array_equal(npy(obs["action_mask"]), o["mask"])
+            if with_obs:
+                assert np.array_equal(npy(obs["observation"]), o["obs"])
+        for k in range(4):
+            acts = oracle.batch_sample(oracle.batch_legal_mask(s, tm), seed, base, warm + 4 + k)
+            assert np.array_equal(npy(env.sample_actions()), acts)
+            wild = rng.random(n) < 0.2
+            acts = np.where(wild, rng.integers(-3, 60, n), acts).astype(np.int32)
+            obs, rew, done, win = env.step(torch.from_numpy(acts).to(DEV))
+            o = oracle.batch_step(s, tm, dn, acts, illegal_mode=im, auto_reset=True, threads=THREADS, want_obs=with_obs)
+            assert np.array_equal(npy(env.squares), s) and np.array_equal(npy(env.to_move), tm) and np.array_equal(npy(done), dn)
+            assert np.array_equal(npy(win), o["winner"]) and np.array_equal(npy(rew), o["reward"])
+            assert np.array_equal(npy(obs["action_mask"]), o["mask"])
+            if with_obs:
+                assert np.array_equal(npy(obs["observation"]), o["obs"])
 
 
 def test_bench_config_keys_are_all_covered(G):
