@@ -28,7 +28,10 @@ What a caller that shares the device can rely on (round 3):
     when it started (the two arrays' own blocks always count), and leaves ``RESERVE_BYTES`` untouched;
   * an allocation the device refuses ENDS the search (the best pair seen so far is used); if not even the two arrays'
     own blocks fit the plain pair is kept (without one, ``PlacementUnavailable`` is raised) -- the reason is recorded;
-  * ``torch.cuda.empty_cache()`` is never called: rejected blocks are ``hipFree``d, torch's cache is left alone.
+  * ``torch.cuda.empty_cache()`` is never called: rejected blocks are ``hipFree``d, torch's cache is left alone -- which also
+    means that when a block pair replaces the allocator's own pair, that pair's memory stays in torch's cache (``torch_cache_gib``
+    in the record: 1.4 GiB at 2^20 boards x 8 plies) on top of the winner's blocks;
+  * a block whose last owner goes away during a stream capture is parked and freed later (``hipFree`` synchronises).
 """
 from __future__ import annotations
 
@@ -65,6 +68,7 @@ class DeviceBlock:
 
     def __init__(self, nbytes: int, device):
         self.nbytes, self.device, self.ptr = int(nbytes), torch.device(device), None
+        free_parked()
         p = C.c_void_p()
         with torch.cuda.device(self.device):
             nat.check(nat.lib().gbl_block_alloc(self.nbytes, C.byref(p)), "gbl_block_alloc")
@@ -78,10 +82,25 @@ class DeviceBlock:
     def __del__(self):
         if getattr(self, "ptr", None):
             try:
-                nat.lib().gbl_block_free(self.ptr)
+                # hipFree synchronises the device, which is illegal while a stream capture is under way (a buffer dict
+                # garbage-collected inside torch.cuda.graph): the block is then parked and freed with the next one
+                if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                    _parked.append(self.ptr)
+                else:
+                    nat.lib().gbl_block_free(self.ptr)
+                    free_parked()
             except Exception:  # noqa: BLE001  (interpreter shutdown)
                 pass
             self.ptr = None
+
+
+_parked: list[int] = []  # blocks whose last owner went away during a stream capture
+
+
+def free_parked() -> None:
+    """Free the blocks that could not be freed when their last owner went away (a stream capture was under way)."""
+    while _parked and not torch.cuda.is_current_stream_capturing():
+        nat.lib().gbl_block_free(_parked.pop())
 
 
 def device_alloc(device):
@@ -224,10 +243,13 @@ def spread_pair(bytes_a: int, bytes_b: int, device, slot_boards: int = 0, plies:
         tried.insert(0, round(first[2], 3))
     a, b = pool["a"][ia][:size["a"]], pool["b"][ib][:size["b"]]
     a.zero_(); b.zero_()  # (a probe writes only zeros, but say so explicitly)
+    # the caller's own pair lost: its memory goes back to torch's caching allocator, which keeps it for the process (it is not
+    # returned to the driver unless somebody calls torch.cuda.empty_cache()) -- recorded, so that the footprint is not a surprise
+    stranded = (size["a"] + size["b"]) / GIB if first is not None else 0.0
     released = len(pool["a"]) + len(pool["b"]) - 2 + len(skips)
     pool.clear()    # the rejected blocks and the gaps go back to the driver here (hipFree, no allocator cache involved)
     skips.clear()
     return a, b, {"spread": bool(ratio <= SPREAD_RATIO), "ratio": round(ratio, 3), "probes": tried,
                   "block_gib": [round(block["a"] / GIB, 3), round(block["b"] / GIB, 3)], "held_gib": round(held / GIB, 1),
                   "cap_gib": round(cap / GIB, 1), "released_blocks": released, "ended": ended,
-                  "seconds": round(time.perf_counter() - t0, 3)}
+                  "torch_cache_gib": round(stranded, 3), "seconds": round(time.perf_counter() - t0, 3)}

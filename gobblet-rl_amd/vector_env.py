@@ -59,6 +59,7 @@ class BatchedGobblet:
         self._counters = torch.zeros((nat.COUNTER_STRIPES, nat.COUNTER_STRIDE), dtype=torch.int64, device=dev)
         self._ply, self._ply_dev = 0, None  # lockstep ply counter (keys the sampler), see ``ply`` / ``device_ply``
         self.policy_hist = None             # int8 (N, 2, 3): the device-side greedy policies' last three actions per agent
+        self._staging = {}                  # collect()'s own trajectory buffers, one placed set per (plies, layout, outputs)
         self.reset()
 
     def reset_policy_history(self) -> None:
@@ -327,8 +328,12 @@ class BatchedGobblet:
         position after the last ply; with ``refresh`` the ``action_mask`` / ``observation`` / ``actions`` / ``winner`` /
         ``rewards`` attributes are copied from the last ply (device copies of ~180 B per board: a pure collector that
         only reads the trajectory passes ``refresh=False`` and calls ``refresh()`` before it next steps by hand).
-        ``out``: a dict from ``trajectory_buffers(plies)`` to reuse (a replay buffer's staging area; placed for speed,
-        see there).  Without it every call allocates fresh, unplaced buffers.
+        ``out``: a dict from ``trajectory_buffers(plies)`` to write into (a replay buffer's staging area; placed for speed,
+        see there).  Without it the environment's OWN staging buffers are used: one set per (plies, layout, policy outputs),
+        made -- and placed, see ``trajectory_buffers`` -- on the first call and reused by every later one, so the returned
+        tensors are valid until the next ``collect`` of the same shape on this environment (clone what must outlive it, or
+        pass ``out``).  Round 3 allocated fresh unplaced buffers per call, which ran at 0.72-0.85 of the placed rate at 2^20
+        boards and paid an allocation per call.  ``release_staging()`` drops them.
 
         ``first_actions`` (int (N,)): the first ply plays these actions -- an external policy's decision -- and the
         remaining plies are sampled (``gbl_collect_from``): ``collect(2, out, first_actions=a)`` is one decision of the
@@ -346,9 +351,13 @@ class BatchedGobblet:
             raise ValueError("collect() plays with auto-reset; this environment was created with auto_reset=False")
         T = int(plies)
         if out is None:
-            # (fresh buffers on every call: no probe, no placement -- a loop that cares about the last 20 % makes its
-            # buffers once with trajectory_buffers() and passes them as `out`)
-            out = self.trajectory_buffers(T, layout=layout, placement="any", policy_outputs=policies is not None)
+            key = (T, layout, policies is not None)
+            out = self._staging.get(key)
+            if out is None:
+                out = self.trajectory_buffers(T, layout=layout, policy_outputs=policies is not None)
+                # (buffers made inside a graph capture belong to the graph's private pool: not kept beyond it)
+                if not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+                    self._staging[key] = out
         if out["_plies"] != T:
             raise ValueError("trajectory buffers were made for %d plies" % out["_plies"])
         f, n = out["_full"], self.num_envs
@@ -395,6 +404,11 @@ class BatchedGobblet:
         if self.observation is not None:
             self.observation.copy_(self._last_ply(out, "observation"))
         return out
+
+    def release_staging(self) -> None:
+        """Drop the trajectory buffers ``collect()`` keeps for calls without ``out`` (their blocks go back to the driver
+        once the last tensor over them is gone)."""
+        self._staging.clear()
 
     def step_into(self, actions, out: dict, t: int):
         """``step(actions)`` with this ply's outputs written straight into slot ``t`` of time-major trajectory buffers

@@ -518,7 +518,7 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
         int total = 0;
         for (int l = 0; l < 64; ++l) {
             PLAN[l] = GreedyRootPlan{0ull, 0ull, 0ull};
-            for (int j = 0; j < kRootItems; ++j) undef[l][j] = 0xDEADBEEFDEADBEEFull;  // rows nobody writes are never read
+            for (int j = 0; j < kRootItems; ++j) undef[l][j] = 0xDEADBEEFDEADBEEFull;  // rows nobody writes: poison (see the merge below)
             if (pooled && depth > 1 && MASK[l] != 0) PLAN[l] = greedy_root_plan(H[l], P[l], ME[l], greedy_root(P[l], ME[l]));
             for (uint64_t it = PLAN[l].eval; it; it &= it - 1) pair[total++] = (uint16_t)((l << 8) | __builtin_ctzll(it));
             const int nr = __builtin_popcountll(PLAN[l].items);
@@ -554,7 +554,10 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
         for (int l = 0; l < 64; ++l) {
             for (int j = 0; j < kRootItems; ++j) UND[l][j] = 0ull;
             if (!PLAN[l].items) continue;
-            for (int j = 0; j < kRootItems; ++j) UND[l][j] = (j < __builtin_popcountll(PLAN[l].items) ? undef[l][j] : 0ull) & PLAN[l].resolved;
+            // exactly what the kernel does (gobblet_hip.hip, greedy_tile's tail): ALL kRootItems rows, `& resolved` only -- the rows
+            // nobody wrote hold the poison above (the kernel: stale LDS), and only the `live` guards of greedy_hand_merge /
+            // greedy_hand_lookup keep them out of the result: a regression there shows up as a mismatch below
+            for (int j = 0; j < kRootItems; ++j) UND[l][j] = undef[l][j] & PLAN[l].resolved;
             const GreedyHandSets hs = greedy_hand_merge(PLAN[l].items, H[l].legal_me, UND[l]);
             threat[l] |= hs.threat; second[l] |= hs.second; block[l] |= hs.block; flegal[l] |= hs.flegal;
         }

@@ -1243,7 +1243,12 @@ def test_placement_probe_and_spread_buffers(G):
         G.BatchedGobblet(64, DEV, auto_reset=True).trajectory_buffers(4, placement="spread")  # too small to probe
     small = G.BatchedGobblet(64, DEV, auto_reset=True).trajectory_buffers(4)
     assert small["_placement"]["spread"] is False and "too small" in small["_placement"]["why"]
-    assert G.BatchedGobblet(64, DEV, auto_reset=True).collect(4)["_placement"]["why"] == "placement='any'"  # implicit buffers: no probe
+    # implicit buffers: the environment's own staging set, made once per shape (placed like any other: here too small to probe)
+    small = G.BatchedGobblet(64, DEV, auto_reset=True)
+    first = small.collect(4)
+    assert first["_placement"]["why"] == "arrays too small to probe" and small.collect(4) is first and small.collect(5) is not first
+    small.release_staging()
+    assert small.collect(4) is not first
 
 
 def test_placement_on_a_nearly_full_device(G):
