@@ -1173,60 +1173,52 @@ struct GreedyLds {
     }
 };
 
+// Inclusive prefix sum over the 64 lanes of a wavefront in six DPP adds (Hillis-Steele inside the rows of 16, then the rows'
+// totals: lane 15 of a row into the next one, lane 31 into rows 2 and 3); scripts/microbench/dpp_scan.hip checks it on the GPU.
+__device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 // Compacts the (board, step) entries of a wavefront's lanes -- lane = board, `bits` = the steps (candidates / ranks) it has
-// -- into a list shared by the whole block.  The lanes' counts are prefix-summed BIT-SLICED: the count of the lanes below is
-// sum_k 2^k * mbcnt(ballot(bit k of the count)), one ballot per bit of the largest possible count, no cross-lane data
-// movement; the wavefront reserves its stretch of the list with ONE atomic, and a lane writes its few entries in a loop (as
-// long as the busiest lane's count: 4-6 of 14 steps).  Round 3's first form -- one ballot + mbcnt + store per STEP, in two
-// passes around the atomic -- cost a wavefront 2 400 cycles (per-wavefront stamps), five barriers' worth.
+// -- into a list shared by the whole block.  The lanes' counts are prefix-summed with six DPP adds (round 3: bit-sliced, one
+// ballot + two mbcnt per bit of the largest possible count); the wavefront reserves its stretch of the list with ONE atomic,
+// and a lane writes its few entries in a loop (as long as the busiest lane's count: 4-6 of 14 steps).  Round 3's first form --
+// one ballot + mbcnt + store per STEP, in two passes around the atomic -- cost a wavefront 2 400 cycles (per-wavefront stamps),
+// five barriers' worth.  (Every lane of the wavefront must be active: both callers are wave-uniform branches.)
 template <int STEPS>
 __device__ __forceinline__ void list_append(uint16_t *list, int *fill, uint32_t tag, int lane, uint32_t bits)
 {
     static_assert(STEPS <= 31, "the steps of a lane fit a 32-bit set");
-    constexpr int kBits = STEPS < 2 ? 1 : STEPS < 4 ? 2 : STEPS < 8 ? 3 : STEPS < 16 ? 4 : 5;
     const uint32_t cnt = (uint32_t)__popc(bits);
-    uint32_t below = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < kBits; ++k) {
-        const unsigned long long m = __ballot((cnt >> k) & 1u);
-        below += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << k;
-        total += (uint32_t)__popcll(m) << k;
-    }
+    const uint32_t inc = wave_incl_scan_add(cnt);
     uint32_t base = 0;
-    if (lane == 0 && total) base = (uint32_t)atomicAdd(fill, (int)total);
-    uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + below;
+    if (lane == kTile - 1 && inc) base = (uint32_t)atomicAdd(fill, (int)inc);
+    uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)base, kTile - 1) + inc - cnt;
     for (uint32_t rest = bits; rest; rest &= rest - 1u) list[at++] = (uint16_t)(tag + (uint32_t)__builtin_ctz(rest));
 }
 
 // list_append for two lists at once -- entries of `bits` go to `list` upwards, those of `bitsx` (few lanes have any) from
-// `listx` DOWNWARDS (the two share one array) -- whose fill counts share one word (low / high 16 bits): still one atomic per
-// wavefront.
+// `listx` DOWNWARDS (the two share one array) -- whose fill counts share one word (low / high 16 bits): one scan of the packed
+// counts, one atomic per wavefront.
 template <int STEPS>
 __device__ __forceinline__ void list_append2(uint16_t *list, uint16_t *listx, int *fill, uint32_t tag, int lane, uint64_t bits, uint64_t bitsx)
 {
     static_assert(STEPS <= 63, "the steps of a lane fit a 64-bit set");
-    constexpr int kBits = STEPS < 2 ? 1 : STEPS < 4 ? 2 : STEPS < 8 ? 3 : STEPS < 16 ? 4 : STEPS < 32 ? 5 : 6;
     const uint32_t cnt = STEPS < 32 ? (uint32_t)__popc((uint32_t)bits) : (uint32_t)__popcll(bits);
     const uint32_t cntx = STEPS < 32 ? (uint32_t)__popc((uint32_t)bitsx) : (uint32_t)__popcll(bitsx);
-    uint32_t below = 0, total = 0, belowx = 0, totalx = 0;
-#pragma unroll
-    for (int k = 0; k < kBits; ++k) {
-        const unsigned long long m = __ballot((cnt >> k) & 1u);
-        below += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << k;
-        total += (uint32_t)__popcll(m) << k;
-    }
-    if (__ballot(bitsx != 0ull)) {  // (wavefront-uniform)
-#pragma unroll
-        for (int k = 0; k < kBits; ++k) {
-            const unsigned long long m = __ballot((cntx >> k) & 1u);
-            belowx += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << k;
-            totalx += (uint32_t)__popcll(m) << k;
-        }
-    }
+    const uint32_t own = cnt | (cntx << 16);          // (a wavefront's totals are < 2^16 each: no carry between the halves)
+    const uint32_t inc = wave_incl_scan_add(own);
     uint32_t base = 0;
-    if (lane == 0 && (total | totalx)) base = (uint32_t)atomicAdd(fill, (int)(total | (totalx << 16)));
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    uint32_t at = (base & 0xFFFFu) + below, atx = (base >> 16) + belowx;
+    if (lane == kTile - 1 && inc) base = (uint32_t)atomicAdd(fill, (int)inc);
+    const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)base, kTile - 1) + inc - own;
+    uint32_t at = start & 0xFFFFu, atx = start >> 16;
     if (STEPS < 32) {
         for (uint32_t rest = (uint32_t)bits; rest; rest &= rest - 1u) list[at++] = (uint16_t)(tag + (uint32_t)__builtin_ctz(rest));
         for (uint32_t rest = (uint32_t)bitsx; rest; rest &= rest - 1u) listx[-(int)(atx++)] = (uint16_t)(tag + (uint32_t)__builtin_ctz(rest));

@@ -362,6 +362,8 @@ def test_placement_search_logic(monkeypatch):
     a new block, honours the probe budget and the memory cap (64 GiB, a quarter of what was free at entry), ends quietly
     when the device refuses a block, refuses to start when not even the arrays' own blocks fit, probes a new block
     against one representative unless that pair is in between, and returns zero-filled arrays of the sizes asked for."""
+    import weakref
+
     import torch
     from gobblet_rl_amd import placement
     GIB = placement.GIB
@@ -374,7 +376,12 @@ def test_placement_search_logic(monkeypatch):
             raise MemoryError("scripted out-of-memory")
         made.append(nbytes)
         state["free"] -= nbytes
-        return torch.full((4096,), len(made), dtype=torch.uint8)  # (a stand-in for the block; the value tells which)
+        t = torch.full((4096,), len(made), dtype=torch.uint8)  # (a stand-in for the block; the value tells which)
+        weakref.finalize(t, give_back, nbytes)                 # (a block that is dropped goes back to the "driver")
+        return t
+
+    def give_back(nbytes):
+        state["free"] += nbytes
 
     def run(ratios, free=288 * GIB, refuse_after=None, **kw):
         made.clear()
@@ -387,10 +394,11 @@ def test_placement_search_logic(monkeypatch):
             return 100.0 * r, 60.0, 40.0
 
         monkeypatch.setattr(placement, "probe", fake_probe)
+        kw.setdefault("far", False)  # (the far candidates have their own cases below)
         a, b, info = placement.spread_pair(1000, 500, "cpu", alloc=alloc, free=lambda: state["free"], **kw)
         assert a.numel() == 1000 and b.numel() == 500 and int(a.max()) == 0 and int(b.max()) == 0
         assert all(m >= placement.MIN_BLOCK_BYTES and m % placement.BLOCK_GRANULE == 0 for m in made)
-        assert info["held_gib"] <= info["cap_gib"] <= placement.MAX_HOLD_BYTES / GIB
+        assert info["cap_gib"] <= placement.MAX_HOLD_BYTES / GIB and (kw["far"] or info["held_gib"] <= info["cap_gib"])
         return seen, info
 
     assert placement.block_bytes(1) == 2 << 30 and placement.block_bytes((2 << 30) + 1) == (2 << 30) + (2 << 20)
@@ -431,6 +439,16 @@ def test_placement_search_logic(monkeypatch):
     with pytest.raises(placement.PlacementUnavailable):
         run([0.8], refuse_after=1)
     assert made == [2 << 30]
+    # a device that is all ours hands out ONE class for 62 GiB on end (the driver's box, round 4): the capped search finds nothing,
+    # then a candidate behind a transient gap of 64 GiB is still in the class, the one behind 96 GiB is clean
+    near = len(run([1.0] * 40)[0])                        # (probes of the capped search when nothing is clean)
+    seen, info = run([1.0] * near + [1.0, 0.81], far=True)
+    assert info["ratio"] == 0.81 and info["spread"] and info["far_gaps_gib"] == [64, 96] and "transient gap of 96 GiB" in info["ended"]
+    assert [m >> 30 for m in made][-4:] == [64, 2, 96, 2] and seen[-1][0] == 1   # (gap, block) twice; against the first observation block
+    seen, info = run([1.0] * 40, far=True)                # nothing anywhere: three far candidates, then the best seen
+    assert info["far_gaps_gib"] == [64, 96, 128] and info["ratio"] == 1.0 and not info["spread"]
+    seen, info = run([1.0] * 40, free=150 * GIB, far=True)  # a device that is not mostly free: no far candidates at all
+    assert info["far_gaps_gib"] == [] and max(made) <= placement.MAX_SKIP_BYTES
     # the pair as the caller's allocator places it is probed first and stays in the race
     plain_made = []
 
