@@ -771,6 +771,9 @@ __device__ __forceinline__ uint32_t draw_word(const Draw4 &d, uint32_t ply)
     return (ply & 2u) ? hi : lo;
 }
 
+// which word of the block draw_word picks: ply & 3 = 0, 1, 2, 3 -> w[0], w[1], w[2], w[3]
+__device__ __forceinline__ uint32_t draw_word_index(uint32_t ply) { return ply & 3u; }
+
 __device__ __forceinline__ uint32_t draw32(uint64_t seed, uint64_t env_id, uint32_t ply, uint32_t stream = kStreamEnv)
 {
     return draw_word(draw_block(seed, env_id, ply, stream), ply);

@@ -1555,6 +1555,9 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
 // The owner wavefronts do everything but the shared depth-2 work.
 // (Register budget: four wavefronts per SIMD = 128 VGPRs.  Left alone the compiler takes ~160 -- the ply loop keeps the
 // decision's literal constants live across iterations -- which costs a wavefront of occupancy for nothing.)
+#ifndef GBL_X_POLICY16_CALL
+#define GBL_X_POLICY16_CALL 0  // (A/B: <4,16> behind greedy_tile_call; inlined it holds exactly its 128 VGPRs and is 5 % faster)
+#endif
 #ifndef GBL_CP_WAVES_PER_EU
 #define GBL_CP_WAVES_PER_EU 4
 #endif
@@ -1569,6 +1572,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
 {
     __shared__ uint32_t s_states[NT][image_words<kCells>()];
     __shared__ GreedyLds<NT, W> S;
+    // The two generator blocks of a board (environment stream, fallback-draw stream: four plies' words each) are parked here, not
+    // held in eight registers across the decision: a ply reads back the one word of each it needs.
+    __shared__ uint32_t s_draws[NT][8][kTile];
     if (ply_dev) ply0 += *ply_dev;
     Lane L;
     if (!block_lane_setup<NT>(L, n, ntiles)) return;  // the same for every thread of the workgroup
@@ -1579,7 +1585,18 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
     Planes p{0u, 0u, 0u};
     int mover = 0, dn = 0, tabs = 0;
     uint32_t hp0 = 0x00FFFFFFu, hp1 = 0x00FFFFFFu;  // the two agents' last three actions, one per byte (0xFF = none)
-    Draw4 block{{0u, 0u, 0u, 0u}}, fblock{{0u, 0u, 0u, 0u}};  // generator blocks of the environment's and the fallback draws' streams
+    uint32_t (*const draws)[kTile] = s_draws[owner ? wave : 0];
+    auto park_draws = [&](uint32_t ply) {  // the blocks that serve plies 4 * (ply >> 2) ... of this board: generated once per four plies
+        const Draw4 block = draw_block(seed, env_base + (uint64_t)L.b, ply);
+        Draw4 fblock{{0u, 0u, 0u, 0u}};
+        if (deep || policy0 > 0 || policy1 > 0) fblock = draw_block(seed, env_base + (uint64_t)L.b, ply, kStreamGreedy);
+        // (word w of a block serves the ply with ply & 3 == w: draw_word's order)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            draws[w][L.lane] = block.w[w];
+            draws[4 + w][L.lane] = fblock.w[w];
+        }
+    };
     const ImageRow row{reinterpret_cast<uint8_t *>(s_state) + L.lane * kCells};
     uint64_t legal = 0;
     uint32_t games = 0, w1 = 0, w2 = 0;
@@ -1594,10 +1611,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
             hp1 = hist_prev3(h0, h1, h2, 1);
         }
         uint32_t r[7];
-        load_state(state, s_state, L, r, [&] {
-            block = draw_block(seed, env_base + (uint64_t)L.b, ply0);
-            if (deep || policy0 > 0 || policy1 > 0) fblock = draw_block(seed, env_base + (uint64_t)L.b, ply0, kStreamGreedy);
-        });
+        load_state(state, s_state, L, r, [&] { park_draws(ply0); });
         mover = L.valid && tm != 0;
         p = planes_of(L, r);
         legal = legal54(p, mover);
@@ -1610,9 +1624,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
         const bool gre = active && L.valid && pol > 0 && tabs >= opening_plies;
         const uint32_t prev3 = mover ? hp1 : hp0;
         // (one tile per workgroup: behind a call, see greedy_tile_call -- 12.6 -> 11.6 us per ply at 16 384 boards, 79 -> 71 at
-        // 262 144; blocks of tiles run at two wavefronts per SIMD anyway and have the registers: inlined, 19.1 -> 18.8 at 65 536)
+        // 262 144; blocks of tiles inlined: <2,8> has the registers, <4,16> exactly its 128 since round 4 -- table above policy_shape)
         GreedyResult g;
-        if constexpr ((NT == 1 && W > 1) || W >= 16)
+        if constexpr ((NT == 1 && W > 1) || (W >= 16 && GBL_X_POLICY16_CALL))
             g = greedy_tile_call<NT, W>(S, p, mover, gre ? legal : 0ull, pol, deep, prev3);
         else
             g = greedy_tile<NT, W>(S, p, mover, gre ? legal : 0ull, pol, deep, prev3, ts);
@@ -1622,8 +1636,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
             // :211-217 with the library's sampler on generator stream 1 (as gbl_greedy_act, keyed by the ply index)
             // (draw32(seed, board, ply, kStreamGreedy) is word ply & 3 of the stream's block for plies 4 * (ply >> 2) ...: one
             // generator call per four plies, like the environment's)
-            const int greedy_action = g.fallback ? pick54(g.cands, draw_word(fblock, ply)) : g.chosen;
-            const int random_action = pick54(legal, draw_word(block, ply));
+            const uint32_t wsel = draw_word_index(ply);
+            const int greedy_action = g.fallback ? pick54(g.cands, draws[4 + wsel][L.lane]) : g.chosen;
+            const int random_action = pick54(legal, draws[wsel][L.lane]);
             action = gre ? greedy_action : random_action;
             if (gre) {  // :219: the acting agent's history takes the returned action
                 const uint32_t np3 = (prev3 >> 8) | (((uint32_t)action & 0xFFu) << 16);
@@ -1631,10 +1646,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
                 hp1 = mover ? np3 : hp1;
             }
         }
-        if (t + 1 < plies && ((ply + 1) & 3u) == 0) {
-            block = draw_block(seed, env_base + (uint64_t)L.b, ply + 1);
-            if (deep || policy0 > 0 || policy1 > 0) fblock = draw_block(seed, env_base + (uint64_t)L.b, ply + 1, kStreamGreedy);
-        }
+        if (t + 1 < plies && ((ply + 1) & 3u) == 0) park_draws(ply + 1);
         const Ply y = play_ply(p, row, mover, legal, action, illegal_mode);
         dn = y.terminal ? 1 : 0;
         if (y.terminal) {  // raw_env.reset, gobblet.py:275-290
@@ -2189,12 +2201,12 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
                            hist, policy0, policy1, opening_plies, illegal_mode, counters, turn);                           \
     } while (0)
     // (the product build instantiates the shapes policy_shape() can return; an A/B build the one it forces as well)
-    if (shape == 48) GBL_CP(4, 8);
+    if (shape == 56) GBL_CP(4, 16);
     else if (shape == 26) GBL_CP(1, 16);
     else if (shape == 28) GBL_CP(2, 8);
     else if (shape == 14) GBL_CP(1, 4);
-#if defined(GBL_FORCE_GREEDY_SHAPE) && GBL_FORCE_GREEDY_SHAPE == 56
-    else if (shape == 56) GBL_CP(4, 16);
+#if defined(GBL_FORCE_GREEDY_SHAPE) && GBL_FORCE_GREEDY_SHAPE == 48
+    else if (shape == 48) GBL_CP(4, 8);
 #endif
 #if defined(GBL_FORCE_GREEDY_SHAPE) && GBL_FORCE_GREEDY_SHAPE == 18
     else if (shape == 18) GBL_CP(1, 8);
@@ -2334,13 +2346,20 @@ int greedy_shape(int depth, int64_t n)
 //     <2,8>                 11.2    11.0      11.2     22.4      44.2      87.8
 //     <4,8>                 15.0    14.9      15.0     15.5      30.5      60.4
 //     <4,16> (behind a call) 16.5   16.7      16.7     16.9      33.3      66.2
+// Round 4 (scripts/ab_policy_collect.py; the wave index a scalar, the output rows' lane index opaque per ply, the two generator
+// blocks parked in LDS: <4,8> 209 -> 132 VGPRs, and <4,16> fits its 128 INLINED without a spill):
+//                                            32 768   65 536   131 072   262 144
+//     <2,8>  / <4,8>  (round 3's choice)       11.1     15.0      29.9      59.4
+//     the same after the register work         10.9     14.7      29.0      57.7
+//     <4,16> behind a call                     13.2     13.5      26.6      52.7
+//     <4,16> inlined                           12.6     12.9      25.2      49.9
 int policy_shape(int depth, int64_t n)
 {
 #ifdef GBL_FORCE_GREEDY_SHAPE
     (void)n;
     return depth <= 1 ? 11 : GBL_FORCE_GREEDY_SHAPE;
 #else
-    return depth <= 1 ? 11 : n <= 16384 ? 26 : n <= 32768 ? 28 : n <= 65536 ? 48 : n <= 262144 && whole_generations(n) ? 48 : 14;
+    return depth <= 1 ? 11 : n <= 16384 ? 26 : n <= 32768 ? 28 : n <= 65536 ? 56 : n <= 262144 && whole_generations(n) ? 56 : 14;
 #endif
 }
 
