@@ -71,9 +71,11 @@ def main():
     for name in ("bench_default", "bench_driver_cmd", "bench_single_ply", "bench_stepmode", "bench_maskonly",
                  "bench_c4_shard_131072", "greedy_65536", "greedy_1048576", "greedy_policy", "playouts"):
         shutil.copy(os.path.join(SRC, name + ".json"), os.path.join(dst, name + ".json"))
+        if os.path.exists(os.path.join(SRC, name + "_full.json")):  # (bench.py: the full record behind the compact line)
+            shutil.copy(os.path.join(SRC, name + "_full.json"), os.path.join(dst, name + "_full.json"))
     for name in ("facade.txt", "valu_rates.txt", "winner_lanes.txt", "write_classes.txt", "placement_probe_check.txt",
                  "placement_ab.txt", "soak_parity.txt", "wave_placement.txt", "valu_mix.txt", "reply_rate.txt",
-                 "greedy_wave_stamps.txt", "icache_cold.txt"):
+                 "greedy_wave_stamps.txt", "icache_cold.txt", "flag_sync.txt", "policy_wave_stamps.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
     # instruction-cache counters of k_greedy at 65 536 and 2^20 boards: the kernel's rows only

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything the numbers in README.md / DESIGN.md / profiles/ come from, in one GPU call:
-#   gpurun -- 'scripts/profile_round.sh'      then      python scripts/profile_collect.py r02
+#   gpurun -- 'scripts/profile_round.sh'      then      python scripts/profile_collect.py r04
 # Writes bench lines and rocprofv3 databases under gpurun_out/final/.
 #   (two calls when one does not fit gpurun's time limit:  scripts/profile_round.sh a   then   scripts/profile_round.sh b;
 #    after a kernel change a third, scripts/profile_round.sh c, re-takes the bench lines against the fresh counters)
@@ -11,18 +11,19 @@ O=gpurun_out/final
 [ "$STAGE" = b ] || [ "$STAGE" = c ] || rm -rf $O
 mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build_$STAGE.log 2>&1   # (no compiler may run under the profiler's preload)
-for m in valu_rates valu_mix icache_cold winner_lanes write_classes wave_placement; do   # the microbenchmarks this script runs
+for m in valu_rates valu_mix icache_cold winner_lanes write_classes wave_placement flag_sync dpp_scan; do   # the microbenchmarks this script runs
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scripts/microbench/$m scripts/microbench/$m.hip >> $O/build_$STAGE.log 2>&1   # always rebuilt: a stale binary must never publish numbers
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gobblet-rl_amd/csrc -o scripts/microbench/reply_rate scripts/microbench/reply_rate.hip >> $O/build_$STAGE.log 2>&1
 [ "$STAGE" = b ] || scripts/build_variant.sh stamps -DGBL_STAMPS >> $O/build_$STAGE.log 2>&1   # (diagnostic build for the phase stamps)
 bench_lines() {
-python bench.py > $O/bench_default.json
-python bench.py --gpus 1 --steps 20 --warmup 5 --no-configs --no-cpu-baseline > $O/bench_driver_cmd.json
-python bench.py --mode fused --no-configs --no-cpu-baseline > $O/bench_single_ply.json
-python bench.py --mode step --no-configs --no-cpu-baseline > $O/bench_stepmode.json
-python bench.py --no-obs --no-configs --no-cpu-baseline > $O/bench_maskonly.json
-python bench.py --boards 131072 --no-configs --no-cpu-baseline > $O/bench_c4_shard_131072.json
+# stdout of bench.py is the compact contract line; the full record (sub-records, per-rank lists) goes to --configs-out
+python bench.py --configs-out $O/bench_default_full.json > $O/bench_default.json
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --configs-out $O/bench_driver_cmd_full.json > $O/bench_driver_cmd.json   # the driver's exact command
+python bench.py --mode fused --no-configs --no-cpu-baseline --configs-out $O/bench_single_ply_full.json > $O/bench_single_ply.json
+python bench.py --mode step --no-configs --no-cpu-baseline --configs-out $O/bench_stepmode_full.json > $O/bench_stepmode.json
+python bench.py --no-obs --no-configs --no-cpu-baseline --configs-out $O/bench_maskonly_full.json > $O/bench_maskonly.json
+python bench.py --boards 131072 --no-configs --no-cpu-baseline --configs-out $O/bench_c4_shard_131072_full.json > $O/bench_c4_shard_131072.json
 }
 if [ "$STAGE" = c ]; then
 # the bench lines once more, AFTER scripts/profile_collect.py has written profiles/pmc_traffic.json for these kernel sources
@@ -45,7 +46,10 @@ scripts/microbench/icache_cold > $O/icache_cold.txt
 scripts/microbench/reply_rate > $O/reply_rate.txt
 GOBBLET_HIP_LIB=build/lib_stamps.so python scripts/microbench/greedy_wave_stamps.py 65536 2> /dev/null > $O/greedy_wave_stamps.txt
 GOBBLET_HIP_LIB=build/lib_stamps.so python scripts/microbench/greedy_wave_stamps.py 1048576 2> /dev/null >> $O/greedy_wave_stamps.txt
+GOBBLET_HIP_LIB=build/lib_stamps.so python scripts/microbench/policy_wave_stamps.py 2> /dev/null > $O/policy_wave_stamps.txt || true
 scripts/microbench/winner_lanes > $O/winner_lanes.txt
+timeout -k 5 60 scripts/microbench/flag_sync > $O/flag_sync.txt
+scripts/microbench/dpp_scan >> $O/flag_sync.txt
 scripts/microbench/wave_placement 1024 28672 > $O/wave_placement.txt
 # ---- placement of the trajectory arrays -------------------------------------------------------
 scripts/microbench/write_classes 160 > $O/write_classes.txt
@@ -54,10 +58,12 @@ python scripts/placement_probe_check.py 224 > $O/placement_probe_check.txt 2> /d
 python scripts/placement_probe_check.py 224 131072 32 >> $O/placement_probe_check.txt 2> /dev/null
 for i in 1 2 3 4 5; do   # fresh processes: placed by the probe / as the allocator hands the arrays out
   for pl in auto any; do
-    python bench.py --no-configs --no-cpu-baseline --placement $pl 2> /dev/null | python -c "
-import json, sys
-d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('run $i placement $pl: %.3e env-steps/s, %.2f us per ply, roofline.frac %.3f, %s' % (d['value'], d['ms_per_step'] * 1e3, d['roofline']['frac'], json.dumps(d['config']['trajectory_placement'])))" >> $O/placement_ab.txt
+    python bench.py --no-configs --no-cpu-baseline --placement $pl --configs-out $O/placement_run.json > $O/placement_run.line 2> /dev/null
+    python -c "
+import json
+d = json.loads(open('$O/placement_run.line').read().strip().splitlines()[-1])
+f = json.load(open('$O/placement_run.json'))
+print('run $i placement $pl: %.3e env-steps/s, %.2f us per ply, roofline.frac %.3f, %s' % (d['value'], d['ms_per_step'] * 1e3, d['roofline']['frac'], json.dumps(f['detail']['trajectory_placement_per_rank'][0])))" >> $O/placement_ab.txt
   done
 done
 # the same with 200 GiB of the device already taken by the process (a trainer's model and replay buffer): the search is capped
