@@ -1,4 +1,4 @@
-"""world_size-2 `gloo` test of the N>1 path on CPU: contiguous shards, sampler keyed by the global
+"""world_size-2 and -8 `gloo` tests of the N>1 path on CPU: contiguous shards, sampler keyed by the global
 board id (results independent of the number of shards), no collective on the step path, tallies
 summed afterwards.  The per-shard compute is the device code compiled for the host (tests/emu),
 standing in for the GPU each rank would own."""
@@ -40,18 +40,22 @@ def test_shard_bounds():
         G.shard_bounds(10, 2, 2)
 
 
-def test_two_rank_gloo_equals_single_shard():
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_ranks_equal_single_shard(world):
+    """Two ranks, and EIGHT -- the shape of BASELINE config 4 (one rank per GPU of a node; here eight CPU processes over gloo):
+    ragged shards (1037 boards over 8 ranks: 130 and 129), the rendezvous, the one all-reduce after the run."""
     with tempfile.TemporaryDirectory() as d:
         initfile = os.path.join(d, "init")
-        mp.spawn(_worker, args=(2, initfile, d), nprocs=2, join=True)
-        parts = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(2)]
+        mp.spawn(_worker, args=(world, initfile, d), nprocs=world, join=True)
+        parts = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
     s, tm, dn = oracle.batch_reset(TOTAL)
     ref = oracle.batch_rollout(s, tm, dn, SEED, 0, 0, PLIES, threads=4)
-    assert int(parts[0]["start"]) == 0 and int(parts[1]["start"]) == int(parts[0]["count"])
+    assert int(parts[0]["start"]) == 0
+    assert all(int(parts[r + 1]["start"]) == int(parts[r]["start"]) + int(parts[r]["count"]) for r in range(world - 1))
     assert np.array_equal(np.concatenate([p["state"] for p in parts]), s)
     assert np.array_equal(np.concatenate([p["to_move"] for p in parts]), tm)
     assert np.array_equal(np.concatenate([p["mask"] for p in parts]), ref["mask"])
-    for p in parts:  # both ranks hold the global tallies
+    for p in parts:  # every rank holds the global tallies
         assert np.array_equal(p["tallies"], ref["counters"])
 
 
