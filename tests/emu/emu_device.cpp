@@ -107,6 +107,11 @@ void load_rows_keep(const int8_t *state, const TileCtx &t, uint32_t (*r)[7], uin
     }
 }
 
+struct RegRowNone {
+    void apply(const MoveCells &) const {}
+    void reset() const {}
+};
+
 template <typename F>
 void for_tiles(int64_t n, F f)
 {
@@ -329,6 +334,80 @@ void emu_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_
             out_all<kObs>(obs_out + t.tile * (kTile * kObs), io.p(), t.rows);
         }
     });
+}
+
+// The small-batch kernel's walk (k_collect_small, gobblet_hip.hip): a sub-tile of 16 boards per wavefront, lane = 4 * board + j;
+// the four lanes of a board play the game alike and share the row work -- lane j writes bytes [16 j, 16 j + 16) of the board's
+// mask row (mask_row_quad) and drops channels j, j + 4, j + 8 of its observation row (obs_scatter_quad).  `plies` plies, the
+// outputs of the last one stored (what gbl_collect's last slot holds), all three roles folded into one walk.
+void emu_rollout_small(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_out, int8_t *winner_out,
+                       int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, uint64_t seed, uint64_t env_base,
+                       uint32_t ply0, uint32_t plies, int illegal_mode)
+{
+    const int64_t nsub = (n + kSub - 1) / kSub;
+    for (int64_t sub = 0; sub < nsub; ++sub) {
+        const int64_t left = n - sub * kSub;
+        const int rows = left < kSub ? (int)left : kSub;
+        std::vector<uint32_t> is(kSub * kCells / 4 + 4, 0xDEADBEEFu), im(kSub * kActions / 4 + 4, 0xDEADBEEFu),
+            io(kSub * kObs / 4 + 4, 0xDEADBEEFu);
+        for (int lane = 0; lane < 64; ++lane) sub_in<kCells>(state + sub * (kSub * kCells), is.data(), lane, rows);
+        Planes P[64];
+        int MOVER[64];
+        uint64_t LEGAL[64];
+        uint32_t R[64][7];
+        int MOVER0[64];
+        for (int lane = 0; lane < 64; ++lane) {  // all lanes read their rows and movers before any lane patches or stores (lockstep)
+            row_load<kCells>(is.data(), lane >> 2, R[lane]);
+            R[lane][6] &= 0x00FFFFFFu;
+            MOVER0[lane] = (lane >> 2) < rows ? (to_move[sub * kSub + (lane >> 2)] != 0) : 0;
+        }
+        for (int lane = 0; lane < 64; ++lane) {  // every lane of a quad has read the same row and plays the same game
+            const int bq = lane >> 2;
+            const bool valid = bq < rows;
+            const int64_t b = sub * kSub + bq;
+            Planes p = make_planes(R[lane]);
+            p.nz = valid ? p.nz : 0u;
+            int mover = MOVER0[lane];
+            Ply y{0, 0, 0, false, false};
+            int dn = 0, action = -1;
+            uint64_t legal = legal54(p, mover);
+            for (uint32_t k = 0; k < plies; ++k) {
+                action = sample54(legal, seed, env_base + (uint64_t)b, ply0 + k);
+                // (only lane 0 of a quad patches the state image, as role 0's four lanes write the same bytes)
+                if ((lane & 3) == 0)
+                    y = play_ply(p, ImageRow{reinterpret_cast<uint8_t *>(is.data()) + bq * kCells}, mover, legal, action, illegal_mode);
+                else
+                    y = play_ply(p, RegRowNone{}, mover, legal, action, illegal_mode);
+                dn = y.terminal ? 1 : 0;
+                if (y.terminal) {
+                    p = Planes{0u, 0u, 0u};
+                    mover = 0;
+                    if ((lane & 3) == 0) ImageRow{reinterpret_cast<uint8_t *>(is.data()) + bq * kCells}.reset();
+                }
+                legal = legal54(p, mover);
+            }
+            P[lane] = p; MOVER[lane] = mover; LEGAL[lane] = legal;
+            if (valid && (lane & 3) == 0) {
+                to_move[b] = (int8_t)mover;
+                done[b] = (int8_t)dn;
+                if (actions_out) actions_out[b] = action;
+                if (winner_out) winner_out[b] = (int8_t)y.winner;
+                if (reward_out) { reward_out[2 * b] = (int8_t)y.r0; reward_out[2 * b + 1] = (int8_t)y.r1; }
+            }
+        }
+        for (int lane = 0; lane < 64; ++lane) sub_out<kCells, kStorePlain>(state + sub * (kSub * kCells), is.data(), lane, rows);
+        if (mask_out) {
+            for (int lane = 0; lane < 64; ++lane)
+                mask_row_quad(reinterpret_cast<uint8_t *>(im.data()) + (lane >> 2) * kActions, LEGAL[lane], lane & 3);
+            for (int lane = 0; lane < 64; ++lane) sub_out<kActions, kStorePlain>(mask_out + sub * (kSub * kActions), im.data(), lane, rows);
+        }
+        if (obs_out) {
+            for (int lane = 0; lane < 64; ++lane) sub_obs_zero(io.data(), lane);
+            for (int lane = 0; lane < 64; ++lane)
+                obs_scatter_quad(reinterpret_cast<uint8_t *>(io.data()) + (lane >> 2) * kObs, P[lane], MOVER[lane], lane & 3);
+            for (int lane = 0; lane < 64; ++lane) sub_out<kObs, kStorePlain>(obs_out + sub * (kSub * kObs), io.data(), lane, rows);
+        }
+    }
 }
 
 void emu_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply)
