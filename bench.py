@@ -76,8 +76,9 @@ CONFIG_RECORDS = {
     "step_pipeline_1048576": (1 << 20, 200, False, "step"),
 }
 # ... plus two records with their own drivers: c5_greedy_65536 (greedy_run) and greedy_collect_65536 (greedy_collect_run)
-EXTRA_RECORDS = ("c5_greedy_65536", "greedy_collect_65536", "two_stream_single_ply_131072", "two_stream_single_ply_262144",
-                 "step_reply_131072", "step_reply_262144")
+EXTRA_RECORDS = ("c5_greedy_65536", "greedy_collect_65536", "step_reply_131072", "step_reply_262144")
+# (rounds 3-4 also carried two_stream_single_ply_*: two half batches on two streams inside one hipGraph, a negative result --
+#  0.35-0.39 / 0.48-0.58 of the peak against 0.57 / 0.73 on one stream, profiles/r03 and r04/bench_default_full.json; dropped)
 
 
 def parse():
@@ -350,40 +351,6 @@ def short_run(G, torch, dev, boards, K, W, no_obs=False, mode="collect", traj=32
         rec["trajectory_placement"] = p.traj["_placement"]
     del g, p
     return rec
-
-
-def two_stream_run(G, torch, dev, boards, K, W):
-    """One ply per launch (gbl_rollout, the external-consumer pipeline) with the batch cut in two halves that run on two
-    streams inside one hipGraph: a half's launch ramp (XCD start stagger + first wave's life) overlaps the
-    other half's store phase.  Candidate (a) of the one-ply pipelines at C3 / C4-shard sizes."""
-    half = boards // 2
-    pa = Pipeline(G, torch, half, 0, dev, mode="fused")
-    pb = Pipeline(G, torch, boards - half, half, dev, mode="fused")
-    pa.eager(W); pb.eager(W)
-    torch.cuda.synchronize(dev)
-    g, s2 = torch.cuda.CUDAGraph(), torch.cuda.Stream(dev)
-    with torch.cuda.graph(g, capture_error_mode="thread_local"):
-        s1 = torch.cuda.current_stream(dev)
-        s2.wait_stream(s1)
-        for i in range(K):
-            pa.enqueue(i, 1, s1.cuda_stream)
-            pb.enqueue(i, 1, s2.cuda_stream)
-        pa.advance(K, s1.cuda_stream); pb.advance(K, s2.cuda_stream)
-        s1.wait_stream(s2)
-    g.replay()
-    torch.cuda.synchronize(dev)
-    a, b = pa.events(1)[0]
-    a.record(); g.replay(); b.record()
-    torch.cuda.synchronize(dev)
-    sec = a.elapsed_time(b) / 1e3
-    total = ALGO_BYTES_FULL * boards * K
-    return {"workload": f"{boards} boards x 1 GPU as two half batches on two streams in one hipGraph, one ply per launch "
-                        f"(gbl_rollout), FULL outputs every ply, {K} plies",
-            "value": boards * K / sec, "unit": "env-steps/s", "us_per_step": sec / K * 1e6,
-            "roofline": {"bound": "hbm", "achieved": total / sec / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": total / sec / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "2 x k_rollout (plies=1)<mask,obs> on two streams", "algorithmic_bytes_per_env_step": ALGO_BYTES_FULL,
-                         "timing": "HIP events around the graph replay (two streams forked and joined inside the graph)"}}
 
 
 def step_reply_run(G, torch, dev, boards, K, W):
@@ -790,9 +757,8 @@ def main():
             for name, (n, k, noobs, mode) in CONFIG_RECORDS.items():
                 cfg[name] = short_run(G, torch, dev, n, k, W, no_obs=noobs, mode=mode, traj=auto_traj(n, k),
                                       placement=args.placement)
-            # the external-policy pipelines at the C3 / C4-shard sizes: two candidates against single_ply_* above
+            # an external policy's ply + the masked-random reply in one launch, at the C3 / C4-shard sizes (against single_ply_*)
             for n in (131072, 262144):
-                cfg[f"two_stream_single_ply_{n}"] = two_stream_run(G, torch, dev, n, 200, W)
                 cfg[f"step_reply_{n}"] = step_reply_run(G, torch, dev, n, 200, W)
             cfg["c5_greedy_65536"] = greedy_run(G, torch, dev)
             cfg["greedy_collect_65536"] = greedy_collect_run(G, torch, dev)

@@ -342,8 +342,6 @@ def test_bench_config_keys_are_all_covered(G):
         "step_pipeline_1048576",   # test_bench_step_mode_vs_oracle
         "c5_greedy_65536",         # test_gpu_parity.py::test_greedy_config5_full_size
         "greedy_collect_65536",    # test_gpu_policy_collect.py::test_policy_collect_config5_size_selfplay
-        # gbl_collect_from, T = 2: test_collect_from_external_first_ply_vs_oracle; the two-stream records launch the
-        # single_ply kernel on half batches (test_bench_single_ply_record_vs_oracle[single_ply_131072] covers that size's half
-        # through single_ply_4096 .. 131072: the same instantiation at every size below 2^21 boards)
-        "step_reply_131072", "step_reply_262144", "two_stream_single_ply_131072", "two_stream_single_ply_262144"}
+        # gbl_collect_from, T = 2: test_collect_from_external_first_ply_vs_oracle
+        "step_reply_131072", "step_reply_262144"}
     assert keys <= covered, keys - covered
