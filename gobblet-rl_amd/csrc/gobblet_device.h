@@ -1352,6 +1352,48 @@ __device__ __forceinline__ uint32_t greedy_hand_lookup(uint64_t replies, uint64_
     return s;
 }
 
+// The same two in the form the kernel's owners run them (round 4): an item's lane TAGS its table row -- bits 0-53 the set
+// greedy_undefused gives, bits 56-61 the member a2 itself, bit 63 "a2 is a legal move of ours on the root" -- so that the owner's
+// merge needs neither the k-th member of R (a 64-bit find-first-set and clear per step) nor a 64-bit shift of its legal set:
+// the rows are in rank order, row j is live iff j < |R|, and everything else is in the row.  ~14 instead of ~30 instructions per
+// step of a loop that runs on ONE wavefront per SIMD.  tests/emu runs the kernel's walk through these and checks every settled
+// candidate against the exact evaluation, as before.
+__device__ __forceinline__ uint64_t greedy_item_row(const Planes &p, int me, uint64_t legal_me, uint32_t a2)
+{
+    return greedy_undefused(p, me, a2) | ((uint64_t)a2 << 56) | (((legal_me >> a2) & 1ull) << 63);
+}
+
+__device__ __forceinline__ GreedyHandSets greedy_hand_merge_tagged(int n, uint64_t resolved, const uint64_t (&rows)[kRootItems])
+{
+    GreedyHandSets s{0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+    for (int j = 0; j < kRootItems; ++j) {
+        const bool live = j < n;
+        const uint64_t u = live ? rows[j] & resolved : 0ull;     // (resolved has no bit above 53: the tags go with the mask)
+        const bool ours = live && (int64_t)rows[j] < 0;
+        s.second |= u & s.threat;
+        s.flegal |= ours ? (u & ~s.threat) : 0ull;  // the FIRST winning reply is a legal move of ours
+        s.block |= ours ? u : 0ull;
+        s.threat |= u;
+    }
+    return s;
+}
+
+__device__ __forceinline__ uint32_t greedy_hand_lookup_tagged(int n, uint64_t legal_me, const uint64_t (&rows)[kRootItems], uint32_t a)
+{
+    uint64_t ow = 0;
+#pragma unroll
+    for (int j = 0; j < kRootItems; ++j)
+        if (j < n && ((rows[j] >> a) & 1ull)) ow |= 1ull << ((uint32_t)(rows[j] >> 56) & 63u);
+    const uint64_t block = ow & legal_me;
+    uint32_t s = ow ? 1u : 0u;
+    s |= (ow ? (uint32_t)__builtin_ctzll(ow) : 0u) << 1;
+    s |= (ow & (ow - 1)) ? 1u << 7 : 0u;
+    s |= block ? 1u << 8 : 0u;
+    s |= (block ? (uint32_t)__builtin_ctzll(block) : 0u) << 9;
+    return s;
+}
+
 // Which candidates are evaluated (exactly, in the pooled round), which are settled from the root, and the root's
 // replies if they are to be dealt out as items.
 struct GreedyRootPlan {

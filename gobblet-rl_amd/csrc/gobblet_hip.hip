@@ -1390,7 +1390,7 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
                     const uint32_t it = S.item[g], o = it >> 8, jr = it & 0xFFu;
                     const Planes q{S.board[o][0], S.board[o][1], S.board[o][2]};
                     const uint32_t a2 = kth_bit64(S.replies[o], jr);
-                    S.undef[o][jr] = greedy_undefused(q, (int)(S.board[o][3] & 1u), a2);
+                    S.undef[o][jr] = greedy_item_row(q, (int)(S.board[o][3] & 1u), S.legal[o], a2);  // (tagged: see greedy_hand_merge_tagged)
                 }
             }
         }
@@ -1405,10 +1405,11 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
     if (two) {  // :103-157 on the owner's lane, in closed form over the candidate sets
         ReplySets r{S.threat[bi], S.allwin[bi], S.second[bi], S.block[bi], S.flegal[bi]};
         uint64_t undef[kRootItems] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-        if (plan.items) {  // the placements settled from the root: the table's rows merged in the reference's reply order
+        const int nitems_b = __popcll(plan.items);
+        if (plan.items) {  // the placements settled from the root: the table's (tagged) rows merged in the reference's reply order
 #pragma unroll
-            for (int j = 0; j < kRootItems; ++j) undef[j] = S.undef[bi][j] & plan.resolved;
-            const GreedyHandSets hs = greedy_hand_merge(plan.items, h.legal_me, undef);
+            for (int j = 0; j < kRootItems; ++j) undef[j] = S.undef[bi][j];
+            const GreedyHandSets hs = greedy_hand_merge_tagged(nitems_b, plan.resolved, undef);
             r.threat |= hs.threat;
             r.second |= hs.second;
             r.block |= hs.block;
@@ -1416,7 +1417,7 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
         }
         greedy_replay_closed(h, r, [&](int a) {
             const uint32_t twin = ((h.dup >> a) & 1ull) ? (uint32_t)a - 9u : (uint32_t)a;  // twin placements share a summary
-            return ((plan.resolved >> twin) & 1ull) ? greedy_hand_lookup(plan.items, h.legal_me, undef, twin)
+            return ((plan.resolved >> twin) & 1ull) ? greedy_hand_lookup_tagged(nitems_b, h.legal_me, undef, twin)
                                                     : (uint32_t)S.reply[bi][twin];
         });
     }

@@ -602,7 +602,7 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
             for (uint64_t it = PLAN[l].eval; it; it &= it - 1) pair[total++] = (uint16_t)((l << 8) | __builtin_ctzll(it));
             const int nr = __builtin_popcountll(PLAN[l].items);
             for (int j = 0; j < nr; ++j) {  // the items (board, j)
-                undef[l][j] = greedy_undefused(P[l], ME[l], kth_bit64(PLAN[l].items, (uint32_t)j));
+                undef[l][j] = greedy_item_row(P[l], ME[l], H[l].legal_me, kth_bit64(PLAN[l].items, (uint32_t)j));  // (tagged, as the kernel's item lanes leave them)
                 g_items++;
             }
         }
@@ -636,8 +636,15 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
             // exactly what the kernel does (gobblet_hip.hip, greedy_tile's tail): ALL kRootItems rows, `& resolved` only -- the rows
             // nobody wrote hold the poison above (the kernel: stale LDS), and only the `live` guards of greedy_hand_merge /
             // greedy_hand_lookup keep them out of the result: a regression there shows up as a mismatch below
-            for (int j = 0; j < kRootItems; ++j) UND[l][j] = undef[l][j] & PLAN[l].resolved;
-            const GreedyHandSets hs = greedy_hand_merge(PLAN[l].items, H[l].legal_me, UND[l]);
+            for (int j = 0; j < kRootItems; ++j) UND[l][j] = undef[l][j];
+            const int nr = __builtin_popcountll(PLAN[l].items);
+            const GreedyHandSets hs = greedy_hand_merge_tagged(nr, PLAN[l].resolved, UND[l]);
+            {   // the tagged merge against the plain one (greedy_hand_merge on rows without tags, live rows only)
+                uint64_t plain[kRootItems];
+                for (int j = 0; j < kRootItems; ++j) plain[j] = (j < nr ? undef[l][j] & PLAN[l].resolved : 0xDEADBEEFDEADBEEFull);
+                const GreedyHandSets hp = greedy_hand_merge(PLAN[l].items, H[l].legal_me, plain);
+                if (hp.threat != hs.threat || hp.second != hs.second || hp.block != hs.block || hp.flegal != hs.flegal) g_fast_mismatch++;
+            }
             threat[l] |= hs.threat; second[l] |= hs.second; block[l] |= hs.block; flegal[l] |= hs.flegal;
         }
         // THE RULE ITSELF, on every candidate it settles: the summary looked up in the table and the merged set bits must be
@@ -646,7 +653,7 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
             for (uint64_t it = PLAN[l].resolved; it; it &= it - 1) {
                 const uint32_t a = (uint32_t)__builtin_ctzll(it);
                 const uint32_t want = greedy_reply(P[l], ME[l], H[l].legal_me, a);
-                const uint32_t got = PLAN[l].items ? greedy_hand_lookup(PLAN[l].items, H[l].legal_me, UND[l], a) : 0u;
+                const uint32_t got = PLAN[l].items ? greedy_hand_lookup_tagged(__builtin_popcountll(PLAN[l].items), H[l].legal_me, UND[l], a) : 0u;
                 const bool fl = (want & 1u) && ((H[l].legal_me >> ((want >> 1) & 63u)) & 1ull);
                 g_held++;
                 if (want != got || ((threat[l] >> a) & 1ull) != (want & 1u) || ((second[l] >> a) & 1ull) != ((want >> 7) & 1u) ||
@@ -660,7 +667,7 @@ void emu_greedy(const int8_t *state, const int8_t *to_move, const int8_t *mask_i
             if (pooled) {
                 auto reply_of = [&](int a) {
                     const uint32_t twin = ((H[l].dup >> a) & 1ull) ? (uint32_t)a - 9u : (uint32_t)a;
-                    return ((PLAN[l].resolved >> twin) & 1ull) ? greedy_hand_lookup(PLAN[l].items, H[l].legal_me, UND[l], twin)
+                    return ((PLAN[l].resolved >> twin) & 1ull) ? greedy_hand_lookup_tagged(__builtin_popcountll(PLAN[l].items), H[l].legal_me, UND[l], twin)
                                                                : (uint32_t)reply[l][twin];
                 };
                 GreedyHead seq = H[l];  // the loop form and the closed form must agree on everything they leave behind
