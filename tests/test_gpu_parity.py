@@ -1212,7 +1212,7 @@ def test_placement_probe_and_spread_buffers(G):
     free0, _ = torch.cuda.mem_get_info()
     spread = e1.trajectory_buffers(T)  # placement="auto"
     info = spread["_placement"]
-    assert set(info) >= {"spread", "ratio", "probes", "block_gib", "held_gib", "cap_gib", "ended", "seconds"} and 1 <= len(info["probes"]) <= placement.MAX_PROBES + 1  # (+ the allocator's own pair)
+    assert set(info) >= {"spread", "ratio", "probes", "block_gib", "held_gib", "cap_gib", "ended", "seconds"} and 1 <= len(info["probes"]) <= placement.MAX_PROBES + 1 + len(placement.FAR_GAPS_BYTES)  # (+ the allocator's own pair, + the far candidates)
     assert 0.5 < info["ratio"] < 1.2 and info["held_gib"] <= info["cap_gib"] <= placement.MAX_HOLD_BYTES / placement.GIB
     assert info["cap_gib"] * placement.GIB <= max(free0 / placement.FREE_FRACTION, 4 * placement.GIB) + (1 << 30)
     assert spread["observation"].shape == (T, n, 3, 3, 13) and spread["action_mask"].shape == (T, n, 54)
