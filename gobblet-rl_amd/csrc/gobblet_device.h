@@ -1217,6 +1217,16 @@ __device__ __forceinline__ uint64_t greedy_from_hand(const Planes &p, int me)
     return from_hand;
 }
 
+// have = a 9-bit set of squares: the squares that complete a line inside it (exactly one square of the line missing) -- or every
+// square, if it holds a complete line already.  As threat squares (round 4: ~35 instead of the eight-line walk's ~60 instructions, on
+// the longest wavefront of the greedy kernels' B phase): a square both of whose partners on some line are in `have` is a threat
+// square; one that is itself in `have` means a full line.  tests/emu checks all 512 sets against the line walk.
+__device__ __forceinline__ uint32_t risky_from_have(uint32_t have)
+{
+    const uint32_t th = threat3(have & 0x1FFu) & 0x1FFu;  // (one field; what the shifts push into the fields above is masked off)
+    return (th & have) ? 0x1FFu : th;
+}
+
 // The squares on which a placement of ours could let a LIFT by the opponent hand us a line (then the opponent's replies
 // are not just "the root's winning moves, minus the defused ones", see below): with "have" = our tops and our pieces
 // directly under the opponent's, the squares that complete a line inside have -- or every square, if have holds a line already.
@@ -1229,17 +1239,7 @@ __device__ __forceinline__ uint32_t greedy_risky_squares(const Planes &p, int me
     const uint32_t o1 = m1 | t1, o2 = m2 | t2;
     const uint32_t To = t2 | (~o2 & (t1 | (~o1 & t0)));       // our tops
     const uint32_t X = (m1 & t0) | (m2 & (t1 | (~o1 & t0)));  // ours directly below a piece of the opponent's
-    const uint32_t T = (To | X) & 0x1FFu;
-    constexpr uint32_t L[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x111u, 0x054u};
-    uint32_t risky = 0;
-    bool full = false;
-#pragma unroll
-    for (int l = 0; l < 8; ++l) {
-        const uint32_t miss = L[l] & ~T;
-        full = full || miss == 0;
-        if ((miss & (miss - 1)) == 0) risky |= miss;  // exactly one square missing: that square completes the line
-    }
-    return full ? 0x1FFu : risky;
+    return risky_from_have((To | X) & 0x1FFu);
 }
 
 // ---- placements from hand, settled from the ROOT position alone (round 3) ------------------------------------------------

@@ -1639,7 +1639,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
             // generator call per four plies, like the environment's)
             const uint32_t wsel = draw_word_index(ply);
             const int greedy_action = g.fallback ? pick54(g.cands, draws[4 + wsel][L.lane]) : g.chosen;
-            const int random_action = pick54(legal, draws[wsel][L.lane]);
+            // (the masked-random pick only where some board of the tile needs one: none in greedy-vs-greedy play past the openings)
+            int random_action = -1;
+            if (wave_any(L.valid && !gre)) random_action = pick54(legal, draws[wsel][L.lane]);
             action = gre ? greedy_action : random_action;
             if (gre) {  // :219: the acting agent's history takes the returned action
                 const uint32_t np3 = (prev3 >> 8) | (((uint32_t)action & 0xFFu) << 16);

@@ -410,6 +410,24 @@ void emu_rollout_small(int8_t *state, int8_t *to_move, int8_t *done, int32_t *ac
     }
 }
 
+// risky_from_have (threat squares) against the walk over the eight lines it replaced, for all 512 sets: mismatches
+int emu_risky_mismatches(void)
+{
+    constexpr uint32_t L[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x111u, 0x054u};  // board.py:135-153
+    int bad = 0;
+    for (uint32_t T = 0; T < 512; ++T) {
+        uint32_t risky = 0;
+        bool full = false;
+        for (int l = 0; l < 8; ++l) {
+            const uint32_t miss = L[l] & ~T;
+            full = full || miss == 0;
+            if ((miss & (miss - 1)) == 0) risky |= miss;  // exactly one square missing: that square completes the line
+        }
+        bad += risky_from_have(T) != (full ? 0x1FFu : risky);
+    }
+    return bad;
+}
+
 void emu_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply)
 {
     for_tiles(n, [&](TileCtx t) {

@@ -141,6 +141,12 @@ def test_small_batch_walk_vs_oracle(n, plies, illegal):
         assert np.array_equal(o1[k], o2[k]), k
 
 
+def test_risky_squares_as_threat_squares():
+    """greedy_risky_squares' core -- the squares that complete a line inside a 9-bit set, or all nine if it holds one -- as threat
+    squares (risky_from_have) against the walk over the eight lines, on all 512 sets."""
+    assert emu.lib().emu_risky_mismatches() == 0
+
+
 @pytest.mark.parametrize("depth", [1, 2])
 def test_greedy_vs_golden_and_oracle(golden_dir, depth):
     g = np.load(os.path.join(golden_dir, "greedy.npz"))
