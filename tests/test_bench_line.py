@@ -1,0 +1,65 @@
+"""CPU-side guard of bench.py's output contract: the LAST stdout line must be a compact JSON record the driver can parse from
+the tail of stdout (round 3's 20 kB line came back `parsed: null`).  No GPU: the record is built from a stand-in of a run."""
+import json
+import os
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline")
+
+
+def fake_full(world=8, configs=16, blob=2000):
+    args = types.SimpleNamespace(no_obs=False, boards_per_gpu=0, mode="collect", traj=20, dist_backend="nccl")
+    pipe = types.SimpleNamespace()
+    roof = {"bound": "hbm", "achieved": 7002.2, "peak": 8000.0, "unit": "GB/s", "frac": 0.875, "traffic": 3837975851.0,
+            "traffic_over_algorithmic": 1.012, "kernel": "k_collect (20 plies per launch)<mask,obs>", "algorithmic_bytes_per_env_step": 180.85,
+            "algorithmic_bytes_per_launch": 3792699392.0, "mean_launch_us": 541.6, "launches_timed": 1, "timing": "t" * 300,
+            "traffic_source": "s" * 300, "note": "n" * blob}
+    placements = [{"ratio": 0.8 + 0.01 * r, "probes": [1.0] * 19, "held_gib": 62.0, "cap_gib": 64.0, "spread": True, "ended": "e" * 200}
+                  for r in range(world)]
+    full = bench.contract_record(args, pipe, roof, 1 << 20, (1 << 20) // world, world, 20, 5, 6.0e-4, 5.6e-4, 1, False,
+                                 [72.0 + r for r in range(world)], placements, True)
+    full["configs"] = {f"record_{i}": {"workload": "w" * blob, "value": 1.0, "roofline": {"frac": 0.5, "note": "x" * blob}} for i in range(configs)}
+    full["cpu_baseline"] = {"value": 8.7e6, "unit": "env-steps/s", "cores": 16, "kind": "port", "sample": "s" * 400, "value_1core": 5.8e5,
+                            "greedy_depth2": {"decisions_per_s_1core": 1.0e4, "sample": "g" * blob}}
+    return full
+
+
+def test_compact_line_is_small_flat_and_complete():
+    full = fake_full()
+    assert len(json.dumps(full)) > 40000                       # (the full record is what round 3 printed)
+    text = bench.compact_line(full, "gpurun_out/bench_configs.json")
+    assert "\n" not in text and len(text.encode()) < bench.COMPACT_LIMIT == 4096
+    d = json.loads(text)
+    for k in CONTRACT + ("cpu_baseline",):
+        assert k in d, k
+    assert "configs" not in d and "detail" not in d
+    for sub in ("config", "roofline", "cpu_baseline"):
+        assert all(not isinstance(v, (list, dict)) for v in d[sub].values()), sub
+    assert d["roofline"]["frac"] == 0.875 and d["roofline"]["traffic"] and d["roofline"]["traffic_over_algorithmic"] == 1.012
+    assert d["cpu_baseline"]["value"] == 8.7e6 and d["cpu_baseline"]["cores"] == 16 and d["cpu_baseline"]["kind"] == "port"
+    c = d["config"]
+    assert c["configs_file"] == "gpurun_out/bench_configs.json" and c["configs_recorded"] == 16
+    assert c["kernel_us_max"] == 79.0 and c["kernel_us_min"] == 72.0 and c["rccl_ranks"] == 8
+    assert abs(c["placement_ratio_min"] - 0.8) < 1e-9 and abs(c["placement_ratio_max"] - 0.87) < 1e-9
+    # value / ms_per_step come from the ranks' own spans, the trailing barrier is reported beside them
+    assert abs(d["value"] - (1 << 20) * 20 / 5.6e-4) / d["value"] < 1e-12 and abs(d["ms_per_step"] - 5.6e-4 / 20 * 1e3) < 1e-12
+    assert c["ms_per_step_with_trailing_barrier"] > d["ms_per_step"]
+
+
+def test_compact_line_sheds_prose_before_it_grows_too_long():
+    full = fake_full()
+    full["roofline"]["timing"] = "t" * 3000                    # (prose that would push the line past the limit is dropped, numbers never)
+    d = json.loads(bench.compact_line(full, None))
+    assert "timing" not in d["roofline"] and d["roofline"]["frac"] == 0.875 and len(json.dumps(d).encode()) < 4096
+
+
+def test_valu_roofline_uses_the_two_cycle_peak():
+    r = bench.valu_roofline("no-such-key", "k", 1e-5, 1, "t")
+    assert r["peak"] == 1024 * 2.4e9 / 2 and r["frac"] is None   # (no committed counter for that key: null, with the reason)
+    assert bench.VALU_CYCLES_PEAK == 2.0
