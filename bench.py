@@ -59,12 +59,14 @@ ALGO_BYTES_COLLECT_PLY, ALGO_BYTES_COLLECT_PLY_MASK_ONLY, ALGO_BYTES_COLLECT_LAU
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; max shader clock (MI355X_MICROARCH.md)
 TOTAL_BOARDS = 1 << 20
-COLLECT_KERNELS = {0: "k_collect", 1: "k_collect (plain stores)", 2: "k_collect2", 3: "k_collect_small"}  # gbl_collect_variant()
+COLLECT_KERNELS = {0: "k_collect", 1: "k_collect (plain stores)", 2: "k_collect2", 3: "k_collect_small<4 lanes/board>",
+                   4: "k_collect_small<2 lanes/board>", 5: "k_collect_small<1 lane/board>"}  # gbl_collect_variant()
 
 # The sub-records of an N = 1 run: name -> (boards, timed plies, MASK_ONLY, mode).  tests/test_gpu_bench_kernels.py compares
 # the kernel instantiation each one times with the oracle, at the same batch size and through the same entry point.
 CONFIG_RECORDS = {
-    "c2_4096": (4096, 256, False, "collect"), "c3_262144": (262144, 128, False, "collect"),
+    "c2_4096": (4096, 256, False, "collect"), "c_16384": (16384, 256, False, "collect"), "c_32768": (32768, 256, False, "collect"),
+    "c_65536": (65536, 256, False, "collect"), "c3_262144": (262144, 128, False, "collect"),
     "c4_shard_131072": (131072, 256, False, "collect"), "large_4194304": (1 << 22, 64, False, "collect"),
     "maskonly_1048576": (1 << 20, 64, True, "collect"),
     # round 1's pipeline, one launch per ply (gbl_rollout, 234 algorithmic bytes per env-step)
@@ -218,7 +220,7 @@ class Pipeline:
         self.ctr = torch.zeros(1, dtype=torch.int32, device=dev)  # plies played so far (keys the sampler)
         self.traj = None
         if mode == "collect":
-            self.traj = env.trajectory_buffers(self.T, placement=placement)
+            self.traj = env.trajectory_buffers(self.T, placement=placement, far=True)  # (the benchmark owns the device)
             f = self.traj["_full"]
             self.TP = dict(ac=f["actions"].data_ptr(), wi=f["winner"].data_ptr(), rw=f["rewards"].data_ptr(),
                            dn=f["done"].data_ptr(), tm=f["to_move"].data_ptr(), mk=f["action_mask"].data_ptr(),
@@ -517,29 +519,31 @@ def greedy_collect_run(G, torch, dev, boards=65536, T=16, launches=8, policies=(
 
 
 COMPACT_LIMIT = 4096  # bytes: the driver keeps the tail of stdout only; the contract line must fit it with room to spare
-ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel",
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel",
                  "algorithmic_bytes_per_env_step", "algorithmic_bytes_per_launch", "mean_launch_us", "launches_timed", "timing")
 CPU_BASELINE_KEYS = ("value", "unit", "cores", "kind", "sample", "value_1core")
 
 
 def contract_record(args, p, roof, total, boards, world, K, W, elapsed, local_elapsed, nlaunch, graphed, per_rank_us,
-                    per_rank_placement, distributed):
+                    per_rank_placement, distributed, repeats_us):
     """The whole record of the headline run: the contract's keys, a `config` of one workload string and scalars (per-rank
     lists are kept under `detail`, which only the configs file and stderr carry), and the dominant kernel's roofline."""
     variant = "MASK_ONLY" if args.no_obs else "FULL"
     ratios = [pl["ratio"] for pl in per_rank_placement if pl and pl.get("ratio") is not None]
+    reps = sorted(repeats_us)
     return {
         "metric": "env-steps/sec at 2^20 parallel boards, 1/2/4/8 MI355X; bit-exact mask/winner",
-        # the K plies of every rank, bracketed by a barrier + synchronize on both sides; the time is each rank's own span from the
-        # synchronize behind the leading barrier to the synchronize behind its last ply, MAX over ranks (the trailing barrier
-        # itself -- at N > 1 a collective of tens of microseconds behind 72 us of kernel time per rank at 8 GPUs x 20 plies --
-        # is reported beside it: ms_per_step_with_trailing_barrier)
-        "value": total * K / local_elapsed,
+        # THE CONTRACT'S SPAN: the K plies of every rank (and the launch that moves the device-resident ply index on), bracketed
+        # by a barrier + synchronize on both sides, MAX over ranks.  (Round 4 computed `value` from each rank's span WITHOUT the
+        # trailing barrier -- its numbers are not comparable with rounds 1-3 or with this one; that span is still reported, as
+        # config.ms_per_step_own_span: at N = 8 the driver's 20 plies are ~72 us of kernel time per rank and an RCCL barrier
+        # is tens of microseconds.)
+        "value": total * K / elapsed,
         "unit": "env-steps/s",
         "n_gpus": world,
         "steps": K,
         "warmup": W,
-        "ms_per_step": local_elapsed / K * 1e3,
+        "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True,
         "scaling": "weak" if args.boards_per_gpu else "strong",
         "vs_baseline": None,
@@ -552,19 +556,28 @@ def contract_record(args, p, roof, total, boards, world, K, W, elapsed, local_el
                    "plies_per_launch": args.traj if args.mode == "collect" else 1,
                    "launches_timed": nlaunch * (2 if args.mode == "step" else 1),
                    "launch": "hipGraph replay" if graphed else "eager launches",
-                   # the dominant kernel's mean launch duration on the slowest / fastest rank (HIP events)
+                   # the dominant kernel's mean launch duration on the slowest / fastest rank (HIP events), timed pass
                    "kernel_us_max": max(per_rank_us), "kernel_us_min": min(per_rank_us),
-                   # the same span with the trailing barrier and the synchronize behind it included (MAX over ranks)
-                   "ms_per_step_with_trailing_barrier": elapsed / K * 1e3,
+                   # the same K plies played FOUR MORE times behind the contract's pass (rank 0; mean launch duration of each
+                   # pass by HIP events): whether the one timed pass was luck shows here
+                   "kernel_us_median_of_5": reps[len(reps) // 2] if reps else None,
+                   "kernel_us_min_of_5": reps[0] if reps else None, "kernel_us_max_of_5": reps[-1] if reps else None,
+                   # each rank's own span, from the synchronize behind the leading barrier to the synchronize behind its last
+                   # launch, without the trailing barrier (MAX over ranks): round 4's `ms_per_step`
+                   "ms_per_step_own_span": local_elapsed / K * 1e3,
                    # ranks that took part in the barriers / reductions over RCCL (0: none, or a gloo rehearsal)
                    "rccl_ranks": world if (distributed and args.dist_backend == "nccl") else 0,
                    "dist_backend": (args.dist_backend if distributed else None),
                    # where the observation / mask trajectory arrays lie (gobblet-rl_amd/placement.py): probe ratio
-                   # both / (obs alone + mask alone), ~1.0 = same 96 GiB class of HBM, ~0.8 = different classes
+                   # both / (obs alone + mask alone), ~1.0 = same 96 GiB class of HBM, ~0.8 = different classes;
+                   # "unplaced" = some rank's search found no pair in different classes (the headline then runs ~20 % slower)
                    "placement_ratio_min": min(ratios) if ratios else None,
-                   "placement_ratio_max": max(ratios) if ratios else None},
+                   "placement_ratio_max": max(ratios) if ratios else None,
+                   "placement": (None if not ratios else "unplaced" if max(ratios) >= 0.95 else
+                                 "placed" if max(ratios) <= 0.86 else "partly placed")},
         "roofline": roof,
         "detail": {"kernel_us_per_rank": per_rank_us, "trajectory_placement_per_rank": per_rank_placement,
+                   "kernel_us_of_5_passes": repeats_us,
                    "sharding": f"contiguous board ranges, {world} shard(s), no collective on the step path",
                    "launch": ("hipGraph replay of the K plies' launches (device-resident ply index; one untimed warm replay of "
                               "the same graph = K more untimed plies before the timed one)") if graphed else "eager"},
@@ -579,11 +592,15 @@ def compact_line(full, configs_path):
         line["config"]["configs_file"] = configs_path
         line["config"]["configs_recorded"] = len(full["configs"])
     line["roofline"] = {k: full["roofline"].get(k) for k in ROOFLINE_KEYS}
+    # where `traffic` comes from (a committed PMC pass keyed by the kernel sources' hash -- not measured in this run), shortened
+    src = line["roofline"].get("traffic_source")
+    if isinstance(src, str) and len(src) > 140:
+        line["roofline"]["traffic_source"] = src[:137] + "..."
     if "cpu_baseline" in full:
         line["cpu_baseline"] = {k: full["cpu_baseline"].get(k) for k in CPU_BASELINE_KEYS}
     text = json.dumps(line)
     if len(text.encode()) > COMPACT_LIMIT:  # never print a line the driver's tail would cut: drop the prose first
-        for k in ("timing", "sample"):
+        for k in ("timing", "sample", "traffic_source"):
             line["roofline"].pop(k, None)
             line.get("cpu_baseline", {}).pop(k, None)
         text = json.dumps(line)
@@ -614,6 +631,13 @@ def spawn_ranks(n):
     initialised) -- and pass its exit code on.  Rank 0's JSON line is the child's stdout, i.e. ours."""
     import socket
     import subprocess
+    if "--share-device" not in sys.argv:
+        import torch  # (counting devices does not initialise the GPU; the ranks are started as CHILD processes below)
+        ndev = torch.cuda.device_count()
+        if n > ndev:
+            print(f"bench.py: --gpus {n} but this node has {ndev} GPU(s): one rank per GPU is the contract "
+                  f"(--share-device + --dist-backend gloo rehearses more ranks on one card)", file=sys.stderr)
+            return 2
     with socket.socket() as sock:  # a free port for the rendezvous
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
@@ -637,6 +661,12 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): measuring {world}", file=sys.stderr)
         args.gpus = world
+    # FAIL FAST, before any rendezvous: more ranks than devices (e.g. `--gpus 8` under a launcher on a one-GPU box) would
+    # otherwise hang in init_process_group / die in set_device on some ranks while the others wait for them
+    ndev = torch.cuda.device_count()  # (does not initialise the GPU)
+    if not args.share_device and world > max(ndev, 0):
+        sys.exit(f"bench.py: {world} rank(s) but this node has {ndev} GPU(s): one rank per GPU is the contract "
+                 f"(--share-device + --dist-backend gloo rehearses more ranks on one card)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (there is no CPU fallback for the product path)")
     if args.share_device:
@@ -687,24 +717,29 @@ def main():
                 p.enqueue(off, plies, stream, ev[i])
 
     def bookkeeping():
-        if graph is None:         # eager: the ply index moves on behind the timed region (no launch of the K plies reads it)
+        if graph is None:         # eager: the launch that moves the device-resident ply index on (a graph's last node does it)
             p.advance(K, stream)
 
+    def pass_kernel_us():         # mean launch duration of the dominant kernel over the pass just played (HIP events)
+        if graph is None:
+            return sum(a.elapsed_time(b) for a, b in ev) / nlaunch * 1e3
+        return ev[0][0].elapsed_time(ev[0][1]) / nlaunch * 1e3
+
     play_k()                      # untimed rehearsal: K more warm plies
-    torch.cuda.synchronize(dev)
     bookkeeping()
+    torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     play_k()
+    bookkeeping()                 # (inside the timed region, as in the graph)
     torch.cuda.synchronize(dev)
-    local_elapsed = time.perf_counter() - t0  # this rank's K plies done and synchronised: what `value` is computed from (MAX over ranks)
+    local_elapsed = time.perf_counter() - t0  # this rank's own span (reported beside the contract's)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    bookkeeping()
+    elapsed = time.perf_counter() - t0        # the contract's span: barrier + synchronize on both sides
 
     # dominant-kernel time for the roofline: HIP events on the launch stream
     plies_timed = K
@@ -723,6 +758,15 @@ def main():
         kernel_s = sum(a.elapsed_time(b) for a, b in ev2) / 1e3
         timing = "HIP event pair around each of %d eager gbl_step launches after the timed replay" % launches
     mean_kernel_s = kernel_s / launches
+    # the headline's timed sample may be ONE launch: play the same K plies four more times (rank 0 reports the spread)
+    repeats_us = []
+    if args.mode != "step":
+        repeats_us.append(pass_kernel_us())
+        for _ in range(4):
+            play_k()
+            bookkeeping()
+            torch.cuda.synchronize(dev)
+            repeats_us.append(pass_kernel_us())
     per_rank_us = [mean_kernel_s * 1e6]
     mine_pl = p.traj["_placement"] if p.traj is not None else None
     per_rank_placement = [mine_pl]
@@ -751,7 +795,7 @@ def main():
         # (the counters were taken on launches of exactly T plies; the timed launches may end with a shorter one)
         attach_traffic(roof, p, min(args.traj, K) if args.mode == "collect" else 1)
         full = contract_record(args, p, roof, total, boards, world, K, W, elapsed, local_elapsed, nlaunch, graph is not None,
-                               per_rank_us, per_rank_placement, dist is not None)
+                               per_rank_us, per_rank_placement, dist is not None, repeats_us)
         if world == 1 and not args.no_configs:
             cfg = {}
             for name, (n, k, noobs, mode) in CONFIG_RECORDS.items():

@@ -267,21 +267,22 @@ __device__ __forceinline__ void tile_store(int8_t *__restrict__ g, const uint4 (
     if (REM && lane < REM) store16<P>(&gv[lane + 64 * FULL], v[FULL]);
 }
 
-// ---- sub-tiles: 16 boards per wavefront, FOUR lanes per board (small batches) -------------------------------------------
+// ---- sub-tiles: BPS boards per wavefront, LPB = 64 / BPS lanes per board (batches that do not fill the chip) -------------------
 // A batch of a few thousand boards is a few dozen 64-board tiles: most CUs idle and a launch lasts as long as ONE wavefront's
-// serial path.  The small-batch kernels cut a tile in four: lane = 4 * board + j, the four lanes of a board compute the game
-// (sample, move, winner, legal mask) REDUNDANTLY -- no cross-lane traffic at all -- and share the per-row work: lane j builds
-// bytes [16 j, 16 j + 16) of the board's mask row and drops every fourth byte of its observation row, and a sub-tile's images
-// are a quarter of a tile's (16 x 117 B = 117 vectors: two store instructions instead of eight).  Sub-tile s of an array of
-// ROWB-byte rows starts at byte 16 s ROWB, a multiple of 16 like a tile.
+// serial path.  The role kernels (k_collect_small) cut a tile in LPB parts: lane = LPB * board + j, the LPB lanes of a board
+// compute the game (sample, move, winner, legal mask) REDUNDANTLY -- no cross-lane traffic at all -- and share the per-row work:
+// lane j builds bytes [64 j / LPB, 64 (j + 1) / LPB) of the board's mask row and drops every LPB-th channel of its observation
+// row, and a sub-tile's images are 1 / LPB of a tile's (16 x 117 B = 117 vectors: two store instructions instead of eight).
+// LPB = 4: 16 boards per wavefront (up to 8 192 boards), 2: 32 boards (round 5), 1: a whole tile per wavefront.  Sub-tile s of an
+// array of ROWB-byte rows starts at byte BPS s ROWB, a multiple of 16 like a tile.
 constexpr int kSub = 16;
 
-template <int ROWB, typename Between = NoWork>
+template <int ROWB, int BPS = kSub, typename Between = NoWork>
 __device__ __forceinline__ void sub_in(const int8_t *__restrict__ g, uint32_t *lds, int lane, int rows, Between between = Between())
 {
-    constexpr int NV = kSub * ROWB / 16;  // = ROWB vectors of 16 bytes
-    static_assert(NV <= 128, "at most two vectors per lane");
-    if (rows == kSub) {
+    constexpr int NV = BPS * ROWB / 16;
+    static_assert(NV <= 128 && (BPS * ROWB) % 16 == 0, "at most two vectors per lane");
+    if (rows == BPS) {
         const uint4 *gv = reinterpret_cast<const uint4 *>(g);
         uint4 *lv = reinterpret_cast<uint4 *>(lds);
         uint4 v[2];
@@ -301,19 +302,19 @@ __device__ __forceinline__ void sub_in(const int8_t *__restrict__ g, uint32_t *l
     }
 }
 
-template <int ROWB, int NT>
+template <int ROWB, int NT, int BPS = kSub>
 __device__ __forceinline__ void sub_out(int8_t *__restrict__ g, const uint32_t *lds, int lane, int rows)
 {
-    constexpr int NV = kSub * ROWB / 16;
-    static_assert(NV <= 128, "at most two vectors per lane");
-    if (rows == kSub) {
+    constexpr int NV = BPS * ROWB / 16;
+    static_assert(NV <= 128 && (BPS * ROWB) % 16 == 0, "at most two vectors per lane");
+    if (rows == BPS) {
         const uint4 *lv = reinterpret_cast<const uint4 *>(lds);
         uint4 v[2];
         v[0] = lv[lane < NV ? lane : NV - 1];
         if (NV > 64) v[1] = lv[lane + 64 < NV ? lane + 64 : NV - 1];
 #ifndef GBL_HOST_EMU
         if constexpr (NT == kStoreStreamDrop) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g, 0, kSub * ROWB, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g, 0, BPS * ROWB, 0x00020000);
             if (lane < NV) {
                 vec4u t = {v[0].x, v[0].y, v[0].z, v[0].w};
                 __builtin_amdgcn_raw_buffer_store_b128(t, rs, lane * 16, 0, 2 | 16);
@@ -336,14 +337,73 @@ __device__ __forceinline__ void sub_out(int8_t *__restrict__ g, const uint32_t *
     }
 }
 
-// zero image of a sub-tile's 16 observation rows (117 vectors)
+// A sub-tile's output image (mask / observation rows of BPS boards: up to 468 vectors) on its way out: fetched from LDS into
+// registers at the end of one ply, stored behind the next ply's sample and move.  Named members, not an array: an array handed
+// around by reference was "promoted" to LDS by the compiler (round 4).
+template <int N>
+struct SubVecs {
+    uint4 head;
+    SubVecs<N - 1> tail;
+    template <int I>
+    __device__ __forceinline__ uint4 &at()
+    {
+        if constexpr (I == 0) return head;
+        else return tail.template at<I - 1>();
+    }
+};
+template <>
+struct SubVecs<0> {
+};
+
+template <int ROWB, int BPS>
+constexpr int sub_vectors() { return (BPS * ROWB / 16 + 63) / 64; }
+
+template <int ROWB, int BPS, int I = 0>
+__device__ __forceinline__ void sub_fetch(const uint32_t *lds, int lane, SubVecs<sub_vectors<ROWB, BPS>()> &v)
+{
+    constexpr int NV = BPS * ROWB / 16, N = sub_vectors<ROWB, BPS>();
+    if constexpr (I < N) {
+        const uint4 *lv = reinterpret_cast<const uint4 *>(lds);
+        const int i = lane + 64 * I;
+        v.template at<I>() = lv[64 * I + 63 < NV ? i : (i < NV ? i : NV - 1)];
+        sub_fetch<ROWB, BPS, I + 1>(lds, lane, v);
+    }
+}
+
+template <int ROWB, int NT, int BPS, int I = 0>
+__device__ __forceinline__ void sub_store(int8_t *__restrict__ g, SubVecs<sub_vectors<ROWB, BPS>()> &v, int lane)
+{
+    constexpr int NV = BPS * ROWB / 16, N = sub_vectors<ROWB, BPS>();
+    if constexpr (I < N) {
+        const int i = lane + 64 * I;
+        const uint4 &x = v.template at<I>();
+#ifndef GBL_HOST_EMU
+        if constexpr (NT == kStoreStreamDrop) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g, 0, BPS * ROWB, 0x00020000);
+            if (64 * I + 63 < NV || i < NV) {
+                vec4u t = {x.x, x.y, x.z, x.w};
+                __builtin_amdgcn_raw_buffer_store_b128(t, rs, i * 16, 0, 2 | 16);
+            }
+        } else
+#endif
+        {
+            constexpr int P = NT == kStoreStreamDrop ? kStoreStream : NT;
+            if (64 * I + 63 < NV || i < NV) store16<P>(reinterpret_cast<uint4 *>(g) + i, x);
+        }
+        sub_store<ROWB, NT, BPS, I + 1>(g, v, lane);
+    }
+}
+
+// zero image of a sub-tile's BPS observation rows
+template <int BPS = kSub>
 __device__ __forceinline__ void sub_obs_zero(uint32_t *img, int lane)
 {
-    constexpr int NV = kSub * kObs / 16;
+    constexpr int NV = BPS * kObs / 16;
     uint4 *lv = reinterpret_cast<uint4 *>(img);
     const uint4 z = {0u, 0u, 0u, 0u};
-    lv[lane] = z;
-    if (lane + 64 < NV) lv[lane + 64] = z;
+#pragma unroll
+    for (int i = 0; i < (NV + 63) / 64; ++i)
+        if (64 * i + 63 < NV || lane + 64 * i < NV) lv[lane + 64 * i] = z;
 }
 
 // Orders this wave's LDS accesses across lanes.  A workgroup is ONE wavefront, whose LDS
@@ -628,45 +688,65 @@ __device__ __forceinline__ void obs_scatter_row(uint8_t *row, const Planes &p, i
     }
 }
 
-// Lane j (of the four of a board) drops channels j, j + 4, j + 8 and channel-12 bytes of squares j, j + 4 (, 8) of the board's
-// observation row (zero on entry): obs_scatter_row dealt over a quad.
-__device__ __forceinline__ void obs_scatter_quad(uint8_t *row, const Planes &p, int observer, int j)
+// Lane j (of the LPB of a board) drops channels j, j + LPB, ... and the channel-12 bytes of squares j, j + LPB, ... of the board's
+// observation row (zero on entry): obs_scatter_row dealt over the board's lanes.
+template <int LPB = 4>
+__device__ __forceinline__ void obs_scatter_part(uint8_t *row, const Planes &p, int observer, int j)
 {
-    const uint32_t pos = p.nz & ~p.neg, ngv = p.nz & p.neg;
-    const uint32_t own = observer ? ngv : pos, opp = observer ? pos : ngv;
-    // channel ch = j + 4 i: side = ch / 6, level = (ch % 6) / 2, parity = ch & 1 = j & 1
-    const uint32_t oddsel = (j & 1) ? ~p.odd : p.odd;
+    static_assert(LPB == 1 || LPB == 2 || LPB == 4, "lanes per board");
+    if constexpr (LPB == 1) {
+        (void)j;
+        obs_scatter_row(row, p, observer);
+    } else {
+        const uint32_t pos = p.nz & ~p.neg, ngv = p.nz & p.neg;
+        const uint32_t own = observer ? ngv : pos, opp = observer ? pos : ngv;
+        // channel ch = j + LPB i: side = ch / 6, level = (ch % 6) / 2, parity = ch & 1 = j & 1 (LPB is even)
+        const uint32_t oddsel = (j & 1) ? ~p.odd : p.odd;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int ch = j + 4 * i;                    // 0..11
-        const uint32_t side = ch >= 6 ? opp : own;
-        const int k = (ch >= 6 ? ch - 6 : ch) >> 1;
-        const uint32_t grp = ((side & oddsel) >> (9 * k)) & 0x1FFu;
-        if (grp) row[13 * __builtin_ctz(grp) + ch] = 1;
-    }
-    if (observer) {
+        for (int i = 0; i < 12 / LPB; ++i) {
+            const int ch = j + LPB * i;                  // 0..11
+            const uint32_t side = ch >= 6 ? opp : own;
+            const int k = (ch >= 6 ? ch - 6 : ch) >> 1;
+            const uint32_t grp = ((side & oddsel) >> (9 * k)) & 0x1FFu;
+            if (grp) row[13 * __builtin_ctz(grp) + ch] = 1;
+        }
+        if (observer) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int q = j + 4 * i;
-            if (q < 9) row[13 * q + 12] = 1;
+            for (int i = 0; i < (9 + LPB - 1) / LPB; ++i) {
+                const int q = j + LPB * i;
+                if (q < 9) row[13 * q + 12] = 1;
+            }
         }
     }
 }
 
-// Lane j writes bytes [16 j, 16 j + 16) (j = 3: the last 6) of the board's 54-byte mask row at `row` (2-byte aligned: unaligned
-// LDS stores, like ImageRow::reset).
-__device__ __forceinline__ void mask_row_quad(uint8_t *row, uint64_t m, int j)
+__device__ __forceinline__ void obs_scatter_quad(uint8_t *row, const Planes &p, int observer, int j)
 {
-    const uint32_t bits = (uint32_t)(m >> (16 * j)) & 0xFFFFu;
-    uint32_t d[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) d[k] = __umul24((bits >> (4 * k)) & 0xFu, 0x00204081u) & 0x01010101u;
-    uint8_t *dst = row + 16 * j;
-    if (j < 3)
-        __builtin_memcpy(dst, d, 16);
-    else
-        __builtin_memcpy(dst, d, 6);
+    obs_scatter_part<4>(row, p, observer, j);
 }
+
+// Lane j writes bytes [S j, S j + S), S = 64 / LPB, of the board's 54-byte mask row at `row` (the last lane: what is left of the
+// 54; rows are 2-byte aligned: unaligned LDS stores, like ImageRow::reset).
+template <int LPB = 4>
+__device__ __forceinline__ void mask_row_part(uint8_t *row, uint64_t m, int j)
+{
+    static_assert(LPB == 1 || LPB == 2 || LPB == 4, "lanes per board");
+    constexpr int S = 64 / LPB, NW = S / 4, LAST = kActions - S * (LPB - 1);  // bytes per lane, dwords per lane, the last lane's bytes
+    const uint64_t part = LPB == 1 ? m : (m >> (S * j));
+    uint32_t d[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const uint32_t nib = (uint32_t)(part >> (4 * k)) & 0xFu;
+        d[k] = __umul24(nib, 0x00204081u) & 0x01010101u;  // bit i -> byte i
+    }
+    uint8_t *dst = row + S * j;
+    if (LPB > 1 && j < LPB - 1)
+        __builtin_memcpy(dst, d, S);
+    else
+        __builtin_memcpy(dst, d, LAST);
+}
+
+__device__ __forceinline__ void mask_row_quad(uint8_t *row, uint64_t m, int j) { mask_row_part<4>(row, m, j); }
 
 // Board.get_flatboard, board.py:159-177: signed piece number of the top piece per
 // square, as a 9-byte row in 3 dwords.

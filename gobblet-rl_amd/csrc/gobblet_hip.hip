@@ -85,13 +85,22 @@ inline int nt_policy(int64_t n)
 // stores.  A pure function of the call's shape (and of the -D macros of an A/B build).
 constexpr int64_t kCollect2MaxTiles = 2048;  // 8 workgroups per CU (110 VGPRs: 4 wavefronts per SIMD); 4096 tiles would need two batches: 7.45 -> 7.81 us per ply
 
-// Batches up to this many boards run k_collect_small (sub-tiles of 16 boards, see there).  Measured against k_collect2, us per
-// ply, FULL outputs, 32 plies per launch (scripts/ab_small.sh): 1 024 boards 0.85 vs 1.19, 4 096: 0.87 vs 1.20, 8 192: 1.09 vs 1.22,
-// 16 384: 1.43 vs 1.23 (three wavefronts per 16 boards: from there on the redundant game costs more than the idle SIMDs give)
+// Batches up to this many boards run k_collect_small with four lanes per board (sub-tiles of 16 boards, see there).  Measured
+// against k_collect2, us per ply, FULL outputs, 32 plies per launch (scripts/ab_small.sh): 1 024 boards 0.85 vs 1.19, 4 096: 0.87
+// vs 1.20, 8 192: 1.09 vs 1.22, 16 384: 1.43 vs 1.23 (three wavefronts per 16 boards: from there on the redundant game costs more
+// than the idle SIMDs give).  Round 5: the same kernel with two lanes per board (32 boards per wavefront) up to
+// GBL_COLLECT_HALF_MAX boards and with one (a tile per role wavefront) up to GBL_COLLECT_ROLES_MAX, in front of k_collect2.
 #ifndef GBL_COLLECT_SMALL_MAX
 #define GBL_COLLECT_SMALL_MAX 8192
 #endif
-constexpr int64_t kCollectSmallMaxBoards = GBL_COLLECT_SMALL_MAX;
+#ifndef GBL_COLLECT_HALF_MAX
+#define GBL_COLLECT_HALF_MAX 16384
+#endif
+#ifndef GBL_COLLECT_ROLES_MAX
+#define GBL_COLLECT_ROLES_MAX 65536
+#endif
+constexpr int64_t kCollectSmallMaxBoards = GBL_COLLECT_SMALL_MAX, kCollectHalfMaxBoards = GBL_COLLECT_HALF_MAX,
+                  kCollectRolesMaxBoards = GBL_COLLECT_ROLES_MAX;
 
 inline int collect_variant(int64_t n, uint32_t plies, bool with_mask, bool with_obs)
 {
@@ -106,12 +115,13 @@ inline int collect_variant(int64_t n, uint32_t plies, bool with_mask, bool with_
 #else
     const bool pair = (n + kTile - 1) / kTile <= kCollect2MaxTiles && nt && (with_mask || with_obs);
 #endif
-#ifdef GBL_FORCE_COLLECT_SMALL  // 0 / 1: A/B builds
-    const bool small = (GBL_FORCE_COLLECT_SMALL) != 0;
+#ifdef GBL_FORCE_COLLECT_SMALL  // A/B builds: 0 = never, 4 / 2 / 1 = always, with that many lanes per board
+    const int lpb = (GBL_FORCE_COLLECT_SMALL);
 #else
-    const bool small = n <= kCollectSmallMaxBoards && nt;
+    const int lpb = !nt ? 0 : n <= kCollectSmallMaxBoards ? 4 : n <= kCollectHalfMaxBoards ? 2 : n <= kCollectRolesMaxBoards ? 1 : 0;
 #endif
-    return small ? GBL_COLLECT_SMALL : pair ? GBL_COLLECT_PAIR : nt ? GBL_COLLECT_STREAM : GBL_COLLECT_CACHED;
+    return lpb == 4 ? GBL_COLLECT_SMALL : lpb == 2 ? GBL_COLLECT_HALF : lpb == 1 ? GBL_COLLECT_ROLES
+           : pair ? GBL_COLLECT_PAIR : nt ? GBL_COLLECT_STREAM : GBL_COLLECT_CACHED;
 }
 
 // LDS words for a tile image of ROWB-byte rows (+ slack for row_load's look-ahead dword)
@@ -808,21 +818,28 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
     }
 }
 
-// gbl_collect (and the one-ply entry points) for SMALL batches: 16 boards per wavefront, four lanes per board, and the game
+// gbl_collect for batches that do NOT fill the chip: a SUB-TILE of 64 / LPB boards per wavefront, LPB lanes per board, and the game
 // played REDUNDANTLY wherever that saves a hand-over.  At 4 096 boards k_collect2's 64 workgroups leave three CUs in four idle
 // and a ply lasts as long as its playing wavefront's serial path; a lone wavefront issues one instruction per 5-7 cycles
 // whatever it is, so what counts is the number of instructions ONE wavefront executes per ply.  The game itself -- sample,
-// move, winner, auto-reset, next legal mask: the CHAIN, ~200 instructions, every one depending on the ply before -- cannot be
-// dealt out (0.72 us per ply with nothing stored, scripts/ab_floor.sh); everything else can.  A workgroup is a sub-tile of 16
-// boards and up to three wavefronts that share NOTHING: each loads the sub-tile, each plays every ply (the four lanes of a
-// board alike), and each materialises one share of the outputs, a quarter of a row per lane --
+// move, winner, auto-reset, next legal mask: the CHAIN, ~250 instructions, every one depending on the ply before -- cannot be
+// dealt out (0.72 us per ply with nothing stored, scripts/ab_floor.sh); everything else can.  A workgroup is a sub-tile and up
+// to three wavefronts that share NOTHING: each loads the sub-tile, each plays every ply (the LPB lanes of a board alike), and each
+// materialises one share of the outputs, 1 / LPB of a row per lane --
 //   role 0: the five scalars of a ply, the tallies, and at the end the state (the only role that patches a state image);
-//   role 1: the mask rows (lane j: bytes [16 j, 16 j + 16) of its board's row);
-//   role 2: the observation rows (lane j: channels j, j + 4, j + 8).
-// No barrier, no LDS hand-over, no cross-lane instruction; the redundant arithmetic runs on SIMDs that would idle.  A role's
-// image of ply t is read back into registers at the end of its iteration and stored in the NEXT one, behind the sample and the
-// move: the LDS round trip is off the chain.  Bit for bit the trajectories of k_collect (same sampler keys, same arithmetic).
-// cell of sub-tile s at ply t: t * ply_stride + (s / 4) * tile_stride + (s % 4) * 16  (both layouts of gbl_collect).
+//   role 1: the mask rows (lane j: bytes [64 j / LPB, 64 (j + 1) / LPB) of its board's row);
+//   role 2: the observation rows (lane j: channels j, j + LPB, ...).
+// No LDS hand-over, no cross-lane instruction; the redundant arithmetic runs on SIMDs that would idle.  A role's image of ply t
+// is read back into registers at the end of its iteration and stored in the NEXT one, behind the sample and the move: the LDS
+// round trip is off the chain.  Bit for bit the trajectories of k_collect (same sampler keys, same arithmetic).
+//   LPB = 4 (16 boards per wavefront): up to 8 192 boards (round 4);
+//   LPB = 2 (32 boards) and LPB = 1 (a whole tile per role wavefront): the batches between that and the HBM regime (round 5) --
+//       where k_collect2's ONE playing wavefront per tile carried the chain AND both row builders (1.23 - 1.87 us per ply at
+//       16 384 - 65 536 boards against 0.37 - 1.46 of HBM time).
+// cell of sub-tile s at ply t: t * ply_stride + (s / LPB) * tile_stride + (s % LPB) * (64 / LPB)  (both layouts of gbl_collect).
+// ONE barrier per launch (not per ply): the roles read the sub-tile's state, movers and first actions on their own and role 0
+// overwrites them at the end -- the rendezvous behind the loads keeps a late role from reading what an early role 0 wrote back
+// (with one ply per launch role 0 reaches its write-back after ~300 instructions).
 struct NoRow {  // the state image of a wavefront that does not write the state back is never patched
     __device__ __forceinline__ void apply(const MoveCells &) const {}
     __device__ __forceinline__ void reset() const {}
@@ -854,54 +871,30 @@ __device__ __forceinline__ void sub_out_ragged(int8_t *__restrict__ g, const uin
     for (int i = lane; i < bytes; i += 64) g[i] = lb[i];
 }
 
-// a full sub-tile's image -> registers (fetch), registers -> HBM (store): the two halves of sub_out
-// (two named vectors, not an array: an array handed around by reference was "promoted" to 2 KB of LDS per role)
-template <int ROWB>
-__device__ __forceinline__ void sub_fetch(const uint32_t *lds, int lane, uint4 &v0, uint4 &v1)
-{
-    constexpr int NV = kSub * ROWB / 16;
-    const uint4 *lv = reinterpret_cast<const uint4 *>(lds);
-    v0 = lv[lane < NV ? lane : NV - 1];
-    if (NV > 64) v1 = lv[lane + 64 < NV ? lane + 64 : NV - 1];
-}
-
-template <int ROWB, int NT>
-__device__ __forceinline__ void sub_store(int8_t *__restrict__ g, const uint4 &v0, const uint4 &v1, int lane)
-{
-    constexpr int NV = kSub * ROWB / 16;
-    if constexpr (NT == kStoreStreamDrop) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g, 0, kSub * ROWB, 0x00020000);
-        if (lane < NV) {
-            vec4u t = {v0.x, v0.y, v0.z, v0.w};
-            __builtin_amdgcn_raw_buffer_store_b128(t, rs, lane * 16, 0, 2 | 16);
-        }
-        if (NV > 64 && lane + 64 < NV) {
-            vec4u t = {v1.x, v1.y, v1.z, v1.w};
-            __builtin_amdgcn_raw_buffer_store_b128(t, rs, (lane + 64) * 16, 0, 2 | 16);
-        }
-    } else {
-        uint4 *gv = reinterpret_cast<uint4 *>(g);
-        if (lane < NV) store16<NT>(&gv[lane], v0);
-        if (NV > 64 && lane + 64 < NV) store16<NT>(&gv[lane + 64], v1);
-    }
-}
-
-template <int ROLE>
+template <int ROLE, int LPB, bool SYNC>
 __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, uint32_t *out_img, int64_t sub)
 {
-    const int lane = (int)(threadIdx.x & 63u), bq = lane >> 2, j = lane & 3;
-    const int64_t left = A.n - sub * kSub;
-    const int rows = left < kSub ? (int)left : kSub;
-    const bool valid = bq < rows, full = rows == kSub;
-    const int64_t b = sub * kSub + bq, bs = valid ? b : A.n - 1;
+    constexpr int BPS = kTile / LPB, SH = LPB == 4 ? 2 : LPB == 2 ? 1 : 0;
+    const int lane = (int)(threadIdx.x & 63u), bq = lane >> SH, j = lane & (LPB - 1);
+    const int64_t left = A.n - sub * BPS;
+    const int rows = left < BPS ? (int)left : BPS;
+    const bool valid = bq < rows, full = rows == BPS;
+    const int64_t b = sub * BPS + bq, bs = valid ? b : A.n - 1;
     int mover = A.to_move[bs];
-    const int given = A.first_actions ? A.first_actions[bs] : 0;  // (gbl_collect_from / gbl_step: the first ply plays the caller's actions)
+    int given = A.first_actions ? A.first_actions[bs] : 0;  // (gbl_collect_from: the first ply plays the caller's actions)
     Draw4 block{{0u, 0u, 0u, 0u}};
-    sub_in<kCells>(A.state + sub * (kSub * kCells), img, lane, rows, [&] { block = draw_block(A.seed, A.env_base + (uint64_t)b, A.ply0); });
+    sub_in<kCells, BPS>(A.state + sub * (BPS * kCells), img, lane, rows, [&] { block = draw_block(A.seed, A.env_base + (uint64_t)b, A.ply0); });
     wave_lds_fence();
     uint32_t r[7];
     row_load<kCells>(img, bq, r);
     r[6] &= 0x00FFFFFFu;
+    if (SYNC) {
+#ifndef GBL_HOST_EMU
+        // every role's loads of the sub-tile have landed before role 0 may write anything back (waits vmcnt(0) + lgkmcnt(0))
+        asm volatile("" : "+v"(mover), "+v"(given));
+        __syncthreads();
+#endif
+    }
     mover = valid && mover != 0;
     Planes p = make_planes(r);
     p.nz = valid ? p.nz : 0u;
@@ -913,9 +906,10 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
     uint64_t legal = legal54(p, mover);
     constexpr int kRowB = ROLE == kRoleObs ? kObs : kActions;
     constexpr int kRowPolicy = kStoreStreamDrop;  // trajectory slots are written once: streamed
-    uint4 v0{0u, 0u, 0u, 0u}, v1{0u, 0u, 0u, 0u};  // the image of the previous ply, on its way out
+    SubVecs<sub_vectors<kRowB, BPS>()> v{};  // the image of the previous ply, on its way out
     int8_t *vdst = nullptr;
     const uint32_t plies = A.plies;
+    const int64_t cell0 = (sub >> SH) * A.tile_stride + (sub & (LPB - 1)) * BPS;
     for (uint32_t t = 0; t < plies; ++t) {
         const uint32_t ply = A.ply0 + t;
         int action = pick54(legal, draw_word(block, ply));
@@ -931,8 +925,10 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
             mover = 0;
             if (ROLE == kRoleScalars) row.reset();
         }
-        const int64_t cell = (int64_t)t * A.ply_stride + (sub >> 2) * A.tile_stride + (sub & 3) * kSub;
-        if (ROLE != kRoleScalars && t && full) sub_store<kRowB, kRowPolicy>(vdst, v0, v1, lane);  // ply t - 1's rows
+        const int64_t cell = (int64_t)t * A.ply_stride + cell0;
+        if constexpr (ROLE != kRoleScalars) {
+            if (t && full) sub_store<kRowB, kRowPolicy, BPS>(vdst, v, lane);  // ply t - 1's rows
+        }
         if (ROLE == kRoleScalars) {
             tcount = next_turn(tcount, y, 1);
             treset = treset || y.terminal;
@@ -941,44 +937,63 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
                 w1 += __popcll(__ballot(valid && j == 0 && y.winner == 1));
                 w2 += __popcll(__ballot(valid && j == 0 && y.winner == -1));
             }
-            if (valid) {  // the five scalars of a board, dealt over its four lanes
+            if (valid) {  // the five scalars of a board, dealt over its lanes
                 const int64_t at = cell + bq;
-                if (j == 0) {
+                const uint16_t rw = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
+                if constexpr (LPB == 4) {
+                    if (j == 0) {
+                        if (A.actions_t) A.actions_t[at] = action;
+                    } else if (j == 1) {
+                        if (A.reward_t) reinterpret_cast<uint16_t *>(A.reward_t)[at] = rw;
+                    }
+                    int8_t *const sp = j == 0 ? A.to_move_t : j == 2 ? A.winner_t : j == 3 ? A.done_t : nullptr;
+                    const int sv = j == 0 ? mover : j == 2 ? y.winner : dn;
+                    if (sp) sp[at] = (int8_t)sv;  // (one byte store serves three arrays)
+                } else if constexpr (LPB == 2) {
+                    if (j == 0) {
+                        if (A.actions_t) A.actions_t[at] = action;
+                        if (A.winner_t) A.winner_t[at] = (int8_t)y.winner;
+                    } else {
+                        if (A.reward_t) reinterpret_cast<uint16_t *>(A.reward_t)[at] = rw;
+                    }
+                    int8_t *const sp = j == 0 ? A.to_move_t : A.done_t;
+                    const int sv = j == 0 ? mover : dn;
+                    if (sp) sp[at] = (int8_t)sv;
+                } else {
                     if (A.actions_t) A.actions_t[at] = action;
-                } else if (j == 1) {
-                    if (A.reward_t) reinterpret_cast<uint16_t *>(A.reward_t)[at] = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
+                    if (A.winner_t) A.winner_t[at] = (int8_t)y.winner;
+                    if (A.reward_t) reinterpret_cast<uint16_t *>(A.reward_t)[at] = rw;
+                    if (A.done_t) A.done_t[at] = (int8_t)dn;
+                    if (A.to_move_t) A.to_move_t[at] = (int8_t)mover;
                 }
-                int8_t *const sp = j == 0 ? A.to_move_t : j == 2 ? A.winner_t : j == 3 ? A.done_t : nullptr;
-                const int sv = j == 0 ? mover : j == 2 ? y.winner : dn;
-                if (sp) sp[at] = (int8_t)sv;
             }
         }
-        if (ROLE == kRoleObs) {
-            sub_obs_zero(out_img, lane);
+        if constexpr (ROLE == kRoleObs) {
+            sub_obs_zero<BPS>(out_img, lane);
             wave_lds_fence();
-            obs_scatter_quad(reinterpret_cast<uint8_t *>(out_img) + bq * kObs, p, mover, j);
+            obs_scatter_part<LPB>(reinterpret_cast<uint8_t *>(out_img) + bq * kObs, p, mover, j);
             wave_lds_fence();
             vdst = A.obs_t + cell * kObs;
-            if (full) sub_fetch<kObs>(out_img, lane, v0, v1);
+            if (full) sub_fetch<kObs, BPS>(out_img, lane, v);
             else sub_out_ragged(vdst, out_img, lane, rows * kObs);
             wave_lds_fence();
         }
         legal = legal54(p, mover);  // the next mover's: stored now, sampled from next ply
-        if (ROLE == kRoleMask) {
-            mask_row_quad(reinterpret_cast<uint8_t *>(out_img) + bq * kActions, legal, j);
+        if constexpr (ROLE == kRoleMask) {
+            mask_row_part<LPB>(reinterpret_cast<uint8_t *>(out_img) + bq * kActions, legal, j);
             wave_lds_fence();
             vdst = A.mask_t + cell * kActions;
-            if (full) sub_fetch<kActions>(out_img, lane, v0, v1);
+            if (full) sub_fetch<kActions, BPS>(out_img, lane, v);
             else sub_out_ragged(vdst, out_img, lane, rows * kActions);
             wave_lds_fence();
         }
     }
-    if (ROLE != kRoleScalars) {
-        if (full) sub_store<kRowB, kRowPolicy>(vdst, v0, v1, lane);  // the last ply's rows
+    if constexpr (ROLE != kRoleScalars) {
+        if (full) sub_store<kRowB, kRowPolicy, BPS>(vdst, v, lane);  // the last ply's rows
         return;
-    }
+    } else {
     wave_lds_fence();  // every board's byte patches are in the state image
-    sub_out<kCells, kStorePlain>(A.state + sub * (kSub * kCells), img, lane, rows);
+    sub_out<kCells, kStorePlain, BPS>(A.state + sub * (BPS * kCells), img, lane, rows);
     if (valid && j == 0) {
         A.to_move[b] = (int8_t)mover;
         A.done[b] = (int8_t)dn;
@@ -986,18 +1001,19 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
     }
     if (A.counters && lane == 0) {
         unsigned long long *c = reinterpret_cast<unsigned long long *>(A.counters) +
-                                (size_t)((sub >> 2) % GBL_COUNTER_STRIPES) * GBL_COUNTER_STRIDE;
+                                (size_t)((sub >> SH) % GBL_COUNTER_STRIPES) * GBL_COUNTER_STRIDE;
         atomicAdd(c + 0, (unsigned long long)rows * plies);
         if (games) atomicAdd(c + 1, (unsigned long long)games);
         if (w1) atomicAdd(c + 2, (unsigned long long)w1);
         if (w2) atomicAdd(c + 3, (unsigned long long)w2);
+    }
     }
 }
 
 // (The one-ply entry points -- gbl_rollout with plies = 1, gbl_step -- were routed here too and gained nothing: 3.34-3.47 us per
 // launch against k_rollout's 3.29-3.36 at 1 024 - 4 096 boards, scripts/ab_ply.sh: a one-ply launch is its tile load, the chain
 // and the launch boundary, none of which a smaller tile shortens.  They stay on k_rollout / k_step.)
-template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY>
+template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY, int LPB>
 __global__ __launch_bounds__((64 * small_roles<WITH_MASK, WITH_OBS>())) void k_collect_small(
     int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n, int64_t nsub, uint64_t seed, uint64_t env_base,
     const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies, int8_t *__restrict__ done, int64_t ply_stride,
@@ -1005,8 +1021,8 @@ __global__ __launch_bounds__((64 * small_roles<WITH_MASK, WITH_OBS>())) void k_c
     int8_t *__restrict__ done_t, int8_t *__restrict__ to_move_t, int8_t *__restrict__ mask_t, int8_t *__restrict__ obs_t,
     int illegal_mode, int64_t *__restrict__ counters, int32_t *__restrict__ turn, const int32_t *__restrict__ first_actions)
 {
-    constexpr int ROLES = small_roles<WITH_MASK, WITH_OBS>();
-    constexpr int kStateWords = kSub * kCells / 4 + 4, kObsWords = kSub * kObs / 4 + 4, kMaskWords = kSub * kActions / 4 + 4;
+    constexpr int ROLES = small_roles<WITH_MASK, WITH_OBS>(), BPS = kTile / LPB;
+    constexpr int kStateWords = BPS * kCells / 4 + 4, kObsWords = BPS * kObs / 4 + 4, kMaskWords = BPS * kActions / 4 + 4;
     __shared__ uint32_t s_state[ROLES][kStateWords];
     __shared__ uint32_t s_obs[WITH_OBS ? kObsWords : 4];
     __shared__ uint32_t s_mask[WITH_MASK ? kMaskWords : 4];
@@ -1016,17 +1032,18 @@ __global__ __launch_bounds__((64 * small_roles<WITH_MASK, WITH_OBS>())) void k_c
     const int wave = ROLES > 1 ? wave_index() : 0;
     const SmallArgs A{state, to_move, done, n, seed, env_base, ply0, plies, ply_stride, tile_stride, actions_t, winner_t, reward_t,
                       done_t, to_move_t, mask_t, obs_t, illegal_mode, counters, turn, first_actions};
+    constexpr bool SYNC = ROLES > 1;
     if (wave == 0) {
-        small_role<kRoleScalars>(A, s_state[0], nullptr, sub);
+        small_role<kRoleScalars, LPB, SYNC>(A, s_state[0], nullptr, sub);
         return;
     }
     if constexpr (WITH_MASK) {
         if (wave == 1) {
-            small_role<kRoleMask>(A, s_state[1], s_mask, sub);
+            small_role<kRoleMask, LPB, SYNC>(A, s_state[1], s_mask, sub);
             return;
         }
     }
-    if constexpr (WITH_OBS) small_role<kRoleObs>(A, s_state[ROLES - 1], s_obs, sub);
+    if constexpr (WITH_OBS) small_role<kRoleObs, LPB, SYNC>(A, s_state[ROLES - 1], s_obs, sub);
 }
 
 // gbl_placement_probe: the write pattern of k_collect without the game -- tile i of `plies` slots stores 64 rows of
@@ -1639,8 +1656,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
             // generator call per four plies, like the environment's)
             const uint32_t wsel = draw_word_index(ply);
             const int greedy_action = g.fallback ? pick54(g.cands, draws[4 + wsel][L.lane]) : g.chosen;
-            // (the masked-random pick only where some board of the tile needs one: none in greedy-vs-greedy play past the openings)
-            int random_action = -1;
+            // (the masked-random pick only where some board of the tile needs one: none in greedy-vs-greedy play past the openings;
+            //  the lanes past the end of a ragged tile then play their first legal move -- never an illegal one, which in TERMINATE
+            //  mode would end and restart their phantom game every ply: nothing of theirs is stored or tallied, but their state
+            //  stays that of a board that is being played)
+            int random_action = (int)__builtin_ctzll(legal | (1ull << 63));
             if (wave_any(L.valid && !gre)) random_action = pick54(legal, draws[wsel][L.lane]);
             action = gre ? greedy_action : random_action;
             if (gre) {  // :219: the acting agent's history takes the returned action
@@ -1728,25 +1748,30 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
     }
 }
 
-// k_collect_small for a checked call (see gbl_collect_from)
-void launch_small(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *first_actions, int32_t *actions_t, int8_t *winner_t,
+// k_collect_small for a checked call (see gbl_collect_from); lpb = lanes per board (4 / 2 / 1: collect_variant)
+void launch_small(int lpb, int8_t *state, int8_t *to_move, int8_t *done, const int32_t *first_actions, int32_t *actions_t, int8_t *winner_t,
                   int8_t *reward_t, int8_t *done_t, int8_t *to_move_t, int8_t *mask_t, int8_t *obs_t, int64_t n, int64_t ply_stride,
                   int64_t tile_stride, uint64_t seed, uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev, uint32_t plies,
                   int illegal_mode, int64_t *counters, int32_t *turn, hipStream_t s)
 {
-    const int64_t nsub = (n + kSub - 1) / kSub;
-#define GBL_SMALL_K(M, O, D)                                                                                                  \
-    hipLaunchKernelGGL((k_collect_small<M, O, D>), dim3((uint32_t)nsub), dim3(64 * small_roles<M, O>()), 0, s, state, \
+    const int64_t bps = kTile / lpb, nsub = (n + bps - 1) / bps;
+#define GBL_SMALL_K(M, O, D, L)                                                                                               \
+    hipLaunchKernelGGL((k_collect_small<M, O, D, L>), dim3((uint32_t)nsub), dim3(64 * small_roles<M, O>()), 0, s, state, \
                        to_move, n, nsub, seed, env_base, ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_t, winner_t,   \
                        reward_t, done_t, to_move_t, mask_t, obs_t, illegal_mode, counters, turn, first_actions)
+#define GBL_SMALL_L(M, O, D)                                    \
+    if (lpb == 4) { GBL_SMALL_K(M, O, D, 4); }                  \
+    else if (lpb == 2) { GBL_SMALL_K(M, O, D, 2); }             \
+    else { GBL_SMALL_K(M, O, D, 1); }
 #define GBL_SMALL_D(M, O)                                       \
-    if (ply_dev) { GBL_SMALL_K(M, O, true); }                   \
-    else { GBL_SMALL_K(M, O, false); }
+    if (ply_dev) { GBL_SMALL_L(M, O, true); }                   \
+    else { GBL_SMALL_L(M, O, false); }
     if (mask_t && obs_t) { GBL_SMALL_D(true, true); }
     else if (mask_t) { GBL_SMALL_D(true, false); }
     else if (obs_t) { GBL_SMALL_D(false, true); }
     else { GBL_SMALL_D(false, false); }
 #undef GBL_SMALL_D
+#undef GBL_SMALL_L
 #undef GBL_SMALL_K
 }
 
@@ -2119,8 +2144,8 @@ int gbl_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int32_t
     const int variant = collect_variant(n, plies, mask_traj != nullptr, obs_traj != nullptr);
     const bool pair = variant == GBL_COLLECT_PAIR;
     [[maybe_unused]] const bool nt = variant != GBL_COLLECT_CACHED;
-    if (variant == GBL_COLLECT_SMALL) {
-        launch_small(state, to_move, done, first_actions, actions_traj, winner_traj, reward_traj, done_traj, to_move_traj,
+    if (variant == GBL_COLLECT_SMALL || variant == GBL_COLLECT_HALF || variant == GBL_COLLECT_ROLES) {
+        launch_small(variant == GBL_COLLECT_SMALL ? 4 : variant == GBL_COLLECT_HALF ? 2 : 1, state, to_move, done, first_actions, actions_traj, winner_traj, reward_traj, done_traj, to_move_traj,
                            mask_traj, obs_traj, n, ply_stride, tile_stride, seed, env_base, ply0, ply_dev, plies, illegal_mode,
                            counters, turn, s);
         GBL_LAUNCHED("gbl_collect");

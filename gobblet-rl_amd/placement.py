@@ -25,7 +25,11 @@ What a caller that shares the device can rely on (round 3):
     the caller's own placement (with 200 GiB of the device taken the capped search found nothing in three runs out of
     three while the allocator's pair was clean, profiles/r03/placement_ab.txt);
   * the search never holds more than ``MAX_HOLD_BYTES`` (64 GiB) nor more than a quarter of the memory that was free
-    when it started (the two arrays' own blocks always count), and leaves ``RESERVE_BYTES`` untouched;
+    when it started (the two arrays' own blocks always count), and leaves ``RESERVE_BYTES`` untouched -- EXCEPT with
+    ``far=True`` (opt-in: a caller that owns the device, e.g. bench.py), whose candidates lie behind a transient gap of
+    64 / 96 / 128 GiB that is held for the duration of two ``hipMalloc`` calls (never while probing) and recorded as
+    ``transient_peak_gib``; the default (``far=None``) tries them only on a device with ``FAR_MIN_FREE_BYTES`` (160 GiB)
+    free, ``far=False`` never (``collect()``'s implicit staging buffers);
   * an allocation the device refuses ENDS the search (the best pair seen so far is used); if not even the two arrays'
     own blocks fit the plain pair is kept (without one, ``PlacementUnavailable`` is raised) -- the reason is recorded;
   * ``torch.cuda.empty_cache()`` is never called: rejected blocks are ``hipFree``d, torch's cache is left alone -- which also
@@ -143,7 +147,7 @@ _OOM = (torch.OutOfMemoryError, nat.GobbletHipError, MemoryError)
 
 
 def spread_pair(bytes_a: int, bytes_b: int, device, slot_boards: int = 0, plies: int = 0, max_probes: int = MAX_PROBES,
-                max_hold_bytes: int | None = None, alloc=None, free=None, plain=None, far: bool = True):
+                max_hold_bytes: int | None = None, alloc=None, free=None, plain=None, far: bool | None = None):
     """Two zero-filled uint8 tensors of bytes_a / bytes_b bytes on `device`, placed so that writes to them overlap.
     Returns (a, b, info); info records every probe, what was held and why the search ended.
 
@@ -152,8 +156,9 @@ def spread_pair(bytes_a: int, bytes_b: int, device, slot_boards: int = 0, plies:
     (each array the head of a block of its own, see the module docstring) and the plain pair stays in the race: the best
     pair seen wins, so the result is never worse than the caller's own placement (with most of a device taken the capped
     search may find nothing better).  alloc(nbytes) -> uint8 tensor (raising on out-of-memory) and free() -> free bytes:
-    the allocator and the memory gauge (tests script them).  far: on a device that is mostly free, a capped search that found
-    nothing goes on with candidates behind transient gaps of 64 / 96 / 128 GiB (see FAR_GAPS_BYTES)."""
+    the allocator and the memory gauge (tests script them).  far: a capped search that found nothing goes on with candidates
+    behind transient gaps of 64 / 96 / 128 GiB (see FAR_GAPS_BYTES) -- None: only on a device that is mostly free
+    (FAR_MIN_FREE_BYTES), True: whenever a gap fits beside the reserve (the caller owns the device), False: never."""
     t0 = time.perf_counter()
     dev = torch.device(device)
     alloc = alloc or device_alloc(dev)
@@ -240,8 +245,8 @@ def spread_pair(bytes_a: int, bytes_b: int, device, slot_boards: int = 0, plies:
                 break
             try_pair(*((new, k) if grow == "a" else (k, new)))
         grow = other
-    far_gaps = []
-    if far and best[0] > ACCEPT_RATIO and ended != "the device refused a block":
+    far_gaps, transient = [], 0
+    if far is not False and best[0] > ACCEPT_RATIO and ended != "the device refused a block":
         # the blocks and gaps that led nowhere go back first (all but the arrays' first blocks and the best pair so far)
         keep_a, keep_b = {0, best[1]}, {0, best[2]}
         for k in range(len(pool["a"])):
@@ -254,10 +259,11 @@ def spread_pair(bytes_a: int, bytes_b: int, device, slot_boards: int = 0, plies:
         peak = held
         held = sum(block["a"] for x in pool["a"] if x is not None) + sum(block["b"] for x in pool["b"] if x is not None)
         for gap in FAR_GAPS_BYTES:
-            if free() < max(FAR_MIN_FREE_BYTES, gap + block["b"] + RESERVE_BYTES):
+            if free() < max(0 if far else FAR_MIN_FREE_BYTES, gap + block["b"] + RESERVE_BYTES):
                 break
             try:
                 hold = alloc(gap)
+                transient = max(transient, held + gap + block["b"])
                 blk = alloc(block["b"])
             except _OOM:
                 ended += "; the device refused a far candidate"
@@ -277,7 +283,7 @@ def spread_pair(bytes_a: int, bytes_b: int, device, slot_boards: int = 0, plies:
         out = keep_plain("%s; the allocator's own placement (%.3f) was not beaten" % (ended, first[2]))
         out[2].update(probes=[round(first[2], 3)] + tried, held_gib=round(held / GIB, 1), cap_gib=round(cap / GIB, 1),
                       released_blocks=sum(x is not None for x in pool["a"]) + sum(x is not None for x in pool["b"]) + len(skips),
-                      far_gaps_gib=far_gaps)
+                      far_gaps_gib=far_gaps, transient_peak_gib=round(transient / GIB, 1))
         pool.clear(); skips.clear()
         return out
     if first is not None:
@@ -293,4 +299,5 @@ def spread_pair(bytes_a: int, bytes_b: int, device, slot_boards: int = 0, plies:
     return a, b, {"spread": bool(ratio <= SPREAD_RATIO), "ratio": round(ratio, 3), "probes": tried,
                   "block_gib": [round(block["a"] / GIB, 3), round(block["b"] / GIB, 3)], "held_gib": round(held / GIB, 1),
                   "cap_gib": round(cap / GIB, 1), "released_blocks": released, "ended": ended,
-                  "torch_cache_gib": round(stranded, 3), "far_gaps_gib": far_gaps, "seconds": round(time.perf_counter() - t0, 3)}
+                  "torch_cache_gib": round(stranded, 3), "far_gaps_gib": far_gaps, "transient_peak_gib": round(transient / GIB, 1),
+                  "seconds": round(time.perf_counter() - t0, 3)}

@@ -26,6 +26,7 @@ from .board import BatchedBoard, _as_i32
 
 class BatchedGobblet:
     SLOT_PAD_BOARDS = 0  # see trajectory_buffers
+    STAGING_SETS = 2     # collect()'s own buffer sets kept at most (least recently used dropped first)
 
     metadata = {"name": "gobblet_v1_batched", "num_actions": nat.ACTIONS, "observation_shape": (3, 3, 13)}
 
@@ -132,6 +133,8 @@ class BatchedGobblet:
         if self.turn is not None:
             self.turn.zero_()
         self.ply = 0
+        if getattr(self, "_staging", None):
+            self.release_staging()
         self.refresh()
         return self.observe()
 
@@ -223,7 +226,8 @@ class BatchedGobblet:
                 "greedy2": nat.POLICY_GREEDY2, "greedy3": nat.POLICY_GREEDY3}
 
     def trajectory_buffers(self, plies: int, layout: str = "time", pad_boards: int | None = None,
-                           placement: str = "auto", policy_outputs: bool = False, candidates: bool = False) -> dict:
+                           placement: str = "auto", policy_outputs: bool = False, candidates: bool = False,
+                           far: bool | None = None) -> dict:
         """Device tensors for ``collect``.
 
         policy_outputs: also "chosen" (int32) and "how" (int8: 0 random ply, 1 greedy choice, 2 greedy fallback draw) for
@@ -239,7 +243,10 @@ class BatchedGobblet:
         allocator's own; 33 -> 27 us per ply at 2^20 boards).  When the device cannot spare the blocks the arrays are plain torch allocations and ``_placement``
         says why.  "spread" insists (raises if the arrays are too small to probe or the memory is not there), "any" takes
         the allocator's addresses as they come.  The search synchronises the device and takes a few milliseconds: make
-        the buffers once and reuse them (``collect(out=...)``).  What happened is recorded under ``_placement``.
+        the buffers once and reuse them (``collect(out=...)``).  What happened is recorded under ``_placement``
+        (``ratio`` >= 0.95: the arrays share a class -- "unplaced").  ``far``: see ``placement.spread_pair`` (True = a caller
+        that owns the device lets the search reach behind transient gaps of 64 - 128 GiB; False = never; None = only on a
+        device with 160 GiB free).
 
         layout "time" (default): every entry has shape (plies, N, ...) -- one slice per ply, a view of a
         (plies, slot_boards, ...) allocation; slot_boards = N rounded up to 128 boards (+ ``pad_boards``), so that
@@ -282,7 +289,7 @@ class BatchedGobblet:
             cells = T * ply_stride if layout == "time" else tiles * T * 64
             try:
                 a, b, placed = _placement.spread_pair(
-                    cells * 117, cells * nat.ACTIONS, dev, **geometry,
+                    cells * 117, cells * nat.ACTIONS, dev, **geometry, far=far,
                     plain=lambda: (torch.empty(cells * 117, dtype=torch.uint8, device=dev),
                                    torch.empty(cells * nat.ACTIONS, dtype=torch.uint8, device=dev)))
                 full["observation"] = a.view(torch.int8).view(lead + (3, 3, 13))
@@ -331,9 +338,11 @@ class BatchedGobblet:
         ``out``: a dict from ``trajectory_buffers(plies)`` to write into (a replay buffer's staging area; placed for speed,
         see there).  Without it the environment's OWN staging buffers are used: one set per (plies, layout, policy outputs),
         made -- and placed, see ``trajectory_buffers`` -- on the first call and reused by every later one, so the returned
-        tensors are valid until the next ``collect`` of the same shape on this environment (clone what must outlive it, or
-        pass ``out``).  Round 3 allocated fresh unplaced buffers per call, which ran at 0.72-0.85 of the placed rate at 2^20
-        boards and paid an allocation per call.  ``release_staging()`` drops them.
+        tensors are valid until the next ``collect`` of the same shape on this environment -- two successive calls return THE
+        SAME tensors (clone what must outlive the next call, pass ``out``, or pass ``out="fresh"`` for buffers of your own made
+        on the spot).  At most ``STAGING_SETS`` (2) sets are kept, least recently used dropped first (a set is several GiB at
+        2^20 boards); ``release_staging()`` / ``reset()`` drop them all.  Round 3 allocated fresh unplaced buffers per call,
+        which ran at 0.72-0.85 of the placed rate at 2^20 boards and paid an allocation per call.
 
         ``first_actions`` (int (N,)): the first ply plays these actions -- an external policy's decision -- and the
         remaining plies are sampled (``gbl_collect_from``): ``collect(2, out, first_actions=a)`` is one decision of the
@@ -350,14 +359,22 @@ class BatchedGobblet:
         if not self.auto_reset:
             raise ValueError("collect() plays with auto-reset; this environment was created with auto_reset=False")
         T = int(plies)
+        if isinstance(out, str):
+            if out != "fresh":
+                raise ValueError("out: a dict from trajectory_buffers(), None (the environment's staging buffers) or 'fresh'")
+            # buffers of the caller's own: made (and placed) now, not kept by the environment, never overwritten by a later call
+            out = self.trajectory_buffers(T, layout=layout, policy_outputs=policies is not None, far=False)
         if out is None:
             key = (T, layout, policies is not None)
-            out = self._staging.get(key)
-            if out is None:
-                out = self.trajectory_buffers(T, layout=layout, policy_outputs=policies is not None)
-                # (buffers made inside a graph capture belong to the graph's private pool: not kept beyond it)
-                if not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
-                    self._staging[key] = out
+            out = self._staging.pop(key, None)
+            made = out is None
+            if made:
+                out = self.trajectory_buffers(T, layout=layout, policy_outputs=policies is not None, far=False)
+            # (buffers made inside a graph capture belong to the graph's private pool: not kept beyond it)
+            if not (made and self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+                self._staging[key] = out             # most recently used last
+                while len(self._staging) > self.STAGING_SETS:
+                    self._staging.pop(next(iter(self._staging)))
         if out["_plies"] != T:
             raise ValueError("trajectory buffers were made for %d plies" % out["_plies"])
         f, n = out["_full"], self.num_envs
@@ -407,8 +424,46 @@ class BatchedGobblet:
 
     def release_staging(self) -> None:
         """Drop the trajectory buffers ``collect()`` keeps for calls without ``out`` (their blocks go back to the driver
-        once the last tensor over them is gone)."""
+        once the last tensor over them is gone; blocks parked during a graph capture are freed here too)."""
         self._staging.clear()
+        if self.device.type == "cuda":
+            _placement.free_parked()
+
+    def place(self, out: dict, rehome: bool = True, far: bool | None = None) -> dict:
+        """Probe -- and, with ``rehome``, re-place -- the observation / mask arrays of trajectory buffers the caller made
+        WITHOUT the search (``trajectory_buffers(..., placement="any")``, or buffers whose placement record says the arrays
+        share a 96 GiB class of HBM: ratio >= 0.95, 20 % slower at 2^20 boards).  Returns the placement record (also stored
+        under ``out["_placement"]``); when a better pair is found the dict's two arrays are REPLACED by it (contents copied,
+        views rebuilt) -- tensors taken from the dict before the call keep pointing at the old arrays."""
+        f = out["_full"]
+        if "observation" not in f or f["action_mask"].numel() < _placement.MIN_BYTES:
+            rec = {"spread": False, "why": "arrays too small to probe" if "observation" in f else "no observation stream"}
+            out["_placement"] = rec
+            return rec
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise ValueError("place() probes and synchronises: not inside a graph capture")
+        geometry = (dict(slot_boards=out["_ply_stride"], plies=out["_plies"])
+                    if out["_layout"] == "time" and out["_ply_stride"] % 128 == 0 else {})
+        obs, mask = f["observation"], f["action_mask"]
+        keep_o, keep_m = obs.clone(), mask.clone()  # (a probe overwrites what it measures)
+        flat = lambda t: t.view(torch.uint8).reshape(-1)  # noqa: E731
+        if not rehome:
+            both, ua, ub = _placement.probe(flat(obs), flat(mask), **geometry)
+            rec = {"ratio": round(both / max(ua + ub, 1e-9), 3), "probes": [round(both / max(ua + ub, 1e-9), 3)],
+                   "ended": "probed only"}
+            rec["spread"] = rec["ratio"] <= _placement.SPREAD_RATIO
+            obs.copy_(keep_o); mask.copy_(keep_m)
+        else:
+            a, b, rec = _placement.spread_pair(obs.numel(), mask.numel(), self.device, **geometry, far=far,
+                                               plain=lambda: (flat(obs), flat(mask)))
+            f["observation"] = a.view(torch.int8).view(obs.shape)
+            f["action_mask"] = b.view(torch.int8).view(mask.shape)
+            f["observation"].copy_(keep_o); f["action_mask"].copy_(keep_m)
+            n = self.num_envs
+            for k in ("observation", "action_mask"):
+                out[k] = f[k][:, :n] if out["_layout"] == "time" else f[k]
+        out["_placement"] = rec
+        return rec
 
     def step_into(self, actions, out: dict, t: int):
         """``step(actions)`` with this ply's outputs written straight into slot ``t`` of time-major trajectory buffers

@@ -307,11 +307,16 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
  *   GBL_COLLECT_PAIR    k_collect2, two wavefronts per tile (one plays, one stores): grids of up to 2048 tiles
  *   GBL_COLLECT_SMALL   k_collect_small, 16 boards per wavefront and four lanes per board, the game played redundantly by
  *                       the wavefront that stores the observation rows and the one that stores the mask rows and scalars:
- *                       small batches (a few thousand boards), whose launch lasts as long as one wavefront's serial path */
+ *                       small batches (a few thousand boards), whose launch lasts as long as one wavefront's serial path
+ *   GBL_COLLECT_HALF    the same with 32 boards per wavefront, two lanes per board
+ *   GBL_COLLECT_ROLES   the same with a whole tile of 64 boards per wavefront, one lane per board: up to three role
+ *                       wavefronts per tile that share nothing (batches between GBL_COLLECT_HALF and the HBM-bound regime) */
 #define GBL_COLLECT_STREAM 0
 #define GBL_COLLECT_CACHED 1
 #define GBL_COLLECT_PAIR 2
 #define GBL_COLLECT_SMALL 3
+#define GBL_COLLECT_HALF 4
+#define GBL_COLLECT_ROLES 5
 int gbl_collect_variant(int64_t n, uint32_t plies, int with_mask, int with_obs);
 /* gbl_collect whose FIRST ply plays caller-supplied actions (first_actions int32[n]; NULL = gbl_collect): the collector
  * step of a policy that lives outside the library against masked-random replies -- the loops of the reference's trainers

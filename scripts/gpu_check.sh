@@ -3,7 +3,7 @@
 #   gpurun --timeout 1100 -- 'scripts/gpu_check.sh [outdir]'
 set -e -o pipefail
 export TMPDIR=/tmp
-O=gpurun_out/${1:-r04_check}
+O=gpurun_out/${1:-r05_check}
 rm -rf $O && mkdir -p $O
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $O/build_smoke.log 2>&1 || { tail -20 $O/build_smoke.log; exit 1; }
 tail -1 $O/build_smoke.log

@@ -108,13 +108,14 @@ def rollout(state, to_move, done, seed, env_base, ply0, plies, illegal_mode=0):
     return {"actions": a, "winner": w, "reward": rw, "mask": mask, "obs": obs, "counters": cnt}
 
 
-def rollout_small(state, to_move, done, seed, env_base, ply0, plies, illegal_mode=0):
-    """The small-batch kernel's walk (sub-tiles of 16 boards, four lanes per board): outputs of the last ply."""
+def rollout_small(state, to_move, done, seed, env_base, ply0, plies, illegal_mode=0, lpb=4):
+    """The role kernel's walk (sub-tiles of 64 / lpb boards, lpb lanes per board): outputs of the last ply."""
     n = len(state)
     a = np.full(n, 77, np.int32); w = np.full(n, 77, np.int8); rw = np.full((n, 2), 77, np.int8)
     mask = np.full((n, 54), 77, np.int8); obs = np.full((n, 3, 3, 13), 77, np.int8)
     lib().emu_rollout_small(_p(state), _p(to_move), _p(done), _p(a), _p(w), _p(rw), _p(mask), _p(obs), C.c_int64(n),
-                            C.c_uint64(seed), C.c_uint64(env_base), C.c_uint32(ply0), C.c_uint32(plies), C.c_int(illegal_mode))
+                            C.c_uint64(seed), C.c_uint64(env_base), C.c_uint32(ply0), C.c_uint32(plies), C.c_int(illegal_mode),
+                            C.c_int(lpb))
     return {"actions": a, "winner": w, "reward": rw, "mask": mask, "obs": obs}
 
 

@@ -10,6 +10,7 @@
 #define GBL_HOST_EMU
 #include <stdint.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 #define __device__
@@ -336,35 +337,38 @@ void emu_rollout(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_
     });
 }
 
-// The small-batch kernel's walk (k_collect_small, gobblet_hip.hip): a sub-tile of 16 boards per wavefront, lane = 4 * board + j;
-// the four lanes of a board play the game alike and share the row work -- lane j writes bytes [16 j, 16 j + 16) of the board's
-// mask row (mask_row_quad) and drops channels j, j + 4, j + 8 of its observation row (obs_scatter_quad).  `plies` plies, the
-// outputs of the last one stored (what gbl_collect's last slot holds), all three roles folded into one walk.
-void emu_rollout_small(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_out, int8_t *winner_out,
-                       int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, uint64_t seed, uint64_t env_base,
-                       uint32_t ply0, uint32_t plies, int illegal_mode)
+// The role kernel's walk (k_collect_small<.., LPB>, gobblet_hip.hip): a sub-tile of 64 / LPB boards per wavefront, lane = LPB *
+// board + j; the LPB lanes of a board play the game alike and share the row work -- lane j writes bytes [64 j / LPB, 64 (j + 1) /
+// LPB) of the board's mask row (mask_row_part) and drops channels j, j + LPB, ... of its observation row (obs_scatter_part).
+// `plies` plies, the outputs of the last one stored (what gbl_collect's last slot holds), all three roles folded into one walk.
+}  // extern "C"
+template <int LPB>
+static void rollout_sub(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_out, int8_t *winner_out,
+                        int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, uint64_t seed, uint64_t env_base,
+                        uint32_t ply0, uint32_t plies, int illegal_mode)
 {
-    const int64_t nsub = (n + kSub - 1) / kSub;
+    constexpr int BPS = kTile / LPB, SH = LPB == 4 ? 2 : LPB == 2 ? 1 : 0;
+    const int64_t nsub = (n + BPS - 1) / BPS;
     for (int64_t sub = 0; sub < nsub; ++sub) {
-        const int64_t left = n - sub * kSub;
-        const int rows = left < kSub ? (int)left : kSub;
-        std::vector<uint32_t> is(kSub * kCells / 4 + 4, 0xDEADBEEFu), im(kSub * kActions / 4 + 4, 0xDEADBEEFu),
-            io(kSub * kObs / 4 + 4, 0xDEADBEEFu);
-        for (int lane = 0; lane < 64; ++lane) sub_in<kCells>(state + sub * (kSub * kCells), is.data(), lane, rows);
+        const int64_t left = n - sub * BPS;
+        const int rows = left < BPS ? (int)left : BPS;
+        std::vector<uint32_t> is(BPS * kCells / 4 + 4, 0xDEADBEEFu), im(BPS * kActions / 4 + 4, 0xDEADBEEFu),
+            io(BPS * kObs / 4 + 4, 0xDEADBEEFu);
+        for (int lane = 0; lane < 64; ++lane) sub_in<kCells, BPS>(state + sub * (BPS * kCells), is.data(), lane, rows);
         Planes P[64];
         int MOVER[64];
         uint64_t LEGAL[64];
         uint32_t R[64][7];
         int MOVER0[64];
         for (int lane = 0; lane < 64; ++lane) {  // all lanes read their rows and movers before any lane patches or stores (lockstep)
-            row_load<kCells>(is.data(), lane >> 2, R[lane]);
+            row_load<kCells>(is.data(), lane >> SH, R[lane]);
             R[lane][6] &= 0x00FFFFFFu;
-            MOVER0[lane] = (lane >> 2) < rows ? (to_move[sub * kSub + (lane >> 2)] != 0) : 0;
+            MOVER0[lane] = (lane >> SH) < rows ? (to_move[sub * BPS + (lane >> SH)] != 0) : 0;
         }
-        for (int lane = 0; lane < 64; ++lane) {  // every lane of a quad has read the same row and plays the same game
-            const int bq = lane >> 2;
+        for (int lane = 0; lane < 64; ++lane) {  // every lane of a board has read the same row and plays the same game
+            const int bq = lane >> SH, j = lane & (LPB - 1);
             const bool valid = bq < rows;
-            const int64_t b = sub * kSub + bq;
+            const int64_t b = sub * BPS + bq;
             Planes p = make_planes(R[lane]);
             p.nz = valid ? p.nz : 0u;
             int mover = MOVER0[lane];
@@ -373,8 +377,8 @@ void emu_rollout_small(int8_t *state, int8_t *to_move, int8_t *done, int32_t *ac
             uint64_t legal = legal54(p, mover);
             for (uint32_t k = 0; k < plies; ++k) {
                 action = sample54(legal, seed, env_base + (uint64_t)b, ply0 + k);
-                // (only lane 0 of a quad patches the state image, as role 0's four lanes write the same bytes)
-                if ((lane & 3) == 0)
+                // (only lane 0 of a board patches the state image, as role 0's lanes write the same bytes)
+                if (j == 0)
                     y = play_ply(p, ImageRow{reinterpret_cast<uint8_t *>(is.data()) + bq * kCells}, mover, legal, action, illegal_mode);
                 else
                     y = play_ply(p, RegRowNone{}, mover, legal, action, illegal_mode);
@@ -382,12 +386,12 @@ void emu_rollout_small(int8_t *state, int8_t *to_move, int8_t *done, int32_t *ac
                 if (y.terminal) {
                     p = Planes{0u, 0u, 0u};
                     mover = 0;
-                    if ((lane & 3) == 0) ImageRow{reinterpret_cast<uint8_t *>(is.data()) + bq * kCells}.reset();
+                    if (j == 0) ImageRow{reinterpret_cast<uint8_t *>(is.data()) + bq * kCells}.reset();
                 }
                 legal = legal54(p, mover);
             }
             P[lane] = p; MOVER[lane] = mover; LEGAL[lane] = legal;
-            if (valid && (lane & 3) == 0) {
+            if (valid && j == 0) {
                 to_move[b] = (int8_t)mover;
                 done[b] = (int8_t)dn;
                 if (actions_out) actions_out[b] = action;
@@ -395,19 +399,45 @@ void emu_rollout_small(int8_t *state, int8_t *to_move, int8_t *done, int32_t *ac
                 if (reward_out) { reward_out[2 * b] = (int8_t)y.r0; reward_out[2 * b + 1] = (int8_t)y.r1; }
             }
         }
-        for (int lane = 0; lane < 64; ++lane) sub_out<kCells, kStorePlain>(state + sub * (kSub * kCells), is.data(), lane, rows);
+        for (int lane = 0; lane < 64; ++lane) sub_out<kCells, kStorePlain, BPS>(state + sub * (BPS * kCells), is.data(), lane, rows);
+        // the output images leave through the registers of sub_fetch / sub_store (full sub-tiles) or byte by byte (the ragged last one)
+        auto image_out = [&](auto rowb, int8_t *dst, const uint32_t *img) {
+            constexpr int ROWB = decltype(rowb)::value;
+            if (rows == BPS) {
+                for (int lane = 0; lane < 64; ++lane) {
+                    SubVecs<sub_vectors<ROWB, BPS>()> v{};
+                    sub_fetch<ROWB, BPS>(img, lane, v);
+                    sub_store<ROWB, kStorePlain, BPS>(dst, v, lane);
+                }
+            } else {
+                memcpy(dst, img, (size_t)rows * ROWB);
+            }
+        };
         if (mask_out) {
             for (int lane = 0; lane < 64; ++lane)
-                mask_row_quad(reinterpret_cast<uint8_t *>(im.data()) + (lane >> 2) * kActions, LEGAL[lane], lane & 3);
-            for (int lane = 0; lane < 64; ++lane) sub_out<kActions, kStorePlain>(mask_out + sub * (kSub * kActions), im.data(), lane, rows);
+                mask_row_part<LPB>(reinterpret_cast<uint8_t *>(im.data()) + (lane >> SH) * kActions, LEGAL[lane], lane & (LPB - 1));
+            image_out(std::integral_constant<int, kActions>{}, mask_out + sub * (BPS * kActions), im.data());
         }
         if (obs_out) {
-            for (int lane = 0; lane < 64; ++lane) sub_obs_zero(io.data(), lane);
+            for (int lane = 0; lane < 64; ++lane) sub_obs_zero<BPS>(io.data(), lane);
             for (int lane = 0; lane < 64; ++lane)
-                obs_scatter_quad(reinterpret_cast<uint8_t *>(io.data()) + (lane >> 2) * kObs, P[lane], MOVER[lane], lane & 3);
-            for (int lane = 0; lane < 64; ++lane) sub_out<kObs, kStorePlain>(obs_out + sub * (kSub * kObs), io.data(), lane, rows);
+                obs_scatter_part<LPB>(reinterpret_cast<uint8_t *>(io.data()) + (lane >> SH) * kObs, P[lane], MOVER[lane], lane & (LPB - 1));
+            image_out(std::integral_constant<int, kObs>{}, obs_out + sub * (BPS * kObs), io.data());
         }
     }
+}
+
+extern "C" {
+void emu_rollout_small(int8_t *state, int8_t *to_move, int8_t *done, int32_t *actions_out, int8_t *winner_out,
+                       int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int64_t n, uint64_t seed, uint64_t env_base,
+                       uint32_t ply0, uint32_t plies, int illegal_mode, int lpb)
+{
+    if (lpb == 4)
+        rollout_sub<4>(state, to_move, done, actions_out, winner_out, reward_out, mask_out, obs_out, n, seed, env_base, ply0, plies, illegal_mode);
+    else if (lpb == 2)
+        rollout_sub<2>(state, to_move, done, actions_out, winner_out, reward_out, mask_out, obs_out, n, seed, env_base, ply0, plies, illegal_mode);
+    else
+        rollout_sub<1>(state, to_move, done, actions_out, winner_out, reward_out, mask_out, obs_out, n, seed, env_base, ply0, plies, illegal_mode);
 }
 
 // risky_from_have (threat squares) against the walk over the eight lines it replaced, for all 512 sets: mismatches

@@ -447,8 +447,15 @@ def test_placement_search_logic(monkeypatch):
     assert [m >> 30 for m in made][-4:] == [64, 2, 96, 2] and seen[-1][0] == 1   # (gap, block) twice; against the first observation block
     seen, info = run([1.0] * 40, far=True)                # nothing anywhere: three far candidates, then the best seen
     assert info["far_gaps_gib"] == [64, 96, 128] and info["ratio"] == 1.0 and not info["spread"]
-    seen, info = run([1.0] * 40, free=150 * GIB, far=True)  # a device that is not mostly free: no far candidates at all
-    assert info["far_gaps_gib"] == [] and max(made) <= placement.MAX_SKIP_BYTES
+    assert info["transient_peak_gib"] >= 128 + 2          # (what was held for the duration of two allocations is on record)
+    seen, info = run([1.0] * 40, free=150 * GIB, far=None)  # a device that is not mostly free, nobody asked: no far candidates
+    assert info["far_gaps_gib"] == [] and max(made) <= placement.MAX_SKIP_BYTES and info["transient_peak_gib"] == 0.0
+    seen, info = run([1.0] * 40, free=288 * GIB, far=None)  # ... mostly free: tried unasked (the driver's box of round 4)
+    assert info["far_gaps_gib"] == [64, 96, 128]
+    seen, info = run([1.0] * 40, free=150 * GIB, far=True)  # the caller owns the device and says so: whatever gap still fits
+    assert info["far_gaps_gib"] == [64, 96, 128]
+    seen, info = run([1.0] * 40, free=100 * GIB, far=True)
+    assert info["far_gaps_gib"] == [64] and 64 + 2 <= info["transient_peak_gib"] <= 100 - placement.RESERVE_BYTES / GIB
     # the pair as the caller's allocator places it is probed first and stays in the race
     plain_made = []
 

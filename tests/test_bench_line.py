@@ -23,7 +23,7 @@ def fake_full(world=8, configs=16, blob=2000):
     placements = [{"ratio": 0.8 + 0.01 * r, "probes": [1.0] * 19, "held_gib": 62.0, "cap_gib": 64.0, "spread": True, "ended": "e" * 200}
                   for r in range(world)]
     full = bench.contract_record(args, pipe, roof, 1 << 20, (1 << 20) // world, world, 20, 5, 6.0e-4, 5.6e-4, 1, False,
-                                 [72.0 + r for r in range(world)], placements, True)
+                                 [72.0 + r for r in range(world)], placements, True, [541.6, 539.9, 545.0, 540.2, 560.1])
     full["configs"] = {f"record_{i}": {"workload": "w" * blob, "value": 1.0, "roofline": {"frac": 0.5, "note": "x" * blob}} for i in range(configs)}
     full["cpu_baseline"] = {"value": 8.7e6, "unit": "env-steps/s", "cores": 16, "kind": "port", "sample": "s" * 400, "value_1core": 5.8e5,
                             "greedy_depth2": {"decisions_per_s_1core": 1.0e4, "sample": "g" * blob}}
@@ -47,9 +47,23 @@ def test_compact_line_is_small_flat_and_complete():
     assert c["configs_file"] == "gpurun_out/bench_configs.json" and c["configs_recorded"] == 16
     assert c["kernel_us_max"] == 79.0 and c["kernel_us_min"] == 72.0 and c["rccl_ranks"] == 8
     assert abs(c["placement_ratio_min"] - 0.8) < 1e-9 and abs(c["placement_ratio_max"] - 0.87) < 1e-9
-    # value / ms_per_step come from the ranks' own spans, the trailing barrier is reported beside them
-    assert abs(d["value"] - (1 << 20) * 20 / 5.6e-4) / d["value"] < 1e-12 and abs(d["ms_per_step"] - 5.6e-4 / 20 * 1e3) < 1e-12
-    assert c["ms_per_step_with_trailing_barrier"] > d["ms_per_step"]
+    # value / ms_per_step come from the CONTRACT's span (barrier + synchronize on both sides); the ranks' own spans beside them
+    assert abs(d["value"] - (1 << 20) * 20 / 6.0e-4) / d["value"] < 1e-12 and abs(d["ms_per_step"] - 6.0e-4 / 20 * 1e3) < 1e-12
+    assert c["ms_per_step_own_span"] < d["ms_per_step"]
+    # the line verifies itself: where the traffic figure comes from, the spread of five passes, whether the arrays were placed
+    assert d["roofline"]["traffic_source"].startswith("sss") and len(d["roofline"]["traffic_source"]) <= 140
+    assert c["kernel_us_median_of_5"] == 541.6 and c["kernel_us_min_of_5"] == 539.9 and c["kernel_us_max_of_5"] == 560.1
+    assert c["placement"] == "partly placed"
+
+
+def test_unplaced_arrays_are_flagged():
+    full = fake_full(world=1)
+    assert json.loads(bench.compact_line(full, None))["config"]["placement"] == "placed"
+    full["config"]["placement_ratio_max"] = 1.0
+    args = types.SimpleNamespace(no_obs=False, boards_per_gpu=0, mode="collect", traj=20, dist_backend="nccl")
+    rec = bench.contract_record(args, None, {}, 1 << 20, 1 << 20, 1, 20, 5, 6e-4, 5.6e-4, 1, False, [540.0],
+                                [{"ratio": 1.0, "probes": [1.0] * 15}], False, [540.0] * 5)
+    assert rec["config"]["placement"] == "unplaced" and rec["config"]["placement_ratio_min"] == 1.0
 
 
 def test_compact_line_sheds_prose_before_it_grows_too_long():
@@ -63,3 +77,20 @@ def test_valu_roofline_uses_the_two_cycle_peak():
     r = bench.valu_roofline("no-such-key", "k", 1e-5, 1, "t")
     assert r["peak"] == 1024 * 2.4e9 / 2 and r["frac"] is None   # (no committed counter for that key: null, with the reason)
     assert bench.VALU_CYCLES_PEAK == 2.0
+
+
+def test_more_ranks_than_gpus_fails_fast_with_a_clear_message():
+    """`--gpus N` on a node with fewer than N GPUs (the driver's SCALE run pointed at a one-GPU box; here: none at all) must
+    end at once with a message -- bare, and under a launcher, where every rank has to leave BEFORE the rendezvous."""
+    import subprocess
+    import time
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    t0 = time.time()
+    bare = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"],
+                          capture_output=True, text=True, timeout=120, env=env)
+    assert bare.returncode != 0 and "--gpus 8 but this node has" in bare.stderr and bare.stdout.strip() == ""
+    launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                               "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
+                               "--warmup", "5"], capture_output=True, text=True, timeout=120, env=env)
+    assert launched.returncode != 0 and "2 rank(s) but this node has" in launched.stderr
+    assert time.time() - t0 < 100

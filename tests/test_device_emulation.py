@@ -127,15 +127,18 @@ def test_rollout_vs_oracle(n, plies):
         assert np.array_equal(o1[k], o2[k]), k
 
 
-@pytest.mark.parametrize("n,plies,illegal", [(1, 9, 0), (15, 20, 1), (16, 1, 0), (17, 33, 0), (63, 12, 1), (65, 40, 0), (1000, 25, 0)])
-def test_small_batch_walk_vs_oracle(n, plies, illegal):
-    """The small-batch kernel's device code on the host (k_collect_small: sub-tiles of 16 boards, four lanes per board that play
-    alike and share a mask row -- bytes [16 j, 16 j + 16) -- and an observation row -- channels j, j + 4, j + 8): sub-tile
-    load / store incl. ragged last sub-tiles, the quad row builders, the byte patches of the state image; against the oracle."""
+@pytest.mark.parametrize("lpb", [4, 2, 1])
+@pytest.mark.parametrize("n,plies,illegal", [(1, 9, 0), (15, 20, 1), (16, 1, 0), (17, 33, 0), (31, 5, 0), (33, 7, 1), (63, 12, 1),
+                                             (64, 3, 0), (65, 40, 0), (1000, 25, 0)])
+def test_small_batch_walk_vs_oracle(n, plies, illegal, lpb):
+    """The role kernel's device code on the host (k_collect_small<.., LPB>: sub-tiles of 64 / LPB boards, LPB lanes per board that
+    play alike and share a mask row -- bytes [64 j / LPB, 64 (j + 1) / LPB) -- and an observation row -- channels j, j + LPB, ...):
+    sub-tile load / store incl. ragged last sub-tiles, the images' way out through sub_fetch / sub_store, the row builders of
+    every LPB, the byte patches of the state image; against the oracle."""
     s1, t1, d1 = oracle.batch_reset(n)
     s2, t2, d2 = oracle.batch_reset(n)
     o1 = oracle.batch_rollout(s1, t1, d1, 7, 123456789012, 5, plies, illegal_mode=illegal)
-    o2 = emu.rollout_small(s2, t2, d2, 7, 123456789012, 5, plies, illegal_mode=illegal)
+    o2 = emu.rollout_small(s2, t2, d2, 7, 123456789012, 5, plies, illegal_mode=illegal, lpb=lpb)
     assert np.array_equal(s1, s2) and np.array_equal(t1, t2) and np.array_equal(d1, d2)
     for k in o2:
         assert np.array_equal(o1[k], o2[k]), k

@@ -6,7 +6,9 @@ instantiation each one reaches.  Bit-exact (integer / byte work).
     bench record                  entry point (as bench.py calls it)        kernel instantiation
     ----------------------------  ----------------------------------------  -------------------------------------------
     headline (2^20, collect)      gbl_collect, ply index on the device      k_collect<mask, obs, DEV_PLY, NT>, 8 and 20 plies per launch
-    c2_4096                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY>  (<= 8 192 boards)
+    c2_4096                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 4>  (<= 8 192 boards)
+    c_16384                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 2>  (<= 16 384 boards)
+    c_32768, c_65536              gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 1>  (<= 65 536 boards)
     c3_262144                     gbl_collect                               k_collect<mask, obs, DEV_PLY, NT>
     c4_shard_131072               gbl_collect                               k_collect2<mask, obs, DEV_PLY>  (2048 tiles)
     large_4194304                 gbl_collect                               k_collect<mask, obs, DEV_PLY, NT>, identity tile map
@@ -89,6 +91,9 @@ COLLECT_RECORDS = {
     "headline_1048576": (1 << 20, 8, True),
     "headline_driver_cmd_1048576": (1 << 20, 20, True),   # `--steps 20`: the whole timed run is ONE launch of 20 plies
     "c2_4096": (4096, 32, True),
+    "c_16384": (16384, 32, True),
+    "c_32768": (32768, 32, True),
+    "c_65536": (65536, 32, True),
     "c3_262144": (262144, 16, True),
     "c4_shard_131072": (131072, 32, True),
     "large_4194304": (1 << 22, 3, True),
@@ -224,7 +229,8 @@ def test_bench_step_mode_vs_oracle(G):
 
 
 @pytest.mark.parametrize("n,T,illegal,with_obs", [(131072, 2, "noop", True), (262144, 2, "terminate", True),
-                                                  (4099, 3, "terminate", False), (131073, 2, "noop", True), (70, 1, "noop", True)])
+                                                  (4099, 3, "terminate", False), (131073, 2, "noop", True), (70, 1, "noop", True),
+                                                  (12001, 2, "noop", True), (40001, 1, "terminate", True), (40001, 3, "noop", False)])
 def test_collect_from_external_first_ply_vs_oracle(G, n, T, illegal, with_obs):
     """gbl_collect_from (bench records step_reply_*): the first ply plays caller-supplied actions -- an external policy's,
     some of them illegal or out of range -- the rest are sampled; k_collect2 at 131 072 boards, k_collect beyond.  Three
@@ -264,18 +270,25 @@ def test_collect_from_external_first_ply_vs_oracle(G, n, T, illegal, with_obs):
         env.collect(T, out=tr, first_actions=torch.zeros(n, dtype=torch.int32, device=DEV), policies=("random", "random"))
 
 
-# ---- the small-batch kernel (k_collect_small: sub-tiles of 16 boards, four lanes per board) --------------------------------
-SMALL_SIZES = [1, 15, 16, 17, 63, 65, 4096, 4099, 8192]
+# ---- the role kernel (k_collect_small<.., LPB>: sub-tiles of 64 / LPB boards, LPB lanes per board) -------------------------
+# LPB = 4 up to 8 192 boards (GBL_COLLECT_SMALL), 2 up to 16 384 (GBL_COLLECT_HALF), 1 up to 65 536 (GBL_COLLECT_ROLES)
+SMALL_SIZES = [1, 15, 16, 17, 63, 65, 4096, 4099, 8192,
+               8193, 8223, 12321, 16384,            # two lanes per board: ragged sub-tiles of 1, 31 and 1 rows; whole ones
+               16385, 16447, 32768, 65535, 65536]   # one lane per board: ragged tiles of 1, 63 and 63 rows; whole ones
+
+
+def role_variant(n):
+    return 3 if n <= 8192 else 4 if n <= 16384 else 5
 
 
 @pytest.mark.parametrize("with_obs", [True, False], ids=["full", "maskonly"])
 @pytest.mark.parametrize("n", SMALL_SIZES)
 def test_small_batch_collect_vs_oracle(G, n, with_obs):
-    """gbl_collect on small batches (up to 8 192 boards: GBL_COLLECT_SMALL) directly against the oracle, FULL and MASK_ONLY,
-    time- and tile-major slots, both illegal modes, ply index by value and on the device, tallies and turn counters; ragged
-    last sub-tiles (1, 15, 17, 63, 65, 4 099 boards) and whole ones (16, 4 096, 8 192)."""
-    assert G._native.lib().gbl_collect_variant(n, 7, 1, int(with_obs)) == 3  # GBL_COLLECT_SMALL
-    T, seed, base, warm = 7, 29, 123_456_789_012, 6
+    """gbl_collect on batches that do not fill the chip (GBL_COLLECT_SMALL / _HALF / _ROLES: four, two, one lane per board)
+    directly against the oracle, FULL and MASK_ONLY, time- and tile-major slots, both illegal modes, ply index by value and on
+    the device, tallies and turn counters; ragged last sub-tiles and whole ones of every form."""
+    assert G._native.lib().gbl_collect_variant(n, 7, 1, int(with_obs)) == role_variant(n)
+    T, seed, base, warm = (7 if n <= 8192 else 5), 29, 123_456_789_012, 6
     for layout, illegal, device_ply in (("time", "noop", True), ("tile", "terminate", False)):
         env, s, tm, dn = warm_pair(G, n, seed, base, warm, with_observation=with_obs, illegal_mode=illegal, track_turn=True)
         turn = npy(env.turn).copy()

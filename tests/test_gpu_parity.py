@@ -1074,7 +1074,7 @@ def test_bench_script_runs_and_reports(G):
     d = json.loads(lines[-1])
     assert d["config"]["rccl_ranks"] == 1 and d["config"]["dist_backend"] == "nccl" and len(full["detail"]["kernel_us_per_rank"]) == 1
     assert full["detail"]["trajectory_placement_per_rank"][0]["probes"]
-    assert d["config"]["kernel_us_max"] == full["detail"]["kernel_us_per_rank"][0] and d["config"]["ms_per_step_with_trailing_barrier"] >= d["ms_per_step"] > 0
+    assert d["config"]["kernel_us_max"] == full["detail"]["kernel_us_per_rank"][0] and d["ms_per_step"] >= d["config"]["ms_per_step_own_span"] > 0
 
 
 def test_bench_driver_command_prints_a_compact_line(G):
@@ -1150,8 +1150,29 @@ def test_bench_script_c4_shape_rehearsal(G):
     assert d["roofline"]["kernel"].startswith("k_collect2 (20 plies per launch)"), d["roofline"]["kernel"]
     assert len(full["detail"]["kernel_us_per_rank"]) == ranks and all(u > 0 for u in full["detail"]["kernel_us_per_rank"])
     assert d["config"]["kernel_us_max"] >= d["config"]["kernel_us_min"] > 0
-    assert d["config"]["ms_per_step_with_trailing_barrier"] >= d["ms_per_step"] > 0
+    assert d["ms_per_step"] >= d["config"]["ms_per_step_own_span"] > 0
     assert all(pl is not None and pl.get("ratio", 0) > 0 for pl in full["detail"]["trajectory_placement_per_rank"])
+
+
+def test_bench_more_ranks_than_gpus_fails_fast(G):
+    """The driver's SCALE run pointed at a box with fewer GPUs than ranks (this one has one): `--gpus 8`, bare and under a
+    launcher, ends at once with a message naming the cause -- no rank reaches the rendezvous, none touches the card."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    bare = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"],
+                          capture_output=True, text=True, timeout=200, env=env, cwd=root)
+    assert bare.returncode != 0 and "--gpus 8 but this node has 1 GPU(s)" in bare.stderr and bare.stdout.strip() == ""
+    launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                               "127.0.0.1", "--master-port", "29519", os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20",
+                               "--warmup", "5"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert launched.returncode != 0 and "8 rank(s) but this node has 1 GPU(s)" in launched.stderr
+    assert time.time() - t0 < 240
 
 
 def test_collect_beyond_4gib(G):
@@ -1249,6 +1270,34 @@ def test_placement_probe_and_spread_buffers(G):
     assert first["_placement"]["why"] == "arrays too small to probe" and small.collect(4) is first and small.collect(5) is not first
     small.release_staging()
     assert small.collect(4) is not first
+    # ... at most STAGING_SETS of them are kept (least recently used dropped first), and out="fresh" hands out buffers of the
+    # caller's own that no later call overwrites
+    four = small.collect(4)
+    five = small.collect(5)
+    assert small.collect(4) is four and small.collect(6) is not None and len(small._staging) == small.STAGING_SETS == 2
+    assert small.collect(5) is not five and small.collect(4) is not four
+    fresh = small.collect(4, out="fresh")
+    kept = fresh["actions"].clone()
+    assert small.collect(4) is not fresh and small.collect(4, out="fresh") is not fresh and torch.equal(fresh["actions"], kept)
+    with pytest.raises(ValueError):
+        small.collect(4, out="new")
+    small.reset()
+    assert not small._staging
+    # place(): buffers made WITHOUT the search are probed, or re-homed, afterwards; their contents survive either
+    e4 = G.BatchedGobblet(n, DEV, **kw)
+    mine = e4.trajectory_buffers(T, placement="any")
+    e4.collect(T, out=mine)
+    rec = e4.place(mine, rehome=False)
+    assert rec["ended"] == "probed only" and 0.5 < rec["ratio"] < 1.2 and mine["_placement"] is rec
+    for key in ("action_mask", "observation"):
+        assert torch.equal(mine[key], plain[key]), key
+    rec2 = e4.place(mine)
+    assert "probes" in rec2 and rec2["ratio"] <= rec["ratio"] + 0.08 and mine["observation"].shape == plain["observation"].shape
+    for key in ("actions", "action_mask", "observation"):
+        assert torch.equal(mine[key], plain[key]), key
+    e4.collect(T, out=mine); e2.collect(T, out=plain)
+    for key in ("actions", "action_mask", "observation"):
+        assert torch.equal(mine[key], plain[key]), key
 
 
 def test_placement_on_a_nearly_full_device(G):

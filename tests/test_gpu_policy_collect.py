@@ -94,6 +94,10 @@ def run_and_check(G, n, T, policies, opening, seed=5, base=0, warm=6, with_obs=T
     (40000, 6, ("greedy", "greedy"), 0, {"base": 7_000_000_000}),                       # <4,8> blocks (one generation)
     (20037, 5, ("greedy", "greedy"), 0, {"warm": 6}),                                   # <2,8> blocks
     (98341, 3, ("greedy", "greedy"), 0, {"warm": 6, "candidates": False}),              # <1,4>: between two generations
+    # ragged last tiles (n % 64 != 0), greedy vs greedy, TERMINATE mode: no valid board needs a masked-random pick, so the lanes
+    # past the end take the kernel's cheap path (they must still play a legal move and stay out of every tally)
+    (4099 + 37, 9, ("greedy", "greedy"), 0, {"illegal": "terminate", "launches": 2}),
+    (70001, 4, ("greedy", "greedy"), 0, {"illegal": "terminate", "candidates": False, "layout": "tile"}),
 ])
 def test_policy_collect_vs_oracle(G, n, T, policies, opening, kw):
     seen, _ = run_and_check(G, n, T, policies, opening, **kw)
