@@ -59,8 +59,15 @@ ALGO_BYTES_COLLECT_PLY, ALGO_BYTES_COLLECT_PLY_MASK_ONLY, ALGO_BYTES_COLLECT_LAU
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; max shader clock (MI355X_MICROARCH.md)
 TOTAL_BOARDS = 1 << 20
-COLLECT_KERNELS = {0: "k_collect", 1: "k_collect (plain stores)", 2: "k_collect2", 3: "k_collect_small<4 lanes/board>",
-                   4: "k_collect_small<2 lanes/board>", 5: "k_collect_small<1 lane/board>"}  # gbl_collect_variant()
+COLLECT_KERNELS = {0: "k_collect", 1: "k_collect (plain stores)", 2: "k_collect2"}  # gbl_collect_variant()
+
+
+def collect_kernel_name(variant):
+    """The kernel a gbl_collect_variant() code stands for (>= 1000: the role kernel's form, GBL_COLLECT_ROLES(la, ko, merge))."""
+    if variant >= 1000:
+        la, ko, merge = (variant - 1000) // 100, (variant - 1000) // 10 % 10, variant % 10
+        return f"k_collect_small<{la} lanes/board, {ko} obs waves{', merged' if merge else ''}>"
+    return COLLECT_KERNELS.get(variant, "k_collect?")
 
 # The sub-records of an N = 1 run: name -> (boards, timed plies, MASK_ONLY, mode).  tests/test_gpu_bench_kernels.py compares
 # the kernel instantiation each one times with the oracle, at the same batch size and through the same entry point.
@@ -296,7 +303,7 @@ class Pipeline:
         achieved = total_bytes / kernel_s / 1e9
         # which form of the kernel the library runs for this shape: asked of the library, not re-derived here
         variant = self.lib.gbl_collect_variant(self.boards, self.T, 1, 0 if self.no_obs else 1)
-        collect = COLLECT_KERNELS.get(variant, "k_collect?")
+        collect = collect_kernel_name(variant)
         name = {"step": "k_step", "fused": "k_rollout (plies=1)", "collect": f"{collect} ({self.T} plies per launch)"}[self.mode]
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
@@ -414,7 +421,7 @@ def step_reply_run(G, torch, dev, boards, K, W):
     kern = a.elapsed_time(b) / 1e3 / D
     evs = [None] * D
     per_launch = (2 * ALGO_BYTES_COLLECT_PLY + ALGO_BYTES_COLLECT_LAUNCH + 4) * boards
-    variant = COLLECT_KERNELS[L.gbl_collect_variant(boards, 2, 1, 1)]
+    variant = collect_kernel_name(L.gbl_collect_variant(boards, 2, 1, 1))
     return {"workload": f"{boards} boards x 1 GPU, an external policy's ply (stand-in: gbl_sample on the last mask slot) + the "
                         f"masked-random reply per launch (gbl_collect_from, 2 plies per launch), auto-reset, FULL outputs every ply, "
                         f"{2 * D} plies as one hipGraph",

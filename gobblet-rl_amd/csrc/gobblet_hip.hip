@@ -85,22 +85,26 @@ inline int nt_policy(int64_t n)
 // stores.  A pure function of the call's shape (and of the -D macros of an A/B build).
 constexpr int64_t kCollect2MaxTiles = 2048;  // 8 workgroups per CU (110 VGPRs: 4 wavefronts per SIMD); 4096 tiles would need two batches: 7.45 -> 7.81 us per ply
 
-// Batches up to this many boards run k_collect_small with four lanes per board (sub-tiles of 16 boards, see there).  Measured
-// against k_collect2, us per ply, FULL outputs, 32 plies per launch (scripts/ab_small.sh): 1 024 boards 0.85 vs 1.19, 4 096: 0.87
-// vs 1.20, 8 192: 1.09 vs 1.22, 16 384: 1.43 vs 1.23 (three wavefronts per 16 boards: from there on the redundant game costs more
-// than the idle SIMDs give).  Round 5: the same kernel with two lanes per board (32 boards per wavefront) up to
-// GBL_COLLECT_HALF_MAX boards and with one (a tile per role wavefront) up to GBL_COLLECT_ROLES_MAX, in front of k_collect2.
-#ifndef GBL_COLLECT_SMALL_MAX
-#define GBL_COLLECT_SMALL_MAX 8192
+// Which form of the role kernel (k_collect_small<LA, KO, MERGE>, see there) a batch of n boards runs, as 100 LA + 10 KO + MERGE;
+// 0 = none (k_collect2 / k_collect).  Measured, us per ply, FULL outputs, 32 plies per launch (scripts/ab_roles.sh, round 5):
+// see the table in DESIGN.md 5.2.
+#ifdef GBL_AB_COLLECT_CFG
+int g_ab_collect_cfg = -1;  // A/B builds only: gbl_ab_collect_cfg() picks the form at run time (one library, many forms)
 #endif
-#ifndef GBL_COLLECT_HALF_MAX
-#define GBL_COLLECT_HALF_MAX 16384
+
+inline int small_cfg(int64_t n, bool with_mask, bool with_obs)
+{
+    (void)with_mask;
+#ifdef GBL_AB_COLLECT_CFG
+    if (g_ab_collect_cfg >= 0) return g_ab_collect_cfg;
 #endif
-#ifndef GBL_COLLECT_ROLES_MAX
-#define GBL_COLLECT_ROLES_MAX 65536
+#ifdef GBL_FORCE_COLLECT_SMALL  // A/B builds: 0 = never, else the form
+    return (GBL_FORCE_COLLECT_SMALL);
+#else
+    if (!with_obs) return n <= 65536 ? 111 : 0;  // MASK_ONLY: scalars + mask rows on one wavefront per tile
+    return n <= 4096 ? 410 : n <= 8192 ? 140 : n <= 16384 ? 141 : n <= 40960 ? 121 : 0;
 #endif
-constexpr int64_t kCollectSmallMaxBoards = GBL_COLLECT_SMALL_MAX, kCollectHalfMaxBoards = GBL_COLLECT_HALF_MAX,
-                  kCollectRolesMaxBoards = GBL_COLLECT_ROLES_MAX;
+}
 
 inline int collect_variant(int64_t n, uint32_t plies, bool with_mask, bool with_obs)
 {
@@ -115,13 +119,8 @@ inline int collect_variant(int64_t n, uint32_t plies, bool with_mask, bool with_
 #else
     const bool pair = (n + kTile - 1) / kTile <= kCollect2MaxTiles && nt && (with_mask || with_obs);
 #endif
-#ifdef GBL_FORCE_COLLECT_SMALL  // A/B builds: 0 = never, 4 / 2 / 1 = always, with that many lanes per board
-    const int lpb = (GBL_FORCE_COLLECT_SMALL);
-#else
-    const int lpb = !nt ? 0 : n <= kCollectSmallMaxBoards ? 4 : n <= kCollectHalfMaxBoards ? 2 : n <= kCollectRolesMaxBoards ? 1 : 0;
-#endif
-    return lpb == 4 ? GBL_COLLECT_SMALL : lpb == 2 ? GBL_COLLECT_HALF : lpb == 1 ? GBL_COLLECT_ROLES
-           : pair ? GBL_COLLECT_PAIR : nt ? GBL_COLLECT_STREAM : GBL_COLLECT_CACHED;
+    const int cfg = nt ? small_cfg(n, with_mask, with_obs) : 0;
+    return cfg ? GBL_COLLECT_ROLES(cfg / 100, (cfg / 10) % 10, cfg % 10) : pair ? GBL_COLLECT_PAIR : nt ? GBL_COLLECT_STREAM : GBL_COLLECT_CACHED;
 }
 
 // LDS words for a tile image of ROWB-byte rows (+ slack for row_load's look-ahead dword)
@@ -818,37 +817,36 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
     }
 }
 
-// gbl_collect for batches that do NOT fill the chip: a SUB-TILE of 64 / LPB boards per wavefront, LPB lanes per board, and the game
-// played REDUNDANTLY wherever that saves a hand-over.  At 4 096 boards k_collect2's 64 workgroups leave three CUs in four idle
-// and a ply lasts as long as its playing wavefront's serial path; a lone wavefront issues one instruction per 5-7 cycles
-// whatever it is, so what counts is the number of instructions ONE wavefront executes per ply.  The game itself -- sample,
-// move, winner, auto-reset, next legal mask: the CHAIN, ~250 instructions, every one depending on the ply before -- cannot be
-// dealt out (0.72 us per ply with nothing stored, scripts/ab_floor.sh); everything else can.  A workgroup is a sub-tile and up
-// to three wavefronts that share NOTHING: each loads the sub-tile, each plays every ply (the LPB lanes of a board alike), and each
-// materialises one share of the outputs, 1 / LPB of a row per lane --
-//   role 0: the five scalars of a ply, the tallies, and at the end the state (the only role that patches a state image);
-//   role 1: the mask rows (lane j: bytes [64 j / LPB, 64 (j + 1) / LPB) of its board's row);
-//   role 2: the observation rows (lane j: channels j, j + LPB, ...).
+// gbl_collect for batches that do NOT fill the chip: ROLE wavefronts that share NOTHING, and the game played REDUNDANTLY wherever
+// that saves a hand-over.  At 4 096 boards k_collect2's 64 workgroups leave three CUs in four idle and a ply lasts as long as
+// its playing wavefront's serial path; a lone wavefront issues one instruction per 5-7 cycles whatever it is, so what counts is
+// the number of instructions ONE wavefront executes per ply.  The game itself -- sample, move, winner, auto-reset, next legal
+// mask: the CHAIN, ~250 instructions, every one depending on the ply before -- cannot be dealt out (0.72 us per ply with nothing
+// stored, scripts/ab_floor.sh); everything else can.  A role wavefront loads a SUB-TILE of 64 / LPB boards (LPB lanes per board,
+// all playing alike), plays every ply, and materialises one share of the outputs, 1 / LPB of a row per lane --
+//   scalars: the five scalars of a ply, the tallies, and at the end the state (the only role that patches a state image);
+//   mask:    the mask rows (lane j: bytes [64 j / LPB, 64 (j + 1) / LPB) of its board's row);
+//   obs:     the observation rows (lane j: channels j, j + LPB, ...).
 // No LDS hand-over, no cross-lane instruction; the redundant arithmetic runs on SIMDs that would idle.  A role's image of ply t
 // is read back into registers at the end of its iteration and stored in the NEXT one, behind the sample and the move: the LDS
 // round trip is off the chain.  Bit for bit the trajectories of k_collect (same sampler keys, same arithmetic).
-//   LPB = 4 (16 boards per wavefront): up to 8 192 boards (round 4);
-//   LPB = 2 (32 boards) and LPB = 1 (a whole tile per role wavefront): the batches between that and the HBM regime (round 5) --
-//       where k_collect2's ONE playing wavefront per tile carried the chain AND both row builders (1.23 - 1.87 us per ply at
-//       16 384 - 65 536 boards against 0.37 - 1.46 of HBM time).
-// cell of sub-tile s at ply t: t * ply_stride + (s / LPB) * tile_stride + (s % LPB) * (64 / LPB)  (both layouts of gbl_collect).
-// ONE barrier per launch (not per ply): the roles read the sub-tile's state, movers and first actions on their own and role 0
-// overwrites them at the end -- the rendezvous behind the loads keeps a late role from reading what an early role 0 wrote back
-// (with one ply per launch role 0 reaches its write-back after ~300 instructions).
+//
+// What a role costs a lone wavefront per ply (round 5, scripts/ab_roles.sh): the chain 0.72 us, + scalars ~0.05, + mask rows ~0.10
+// whatever LPB, + observation rows 0.15 / 0.30 / 0.58 at 16 / 32 / 64 boards per wavefront: the observation role is the long one,
+// and it alone gains from more lanes per board.  So a WORKGROUP is a group of 64 / LA boards with
+//   one scalars wavefront (which also builds the mask rows when MERGE) and, unless MERGE, one mask wavefront, LA lanes per board,
+//   KO observation wavefronts of LA * KO lanes per board, each over 1 / KO of the group,
+// <LA, KO, MERGE> chosen by the batch size (collect_variant): every redundant chain is SIMD time that saturated SIMDs do not have.
+// cell of sub-tile s (LPB lanes per board) at ply t: t * ply_stride + (s / LPB) * tile_stride + (s % LPB) * (64 / LPB).
+// ONE barrier per launch (not per ply): the roles read the group's state, movers and first actions on their own and the scalars
+// role overwrites them at the end -- the rendezvous behind the loads keeps a late role from reading what an early one wrote back
+// (with one ply per launch the scalars role reaches its write-back after ~300 instructions).
 struct NoRow {  // the state image of a wavefront that does not write the state back is never patched
     __device__ __forceinline__ void apply(const MoveCells &) const {}
     __device__ __forceinline__ void reset() const {}
 };
 
-constexpr int kRoleScalars = 0, kRoleMask = 1, kRoleObs = 2;
-
-template <bool WITH_MASK, bool WITH_OBS>
-constexpr int small_roles() { return 1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0); }
+constexpr int kRoleScalars = 1, kRoleMask = 2, kRoleObs = 4;  // (bits: a wavefront may hold several roles)
 
 struct SmallArgs {
     int8_t *state, *to_move, *done;
@@ -872,11 +870,18 @@ __device__ __forceinline__ void sub_out_ragged(int8_t *__restrict__ g, const uin
 }
 
 template <int ROLE, int LPB, bool SYNC>
-__device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, uint32_t *out_img, int64_t sub)
+__device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, uint32_t *mask_img, uint32_t *obs_img, int64_t sub)
 {
     constexpr int BPS = kTile / LPB, SH = LPB == 4 ? 2 : LPB == 2 ? 1 : 0;
+    constexpr bool SC = (ROLE & kRoleScalars) != 0, MK = (ROLE & kRoleMask) != 0, OB = (ROLE & kRoleObs) != 0;
     const int lane = (int)(threadIdx.x & 63u), bq = lane >> SH, j = lane & (LPB - 1);
     const int64_t left = A.n - sub * BPS;
+    if (left <= 0) {  // (an observation wavefront whose share of a ragged last group is empty: it still meets the others once)
+#ifndef GBL_HOST_EMU
+        if (SYNC) __syncthreads();
+#endif
+        return;
+    }
     const int rows = left < BPS ? (int)left : BPS;
     const bool valid = bq < rows, full = rows == BPS;
     const int64_t b = sub * BPS + bq, bs = valid ? b : A.n - 1;
@@ -890,7 +895,7 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
     r[6] &= 0x00FFFFFFu;
     if (SYNC) {
 #ifndef GBL_HOST_EMU
-        // every role's loads of the sub-tile have landed before role 0 may write anything back (waits vmcnt(0) + lgkmcnt(0))
+        // every role's loads of the group have landed before the scalars role may write anything back (waits vmcnt(0) + lgkmcnt(0))
         asm volatile("" : "+v"(mover), "+v"(given));
         __syncthreads();
 #endif
@@ -904,10 +909,11 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
     int dn = 0, tcount = 0;
     bool treset = false;
     uint64_t legal = legal54(p, mover);
-    constexpr int kRowB = ROLE == kRoleObs ? kObs : kActions;
     constexpr int kRowPolicy = kStoreStreamDrop;  // trajectory slots are written once: streamed
-    SubVecs<sub_vectors<kRowB, BPS>()> v{};  // the image of the previous ply, on its way out
-    int8_t *vdst = nullptr;
+    // the images of the previous ply, on their way out
+    SubVecs<MK ? sub_vectors<kActions, BPS>() : 0> vm{};
+    SubVecs<OB ? sub_vectors<kObs, BPS>() : 0> vo{};
+    int8_t *mdst = nullptr, *odst = nullptr;
     const uint32_t plies = A.plies;
     const int64_t cell0 = (sub >> SH) * A.tile_stride + (sub & (LPB - 1)) * BPS;
     for (uint32_t t = 0; t < plies; ++t) {
@@ -915,7 +921,7 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
         int action = pick54(legal, draw_word(block, ply));
         if (A.first_actions && t == 0) action = given;
         if (t + 1 < plies && ((ply + 1) & 3u) == 0) block = draw_block(A.seed, A.env_base + (uint64_t)b, ply + 1);
-        if (ROLE == kRoleScalars)
+        if (SC)
             y = play_ply(p, row, mover, legal, action, A.illegal_mode);
         else
             y = play_ply(p, NoRow{}, mover, legal, action, A.illegal_mode);
@@ -923,13 +929,14 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
         if (y.terminal) {  // raw_env.reset, gobblet.py:275-290
             p = Planes{0u, 0u, 0u};
             mover = 0;
-            if (ROLE == kRoleScalars) row.reset();
+            if (SC) row.reset();
         }
         const int64_t cell = (int64_t)t * A.ply_stride + cell0;
-        if constexpr (ROLE != kRoleScalars) {
-            if (t && full) sub_store<kRowB, kRowPolicy, BPS>(vdst, v, lane);  // ply t - 1's rows
+        if (t && full) {  // ply t - 1's rows
+            if constexpr (OB) sub_store<kObs, kRowPolicy, BPS>(odst, vo, lane);
+            if constexpr (MK) sub_store<kActions, kRowPolicy, BPS>(mdst, vm, lane);
         }
-        if (ROLE == kRoleScalars) {
+        if constexpr (SC) {
             tcount = next_turn(tcount, y, 1);
             treset = treset || y.terminal;
             if (A.counters) {  // (one lane per board counts)
@@ -968,82 +975,89 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
                 }
             }
         }
-        if constexpr (ROLE == kRoleObs) {
-            sub_obs_zero<BPS>(out_img, lane);
+        if constexpr (OB) {
+            sub_obs_zero<BPS>(obs_img, lane);
             wave_lds_fence();
-            obs_scatter_part<LPB>(reinterpret_cast<uint8_t *>(out_img) + bq * kObs, p, mover, j);
+            obs_scatter_part<LPB>(reinterpret_cast<uint8_t *>(obs_img) + bq * kObs, p, mover, j);
             wave_lds_fence();
-            vdst = A.obs_t + cell * kObs;
-            if (full) sub_fetch<kObs, BPS>(out_img, lane, v);
-            else sub_out_ragged(vdst, out_img, lane, rows * kObs);
+            odst = A.obs_t + cell * kObs;
+            if (full) sub_fetch<kObs, BPS>(obs_img, lane, vo);
+            else sub_out_ragged(odst, obs_img, lane, rows * kObs);
             wave_lds_fence();
         }
         legal = legal54(p, mover);  // the next mover's: stored now, sampled from next ply
-        if constexpr (ROLE == kRoleMask) {
-            mask_row_part<LPB>(reinterpret_cast<uint8_t *>(out_img) + bq * kActions, legal, j);
+        if constexpr (MK) {
+            mask_row_part<LPB>(reinterpret_cast<uint8_t *>(mask_img) + bq * kActions, legal, j);
             wave_lds_fence();
-            vdst = A.mask_t + cell * kActions;
-            if (full) sub_fetch<kActions, BPS>(out_img, lane, v);
-            else sub_out_ragged(vdst, out_img, lane, rows * kActions);
+            mdst = A.mask_t + cell * kActions;
+            if (full) sub_fetch<kActions, BPS>(mask_img, lane, vm);
+            else sub_out_ragged(mdst, mask_img, lane, rows * kActions);
             wave_lds_fence();
         }
     }
-    if constexpr (ROLE != kRoleScalars) {
-        if (full) sub_store<kRowB, kRowPolicy, BPS>(vdst, v, lane);  // the last ply's rows
-        return;
-    } else {
-    wave_lds_fence();  // every board's byte patches are in the state image
-    sub_out<kCells, kStorePlain, BPS>(A.state + sub * (BPS * kCells), img, lane, rows);
-    if (valid && j == 0) {
-        A.to_move[b] = (int8_t)mover;
-        A.done[b] = (int8_t)dn;
-        if (A.turn) A.turn[b] = treset ? tcount : A.turn[b] + tcount;
+    if (full) {  // the last ply's rows
+        if constexpr (OB) sub_store<kObs, kRowPolicy, BPS>(odst, vo, lane);
+        if constexpr (MK) sub_store<kActions, kRowPolicy, BPS>(mdst, vm, lane);
     }
-    if (A.counters && lane == 0) {
-        unsigned long long *c = reinterpret_cast<unsigned long long *>(A.counters) +
-                                (size_t)((sub >> SH) % GBL_COUNTER_STRIPES) * GBL_COUNTER_STRIDE;
-        atomicAdd(c + 0, (unsigned long long)rows * plies);
-        if (games) atomicAdd(c + 1, (unsigned long long)games);
-        if (w1) atomicAdd(c + 2, (unsigned long long)w1);
-        if (w2) atomicAdd(c + 3, (unsigned long long)w2);
-    }
+    if constexpr (SC) {
+        wave_lds_fence();  // every board's byte patches are in the state image
+        sub_out<kCells, kStorePlain, BPS>(A.state + sub * (BPS * kCells), img, lane, rows);
+        if (valid && j == 0) {
+            A.to_move[b] = (int8_t)mover;
+            A.done[b] = (int8_t)dn;
+            if (A.turn) A.turn[b] = treset ? tcount : A.turn[b] + tcount;
+        }
+        if (A.counters && lane == 0) {
+            unsigned long long *c = reinterpret_cast<unsigned long long *>(A.counters) +
+                                    (size_t)((sub >> SH) % GBL_COUNTER_STRIPES) * GBL_COUNTER_STRIDE;
+            atomicAdd(c + 0, (unsigned long long)rows * plies);
+            if (games) atomicAdd(c + 1, (unsigned long long)games);
+            if (w1) atomicAdd(c + 2, (unsigned long long)w1);
+            if (w2) atomicAdd(c + 3, (unsigned long long)w2);
+        }
     }
 }
+
+// wavefronts of a workgroup of the role kernel: the scalars wavefront, the mask wavefront unless merged, KO observation wavefronts
+template <bool WITH_MASK, bool WITH_OBS, int KO, bool MERGE>
+constexpr int small_waves() { return 1 + ((WITH_MASK && !MERGE) ? 1 : 0) + (WITH_OBS ? KO : 0); }
 
 // (The one-ply entry points -- gbl_rollout with plies = 1, gbl_step -- were routed here too and gained nothing: 3.34-3.47 us per
 // launch against k_rollout's 3.29-3.36 at 1 024 - 4 096 boards, scripts/ab_ply.sh: a one-ply launch is its tile load, the chain
 // and the launch boundary, none of which a smaller tile shortens.  They stay on k_rollout / k_step.)
-template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY, int LPB>
-__global__ __launch_bounds__((64 * small_roles<WITH_MASK, WITH_OBS>())) void k_collect_small(
-    int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n, int64_t nsub, uint64_t seed, uint64_t env_base,
+template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY, int LA, int KO, bool MERGE>
+__global__ __launch_bounds__((64 * small_waves<WITH_MASK, WITH_OBS, KO, MERGE>())) void k_collect_small(
+    int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n, int64_t ngroups, uint64_t seed, uint64_t env_base,
     const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies, int8_t *__restrict__ done, int64_t ply_stride,
     int64_t tile_stride, int32_t *__restrict__ actions_t, int8_t *__restrict__ winner_t, int8_t *__restrict__ reward_t,
     int8_t *__restrict__ done_t, int8_t *__restrict__ to_move_t, int8_t *__restrict__ mask_t, int8_t *__restrict__ obs_t,
     int illegal_mode, int64_t *__restrict__ counters, int32_t *__restrict__ turn, const int32_t *__restrict__ first_actions)
 {
-    constexpr int ROLES = small_roles<WITH_MASK, WITH_OBS>(), BPS = kTile / LPB;
-    constexpr int kStateWords = BPS * kCells / 4 + 4, kObsWords = BPS * kObs / 4 + 4, kMaskWords = BPS * kActions / 4 + 4;
-    __shared__ uint32_t s_state[ROLES][kStateWords];
-    __shared__ uint32_t s_obs[WITH_OBS ? kObsWords : 4];
+    static_assert(LA * KO <= 4, "at most four lanes per board");
+    constexpr int WAVES = small_waves<WITH_MASK, WITH_OBS, KO, MERGE>(), NA = WAVES - (WITH_OBS ? KO : 0);
+    constexpr int GB = kTile / LA, LO = LA * KO, OBB = kTile / LO;  // boards per group; observation wavefronts: LO lanes per board, OBB boards
+    constexpr int kStateWords = GB * kCells / 4 + 4, kObsWords = OBB * kObs / 4 + 4, kMaskWords = GB * kActions / 4 + 4;
+    __shared__ uint32_t s_state[WAVES][kStateWords];
+    __shared__ uint32_t s_obs[WITH_OBS ? KO : 1][WITH_OBS ? kObsWords : 4];
     __shared__ uint32_t s_mask[WITH_MASK ? kMaskWords : 4];
     if (DEV_PLY) ply0 += *ply_dev;
-    const int64_t sub = (int64_t)blockIdx.x;
-    if (sub >= nsub) return;
-    const int wave = ROLES > 1 ? wave_index() : 0;
+    const int64_t group = (int64_t)blockIdx.x;
+    if (group >= ngroups) return;
+    const int wave = WAVES > 1 ? wave_index() : 0;
     const SmallArgs A{state, to_move, done, n, seed, env_base, ply0, plies, ply_stride, tile_stride, actions_t, winner_t, reward_t,
                       done_t, to_move_t, mask_t, obs_t, illegal_mode, counters, turn, first_actions};
-    constexpr bool SYNC = ROLES > 1;
+    constexpr bool SYNC = WAVES > 1;
     if (wave == 0) {
-        small_role<kRoleScalars, LPB, SYNC>(A, s_state[0], nullptr, sub);
+        small_role<kRoleScalars | ((WITH_MASK && MERGE) ? kRoleMask : 0), LA, SYNC>(A, s_state[0], s_mask, nullptr, group);
         return;
     }
-    if constexpr (WITH_MASK) {
+    if constexpr (WITH_MASK && !MERGE) {
         if (wave == 1) {
-            small_role<kRoleMask, LPB, SYNC>(A, s_state[1], s_mask, sub);
+            small_role<kRoleMask, LA, SYNC>(A, s_state[1], s_mask, nullptr, group);
             return;
         }
     }
-    if constexpr (WITH_OBS) small_role<kRoleObs, LPB, SYNC>(A, s_state[ROLES - 1], s_obs, sub);
+    if constexpr (WITH_OBS) small_role<kRoleObs, LO, SYNC>(A, s_state[wave], nullptr, s_obs[wave - NA], group * KO + (wave - NA));
 }
 
 // gbl_placement_probe: the write pattern of k_collect without the game -- tile i of `plies` slots stores 64 rows of
@@ -1748,31 +1762,48 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
     }
 }
 
-// k_collect_small for a checked call (see gbl_collect_from); lpb = lanes per board (4 / 2 / 1: collect_variant)
-void launch_small(int lpb, int8_t *state, int8_t *to_move, int8_t *done, const int32_t *first_actions, int32_t *actions_t, int8_t *winner_t,
+// k_collect_small for a checked call (see gbl_collect_from); cfg = 100 LA + 10 KO + MERGE (collect_variant)
+// (the product build instantiates the forms collect_variant() can return; an A/B build -- GBL_AB_COLLECT_CFG -- a whole menu)
+bool launch_small(int cfg, int8_t *state, int8_t *to_move, int8_t *done, const int32_t *first_actions, int32_t *actions_t, int8_t *winner_t,
                   int8_t *reward_t, int8_t *done_t, int8_t *to_move_t, int8_t *mask_t, int8_t *obs_t, int64_t n, int64_t ply_stride,
                   int64_t tile_stride, uint64_t seed, uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev, uint32_t plies,
                   int illegal_mode, int64_t *counters, int32_t *turn, hipStream_t s)
 {
-    const int64_t bps = kTile / lpb, nsub = (n + bps - 1) / bps;
-#define GBL_SMALL_K(M, O, D, L)                                                                                               \
-    hipLaunchKernelGGL((k_collect_small<M, O, D, L>), dim3((uint32_t)nsub), dim3(64 * small_roles<M, O>()), 0, s, state, \
-                       to_move, n, nsub, seed, env_base, ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_t, winner_t,   \
-                       reward_t, done_t, to_move_t, mask_t, obs_t, illegal_mode, counters, turn, first_actions)
-#define GBL_SMALL_L(M, O, D)                                    \
-    if (lpb == 4) { GBL_SMALL_K(M, O, D, 4); }                  \
-    else if (lpb == 2) { GBL_SMALL_K(M, O, D, 2); }             \
-    else { GBL_SMALL_K(M, O, D, 1); }
-#define GBL_SMALL_D(M, O)                                       \
-    if (ply_dev) { GBL_SMALL_L(M, O, true); }                   \
-    else { GBL_SMALL_L(M, O, false); }
-    if (mask_t && obs_t) { GBL_SMALL_D(true, true); }
-    else if (mask_t) { GBL_SMALL_D(true, false); }
-    else if (obs_t) { GBL_SMALL_D(false, true); }
-    else { GBL_SMALL_D(false, false); }
+    const int la = cfg / 100;
+    const int64_t gb = kTile / la, ngroups = (n + gb - 1) / gb;
+#define GBL_SMALL_K(M, O, D, LA, KO, MG)                                                                                        \
+    hipLaunchKernelGGL((k_collect_small<M, O, D, LA, KO, MG>), dim3((uint32_t)ngroups), dim3(64 * small_waves<M, O, KO, MG>()), 0, s, \
+                       state, to_move, n, ngroups, seed, env_base, ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_t,      \
+                       winner_t, reward_t, done_t, to_move_t, mask_t, obs_t, illegal_mode, counters, turn, first_actions)
+#define GBL_SMALL_D(M, O, LA, KO, MG)                           \
+    if (ply_dev) { GBL_SMALL_K(M, O, true, LA, KO, MG); }       \
+    else { GBL_SMALL_K(M, O, false, LA, KO, MG); }
+#define GBL_SMALL_CFG(LA, KO, MG)                                                                              \
+    if (cfg == 100 * LA + 10 * KO + (MG ? 1 : 0)) {                                                            \
+        if (mask_t && obs_t) { GBL_SMALL_D(true, true, LA, KO, MG); }                                          \
+        else if (mask_t) { GBL_SMALL_D(true, false, LA, KO, MG); }                                             \
+        else if (obs_t) { GBL_SMALL_D(false, true, LA, KO, MG); }                                              \
+        else { GBL_SMALL_D(false, false, LA, KO, MG); }                                                        \
+        return true;                                                                                           \
+    }
+    GBL_SMALL_CFG(4, 1, false)
+    GBL_SMALL_CFG(1, 4, false)
+    GBL_SMALL_CFG(1, 4, true)
+    GBL_SMALL_CFG(1, 2, true)
+    GBL_SMALL_CFG(1, 1, true)
+#ifdef GBL_AB_COLLECT_CFG
+    GBL_SMALL_CFG(2, 1, false)
+    GBL_SMALL_CFG(1, 1, false)
+    GBL_SMALL_CFG(2, 2, false)
+    GBL_SMALL_CFG(2, 2, true)
+    GBL_SMALL_CFG(1, 2, false)
+    GBL_SMALL_CFG(2, 1, true)
+    GBL_SMALL_CFG(4, 1, true)
+#endif
+#undef GBL_SMALL_CFG
 #undef GBL_SMALL_D
-#undef GBL_SMALL_L
 #undef GBL_SMALL_K
+    return false;
 }
 
 int greedy_shape(int depth, int64_t n);  // (defined with the greedy entry points below)
@@ -2144,10 +2175,11 @@ int gbl_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int32_t
     const int variant = collect_variant(n, plies, mask_traj != nullptr, obs_traj != nullptr);
     const bool pair = variant == GBL_COLLECT_PAIR;
     [[maybe_unused]] const bool nt = variant != GBL_COLLECT_CACHED;
-    if (variant == GBL_COLLECT_SMALL || variant == GBL_COLLECT_HALF || variant == GBL_COLLECT_ROLES) {
-        launch_small(variant == GBL_COLLECT_SMALL ? 4 : variant == GBL_COLLECT_HALF ? 2 : 1, state, to_move, done, first_actions, actions_traj, winner_traj, reward_traj, done_traj, to_move_traj,
-                           mask_traj, obs_traj, n, ply_stride, tile_stride, seed, env_base, ply0, ply_dev, plies, illegal_mode,
-                           counters, turn, s);
+    if (GBL_COLLECT_IS_ROLES(variant)) {
+        if (!launch_small(variant - GBL_COLLECT_ROLES(0, 0, 0), state, to_move, done, first_actions, actions_traj, winner_traj, reward_traj,
+                          done_traj, to_move_traj, mask_traj, obs_traj, n, ply_stride, tile_stride, seed, env_base, ply0, ply_dev, plies,
+                          illegal_mode, counters, turn, s))
+            return fail(GBL_ERR_ARG, "gbl_collect: this build has no such form of the role kernel");
         GBL_LAUNCHED("gbl_collect");
     }
 #ifdef GBL_FORCE_COLLECT_NT  // (A/B builds: the plain-store instantiation exists only there)
@@ -2243,6 +2275,14 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
 #undef GBL_CP
     GBL_LAUNCHED("gbl_collect_policy");
 }
+
+#ifdef GBL_AB_COLLECT_CFG
+int gbl_ab_collect_cfg(int cfg)  // (A/B builds only, not part of the ABI: -1 = the library's own choice)
+{
+    g_ab_collect_cfg = cfg;
+    return GBL_OK;
+}
+#endif
 
 int gbl_collect_variant(int64_t n, uint32_t plies, int with_mask, int with_obs)
 {

@@ -305,18 +305,17 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
  *   GBL_COLLECT_STREAM  k_collect,  one wavefront per tile of 64 boards, trajectory rows stored non-temporally
  *   GBL_COLLECT_CACHED  k_collect with plain stores (does not exist in the product build: A/B builds only)
  *   GBL_COLLECT_PAIR    k_collect2, two wavefronts per tile (one plays, one stores): grids of up to 2048 tiles
- *   GBL_COLLECT_SMALL   k_collect_small, 16 boards per wavefront and four lanes per board, the game played redundantly by
- *                       the wavefront that stores the observation rows and the one that stores the mask rows and scalars:
- *                       small batches (a few thousand boards), whose launch lasts as long as one wavefront's serial path
- *   GBL_COLLECT_HALF    the same with 32 boards per wavefront, two lanes per board
- *   GBL_COLLECT_ROLES   the same with a whole tile of 64 boards per wavefront, one lane per board: up to three role
- *                       wavefronts per tile that share nothing (batches between GBL_COLLECT_HALF and the HBM-bound regime) */
+ *   GBL_COLLECT_ROLES(la, ko, merge) = 1000 + 100 la + 10 ko + merge:  k_collect_small<la, ko, merge> -- batches that do
+ *                       not fill the chip, whose launch lasts as long as ONE wavefront's serial path: role wavefronts that
+ *                       share nothing, each playing the whole game and materialising one share of the outputs.  A workgroup
+ *                       is a group of 64 / la boards: one scalars wavefront (which also builds the mask rows when merge = 1),
+ *                       unless merged one mask wavefront, both with la lanes per board, and ko observation wavefronts of
+ *                       la * ko lanes per board over 1 / ko of the group each.  Round 4's small-batch kernel is (4, 1, 0). */
 #define GBL_COLLECT_STREAM 0
 #define GBL_COLLECT_CACHED 1
 #define GBL_COLLECT_PAIR 2
-#define GBL_COLLECT_SMALL 3
-#define GBL_COLLECT_HALF 4
-#define GBL_COLLECT_ROLES 5
+#define GBL_COLLECT_ROLES(la, ko, merge) (1000 + 100 * (la) + 10 * (ko) + (merge))
+#define GBL_COLLECT_IS_ROLES(variant) ((variant) >= 1000)
 int gbl_collect_variant(int64_t n, uint32_t plies, int with_mask, int with_obs);
 /* gbl_collect whose FIRST ply plays caller-supplied actions (first_actions int32[n]; NULL = gbl_collect): the collector
  * step of a policy that lives outside the library against masked-random replies -- the loops of the reference's trainers
