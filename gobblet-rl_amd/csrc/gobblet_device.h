@@ -508,12 +508,14 @@ __device__ __forceinline__ Planes make_planes(const uint32_t (&r)[7])
 // early exit, so the matching line with the HIGHEST index decides; one line
 // cannot match both colours, so comparing the two 8-bit match masks as
 // integers picks that line's colour.
-__device__ __forceinline__ int winner_of(const Planes &p)
+//
+// line_matches: the 8-bit mask of the lines (bit l = line l of board.py:135-153) on which every top piece is `colour`'s
+// (0 = player_1).  side = the colour's cells (nz & ~neg / nz & neg), passed in so that a caller whose lanes split the two colours
+// selects it with one operation.
+__device__ __forceinline__ uint32_t line_matches_of(uint32_t side, uint32_t nz)
 {
-    uint32_t pos = p.nz & ~p.neg, ngv = p.nz & p.neg;
-    uint32_t o1 = (p.nz >> 9) & 0x1FFu, o2 = (p.nz >> 18) & 0x1FFu;
-    uint32_t t1 = ((pos >> 18) & 0x1FFu) | (~o2 & (((pos >> 9) & 0x1FFu) | (~o1 & (pos & 0x1FFu))));
-    uint32_t t2 = ((ngv >> 18) & 0x1FFu) | (~o2 & (((ngv >> 9) & 0x1FFu) | (~o1 & (ngv & 0x1FFu))));
+    uint32_t o1 = (nz >> 9) & 0x1FFu, o2 = (nz >> 18) & 0x1FFu;
+    uint32_t t = ((side >> 18) & 0x1FFu) | (~o2 & (((side >> 9) & 0x1FFu) | (~o1 & (side & 0x1FFu))));  // the colour's tops
     // board.py:135-153: (0,1,2) (3,4,5) (6,7,8) (0,3,6) (1,4,7) (2,5,8) (0,4,8) (2,4,6).
     // Three lines per word in 10-bit fields (bit 9 = guard): adding 0x1FF to "squares of the line the
     // side lacks" carries into the guard iff something is missing.  Lines (0,3,6) / (1,4,7) / (2,5) share
@@ -522,12 +524,34 @@ __device__ __forceinline__ int winner_of(const Planes &p)
     constexpr uint32_t LOW3 = 0x00100401u, G3 = LOW3 << 9, F3 = LOW3 * 0x1FFu;
     constexpr uint32_t WA = L[0] | (L[3] << 10) | (L[6] << 20), WB = L[1] | (L[4] << 10) | (L[7] << 20);
     constexpr uint32_t WC = L[2] | (L[5] << 10), NONE = 1u << 20;  // third field of WC: always "missing"
-    uint32_t n1 = ~(t1 | (t1 << 10) | (t1 << 20)), n2 = ~(t2 | (t2 << 10) | (t2 << 20));
-    uint32_t m1 = ((G3 & ~((WA & n1) + F3)) >> 9) | ((G3 & ~((WB & n1) + F3)) >> 8) |
-                  ((G3 & ~(((WC & n1) | NONE) + F3)) >> 7);
-    uint32_t m2 = ((G3 & ~((WA & n2) + F3)) >> 9) | ((G3 & ~((WB & n2) + F3)) >> 8) |
-                  ((G3 & ~(((WC & n2) | NONE) + F3)) >> 7);
-    return m2 > m1 ? -1 : (m1 > m2 ? 1 : 0);
+    uint32_t n = ~(t | (t << 10) | (t << 20));
+    return ((G3 & ~((WA & n) + F3)) >> 9) | ((G3 & ~((WB & n) + F3)) >> 8) | ((G3 & ~(((WC & n) | NONE) + F3)) >> 7);
+}
+
+__device__ __forceinline__ int winner_from_matches(uint32_t m1, uint32_t m2) { return m2 > m1 ? -1 : (m1 > m2 ? 1 : 0); }
+
+__device__ __forceinline__ int winner_of(const Planes &p)
+{
+    return winner_from_matches(line_matches_of(p.nz & ~p.neg, p.nz), line_matches_of(p.nz & p.neg, p.nz));
+}
+
+// winner_of for kernels whose lanes come in PAIRS that hold the same board (the role kernels with two or four lanes per board):
+// the even lane of a pair walks player_1's lines, the odd lane player_2's, and one DPP quad permutation ([1, 0, 3, 2]) hands
+// each the other's match mask -- half the line arithmetic per lane (~28 instead of ~48 instructions on the ply's serial chain).
+// j = the lane's index among its board's lanes (only its parity is used).  The host emulation, whose lanes run one after the
+// other, computes both masks itself: the same function of the same board.
+__device__ __forceinline__ int winner_of_pair(const Planes &p, int j)
+{
+#ifndef GBL_HOST_EMU
+    const uint32_t flip = (j & 1) ? 0u : ~0u;                                     // (a per-lane constant)
+    const uint32_t mine = line_matches_of(p.nz & (p.neg ^ flip), p.nz);           // colour j & 1
+    const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]
+    const int w = mine > theirs ? 1 : (theirs > mine ? -1 : 0);                   // seen from colour j & 1
+    return (j & 1) ? -w : w;
+#else
+    (void)j;
+    return winner_of(p);
+#endif
 }
 
 // 54-bit legal mask of agent `mover` (0 / 1): raw_env._legal_moves,
@@ -885,12 +909,15 @@ struct Ply {
     bool stepped;   // raw_env.step ran, i.e. the reference did `self.turn += 1` (gobblet.py:270)
 };
 
-template <typename Row>
-__device__ __forceinline__ Ply play_ply(Planes &p, Row row, int &mover, uint64_t legal, int action, int illegal_mode)
+// TRUSTED: the action comes from pick54 on `legal` itself (the masked-random sampler inside a T-plies-per-launch kernel): it is
+// legal by construction, or -1 where a board has no legal move at all (none in the game: only outside the state contract) -- the
+// legality test and the illegal-action branch leave the ply's serial chain.  PAIR > 0: winner_of_pair with j = pair_j.
+template <bool TRUSTED = false, bool PAIR = false, typename Row>
+__device__ __forceinline__ Ply play_ply(Planes &p, Row row, int &mover, uint64_t legal, int action, int illegal_mode, int pair_j = 0)
 {
     Ply y{0, 0, 0, false, false};
-    bool ok = (uint32_t)action < (uint32_t)kActions && ((legal >> (action & 63)) & 1ull);
-    if (!ok && illegal_mode == kIllegalTerminate) {
+    bool ok = TRUSTED ? action >= 0 : ((uint32_t)action < (uint32_t)kActions && ((legal >> (action & 63)) & 1ull));
+    if (!TRUSTED && !ok && illegal_mode == kIllegalTerminate) {
         // gobblet.py:50-51, :114: mover -1, the other 0, everyone terminated, board untouched
         y.r0 = mover ? 0 : -1;
         y.r1 = mover ? -1 : 0;
@@ -900,7 +927,7 @@ __device__ __forceinline__ Ply play_ply(Planes &p, Row row, int &mover, uint64_t
     y.stepped = true;
     if (ok) row.apply(move_planes(p, mover, (uint32_t)action));  // gobblet.py:244 (illegal: silent no-op, board.py:125-126)
     mover ^= 1;                                          // gobblet.py:246,267
-    y.winner = winner_of(p);                             // gobblet.py:248-249
+    y.winner = PAIR ? winner_of_pair(p, pair_j) : winner_of(p);  // gobblet.py:248-249
     y.r0 = y.winner;                                     // gobblet.py:253-260
     y.r1 = -y.winner;
     y.terminal = y.winner != 0;                          // gobblet.py:263

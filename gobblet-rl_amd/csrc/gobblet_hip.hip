@@ -870,7 +870,8 @@ __device__ __forceinline__ void sub_out_ragged(int8_t *__restrict__ g, const uin
 }
 
 template <int ROLE, int LPB, bool SYNC>
-__device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, uint32_t *mask_img, uint32_t *obs_img, int64_t sub)
+__device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, uint32_t *mask_img, uint32_t *obs_img, uint32_t *draw_buf,
+                                           int64_t sub)
 {
     constexpr int BPS = kTile / LPB, SH = LPB == 4 ? 2 : LPB == 2 ? 1 : 0;
     constexpr bool SC = (ROLE & kRoleScalars) != 0, MK = (ROLE & kRoleMask) != 0, OB = (ROLE & kRoleObs) != 0;
@@ -887,12 +888,26 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
     const int64_t b = sub * BPS + bq, bs = valid ? b : A.n - 1;
     int mover = A.to_move[bs];
     int given = A.first_actions ? A.first_actions[bs] : 0;  // (gbl_collect_from: the first ply plays the caller's actions)
+    // The sampler's words.  One lane per board: a generator block per four plies, in registers, as k_collect.  LPB lanes per board:
+    // the generator leaves the ply's serial chain -- lane j of a board generates block (base + j), the words of 4 LPB plies go
+    // through LDS (16 bytes per lane), and a ply reads its word back one ply ahead: ~5 instead of ~30 instructions per ply.
     Draw4 block{{0u, 0u, 0u, 0u}};
-    sub_in<kCells, BPS>(A.state + sub * (BPS * kCells), img, lane, rows, [&] { block = draw_block(A.seed, A.env_base + (uint64_t)b, A.ply0); });
+    uint32_t base = A.ply0 >> 2;                            // the first generator block in draw_buf (wave-uniform)
+    const uint32_t *const my_draws = draw_buf + (lane & ~(LPB - 1)) * 4;
+    auto refill = [&](uint32_t blk) {                       // blocks blk .. blk + LPB - 1 of this wavefront's boards -> draw_buf
+        const Draw4 d = draw_block(A.seed, A.env_base + (uint64_t)b, (blk + (uint32_t)j) << 2);
+        reinterpret_cast<uint4 *>(draw_buf)[lane] = uint4{d.w[0], d.w[1], d.w[2], d.w[3]};
+    };
+    sub_in<kCells, BPS>(A.state + sub * (BPS * kCells), img, lane, rows, [&] {
+        if constexpr (LPB == 1) block = draw_block(A.seed, A.env_base + (uint64_t)b, A.ply0);
+        else refill(base);
+    });
     wave_lds_fence();
     uint32_t r[7];
     row_load<kCells>(img, bq, r);
     r[6] &= 0x00FFFFFFu;
+    uint32_t word = 0;                                      // the current ply's 32 random bits
+    if constexpr (LPB > 1) word = my_draws[A.ply0 & 3u];
     if (SYNC) {
 #ifndef GBL_HOST_EMU
         // every role's loads of the group have landed before the scalars role may write anything back (waits vmcnt(0) + lgkmcnt(0))
@@ -916,15 +931,39 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
     int8_t *mdst = nullptr, *odst = nullptr;
     const uint32_t plies = A.plies;
     const int64_t cell0 = (sub >> SH) * A.tile_stride + (sub & (LPB - 1)) * BPS;
+    constexpr bool PAIR = LPB > 1;  // the lanes of a board split the winner test (winner_of_pair)
     for (uint32_t t = 0; t < plies; ++t) {
         const uint32_t ply = A.ply0 + t;
-        int action = pick54(legal, draw_word(block, ply));
-        if (A.first_actions && t == 0) action = given;
-        if (t + 1 < plies && ((ply + 1) & 3u) == 0) block = draw_block(A.seed, A.env_base + (uint64_t)b, ply + 1);
-        if (SC)
-            y = play_ply(p, row, mover, legal, action, A.illegal_mode);
-        else
-            y = play_ply(p, NoRow{}, mover, legal, action, A.illegal_mode);
+        if constexpr (LPB == 1) word = draw_word(block, ply);
+        int action = pick54(legal, word);
+        if (t + 1 < plies) {  // the next ply's word (nothing here depends on the game)
+            if constexpr (LPB == 1) {
+                if (((ply + 1) & 3u) == 0) block = draw_block(A.seed, A.env_base + (uint64_t)b, ply + 1);
+            } else {
+                uint32_t rel = ply + 1 - 4u * base;
+                if (rel == 4u * LPB) {
+                    wave_lds_fence();  // (every lane has taken this ply's word)
+                    base += LPB;
+                    refill(base);
+                    wave_lds_fence();
+                    rel = 0;
+                }
+                word = my_draws[rel];
+            }
+        }
+        // (a sampled action is legal by construction: only the caller's actions of gbl_collect_from's first ply are tested)
+        if (A.first_actions && t == 0) {
+            action = given;
+            if (SC)
+                y = play_ply<false, PAIR>(p, row, mover, legal, action, A.illegal_mode, j);
+            else
+                y = play_ply<false, PAIR>(p, NoRow{}, mover, legal, action, A.illegal_mode, j);
+        } else {
+            if (SC)
+                y = play_ply<true, PAIR>(p, row, mover, legal, action, A.illegal_mode, j);
+            else
+                y = play_ply<true, PAIR>(p, NoRow{}, mover, legal, action, A.illegal_mode, j);
+        }
         dn = y.terminal ? 1 : 0;
         if (y.terminal) {  // raw_env.reset, gobblet.py:275-290
             p = Planes{0u, 0u, 0u};
@@ -1040,6 +1079,7 @@ __global__ __launch_bounds__((64 * small_waves<WITH_MASK, WITH_OBS, KO, MERGE>()
     __shared__ uint32_t s_state[WAVES][kStateWords];
     __shared__ uint32_t s_obs[WITH_OBS ? KO : 1][WITH_OBS ? kObsWords : 4];
     __shared__ uint32_t s_mask[WITH_MASK ? kMaskWords : 4];
+    __shared__ uint4 s_draw[LO > 1 ? WAVES : 1][LO > 1 ? 64 : 1];  // the sampler's words of 4 LPB plies, 16 bytes per lane
     if (DEV_PLY) ply0 += *ply_dev;
     const int64_t group = (int64_t)blockIdx.x;
     if (group >= ngroups) return;
@@ -1048,16 +1088,19 @@ __global__ __launch_bounds__((64 * small_waves<WITH_MASK, WITH_OBS, KO, MERGE>()
                       done_t, to_move_t, mask_t, obs_t, illegal_mode, counters, turn, first_actions};
     constexpr bool SYNC = WAVES > 1;
     if (wave == 0) {
-        small_role<kRoleScalars | ((WITH_MASK && MERGE) ? kRoleMask : 0), LA, SYNC>(A, s_state[0], s_mask, nullptr, group);
+        small_role<kRoleScalars | ((WITH_MASK && MERGE) ? kRoleMask : 0), LA, SYNC>(A, s_state[0], s_mask, nullptr,
+                                                                                    reinterpret_cast<uint32_t *>(s_draw[0]), group);
         return;
     }
     if constexpr (WITH_MASK && !MERGE) {
         if (wave == 1) {
-            small_role<kRoleMask, LA, SYNC>(A, s_state[1], s_mask, nullptr, group);
+            small_role<kRoleMask, LA, SYNC>(A, s_state[1], s_mask, nullptr, reinterpret_cast<uint32_t *>(s_draw[LO > 1 ? 1 : 0]), group);
             return;
         }
     }
-    if constexpr (WITH_OBS) small_role<kRoleObs, LO, SYNC>(A, s_state[wave], nullptr, s_obs[wave - NA], group * KO + (wave - NA));
+    if constexpr (WITH_OBS)
+        small_role<kRoleObs, LO, SYNC>(A, s_state[wave], nullptr, s_obs[wave - NA], reinterpret_cast<uint32_t *>(s_draw[LO > 1 ? wave : 0]),
+                                       group * KO + (wave - NA));
 }
 
 // gbl_placement_probe: the write pattern of k_collect without the game -- tile i of `plies` slots stores 64 rows of
