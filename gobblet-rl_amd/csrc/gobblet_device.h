@@ -379,11 +379,11 @@ __device__ __forceinline__ void sub_store(int8_t *__restrict__ g, SubVecs<sub_ve
         const uint4 &x = v.template at<I>();
 #ifndef GBL_HOST_EMU
         if constexpr (NT == kStoreStreamDrop) {
+            // (no predicate: the descriptor covers exactly this sub-tile's rows, and the hardware drops a lane whose offset lies
+            //  beyond it -- the lanes past the image's last vector)
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g, 0, BPS * ROWB, 0x00020000);
-            if (64 * I + 63 < NV || i < NV) {
-                vec4u t = {x.x, x.y, x.z, x.w};
-                __builtin_amdgcn_raw_buffer_store_b128(t, rs, i * 16, 0, 2 | 16);
-            }
+            vec4u t = {x.x, x.y, x.z, x.w};
+            __builtin_amdgcn_raw_buffer_store_b128(t, rs, i * 16, 0, 2 | 16);
         } else
 #endif
         {
@@ -402,8 +402,7 @@ __device__ __forceinline__ void sub_obs_zero(uint32_t *img, int lane)
     uint4 *lv = reinterpret_cast<uint4 *>(img);
     const uint4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int i = 0; i < (NV + 63) / 64; ++i)
-        if (64 * i + 63 < NV || lane + 64 * i < NV) lv[lane + 64 * i] = z;
+    for (int i = 0; i < (NV + 63) / 64; ++i) lv[(64 * i + 63 < NV || lane + 64 * i < NV) ? lane + 64 * i : NV - 1] = z;  // (no branch)
 }
 
 // Orders this wave's LDS accesses across lanes.  A workgroup is ONE wavefront, whose LDS
@@ -634,7 +633,8 @@ struct ImageRow {
     uint8_t *row;
     __device__ __forceinline__ void apply(const MoveCells &m) const
     {
-        if (m.had) row[m.cold] = 0;
+        // (no branch: a piece that comes from the hand clears the cell it is about to fill -- LDS stores of a lane land in order)
+        row[m.had ? m.cold : m.cnew] = 0;
         row[m.cnew] = (uint8_t)m.val;
     }
     __device__ __forceinline__ void reset() const { __builtin_memset(row, 0, kCells); }
@@ -722,24 +722,26 @@ __device__ __forceinline__ void obs_scatter_part(uint8_t *row, const Planes &p, 
         (void)j;
         obs_scatter_row(row, p, observer);
     } else {
+        // STRAIGHT-LINE code (the role kernels' wavefronts run alone on their SIMDs: a predicated region costs them its EXEC
+        // round trips, not its instructions): a piece that is not on the board writes a 0 to square 8 of its own channel, which
+        // no other piece can set; a channel-12 byte past square 8 is redirected to the lane's first square (the same value again).
         const uint32_t pos = p.nz & ~p.neg, ngv = p.nz & p.neg;
         const uint32_t own = observer ? ngv : pos, opp = observer ? pos : ngv;
         // channel ch = j + LPB i: side = ch / 6, level = (ch % 6) / 2, parity = ch & 1 = j & 1 (LPB is even)
         const uint32_t oddsel = (j & 1) ? ~p.odd : p.odd;
+        const uint32_t ownsel = own & oddsel, oppsel = opp & oddsel;
 #pragma unroll
         for (int i = 0; i < 12 / LPB; ++i) {
             const int ch = j + LPB * i;                  // 0..11
-            const uint32_t side = ch >= 6 ? opp : own;
+            const uint32_t side = ch >= 6 ? oppsel : ownsel;
             const int k = (ch >= 6 ? ch - 6 : ch) >> 1;
-            const uint32_t grp = ((side & oddsel) >> (9 * k)) & 0x1FFu;
-            if (grp) row[13 * __builtin_ctz(grp) + ch] = 1;
+            const uint32_t grp = (side >> (9 * k)) & 0x1FFu;
+            row[13 * __builtin_ctz(grp | 0x100u) + ch] = (uint8_t)(grp ? 1u : 0u);
         }
-        if (observer) {
 #pragma unroll
-            for (int i = 0; i < (9 + LPB - 1) / LPB; ++i) {
-                const int q = j + LPB * i;
-                if (q < 9) row[13 * q + 12] = 1;
-            }
+        for (int i = 0; i < (9 + LPB - 1) / LPB; ++i) {
+            const int q = j + LPB * i;
+            row[13 * (q < 9 ? q : j) + 12] = (uint8_t)observer;
         }
     }
 }
@@ -749,25 +751,24 @@ __device__ __forceinline__ void obs_scatter_quad(uint8_t *row, const Planes &p, 
     obs_scatter_part<4>(row, p, observer, j);
 }
 
-// Lane j writes bytes [S j, S j + S), S = 64 / LPB, of the board's 54-byte mask row at `row` (the last lane: what is left of the
-// 54; rows are 2-byte aligned: unaligned LDS stores, like ImageRow::reset).
+// Lane j writes S = 64 / LPB bytes of the board's 54-byte mask row at `row` -- bytes [S j, S j + S), the last lane the LAST S
+// bytes of the row (it overlaps its neighbour's share with the same values: no branch, see obs_scatter_part); one lane per board:
+// all 54.  Rows are 2-byte aligned: unaligned LDS stores, like ImageRow::reset.
 template <int LPB = 4>
 __device__ __forceinline__ void mask_row_part(uint8_t *row, uint64_t m, int j)
 {
     static_assert(LPB == 1 || LPB == 2 || LPB == 4, "lanes per board");
-    constexpr int S = 64 / LPB, NW = S / 4, LAST = kActions - S * (LPB - 1);  // bytes per lane, dwords per lane, the last lane's bytes
-    const uint64_t part = LPB == 1 ? m : (m >> (S * j));
+    constexpr int S = 64 / LPB, NW = S / 4;  // bytes per lane, dwords per lane
+    const int first = LPB == 1 ? 0 : (S * j < kActions - S ? S * j : kActions - S);  // the lane's first byte (= bit of m)
+    const uint64_t part = LPB == 1 ? m : (m >> first);
     uint32_t d[NW];
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
         const uint32_t nib = (uint32_t)(part >> (4 * k)) & 0xFu;
         d[k] = __umul24(nib, 0x00204081u) & 0x01010101u;  // bit i -> byte i
     }
-    uint8_t *dst = row + S * j;
-    if (LPB > 1 && j < LPB - 1)
-        __builtin_memcpy(dst, d, S);
-    else
-        __builtin_memcpy(dst, d, LAST);
+    if constexpr (LPB == 1) __builtin_memcpy(row, d, kActions);
+    else __builtin_memcpy(row + first, d, S);
 }
 
 __device__ __forceinline__ void mask_row_quad(uint8_t *row, uint64_t m, int j) { mask_row_part<4>(row, m, j); }

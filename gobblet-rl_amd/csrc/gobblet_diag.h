@@ -24,6 +24,21 @@ __device__ unsigned long long g_wave_stamps[1024][16][12];  // per block and wav
 #define GBL_WAVE_STAMP(i)                                                                                   \
     if ((threadIdx.x & 63u) == 0 && blockIdx.x < 1024)                                                      \
         g_wave_stamps[blockIdx.x][threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime()
+// small_role: cycles per phase of the ply loop, summed over the plies of a launch (a stamp waits for lgkmcnt(0): it perturbs
+// the LDS round trips it brackets, not the VALU chain)
+#define GBL_PHASE_DECL unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_ = __builtin_amdgcn_s_memtime()
+#define GBL_PHASE(i)                                                       \
+    {                                                                      \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
+        ph_[i] += now_ - pt_;                                              \
+        pt_ = now_;                                                        \
+    }
+#define GBL_PHASE_DEP(i, v)                                                \
+    asm volatile("" ::"v"(v));                                             \
+    GBL_PHASE(i)
+#define GBL_PHASE_FLUSH(wave)                                                                              \
+    if ((threadIdx.x & 63u) == 0 && blockIdx.x < 1024)                                                      \
+        for (int i_ = 0; i_ < 8; ++i_) g_wave_stamps[blockIdx.x][wave][i_] = ph_[i_]
 #define GBL_STAMP_FLUSH(tile)                                                                              \
     if (threadIdx.x == 0 && (tile) < (1 << 17)) {                                                          \
         unsigned long long *o_ = g_stamps[tile];                                                           \
@@ -43,6 +58,10 @@ __device__ unsigned long long g_wave_stamps[1024][16][12];  // per block and wav
 #define GBL_STAMP_DRAIN(i)
 #define GBL_STAMP_FLUSH(tile)
 #define GBL_WAVE_STAMP(i)
+#define GBL_PHASE_DECL
+#define GBL_PHASE(i)
+#define GBL_PHASE_DEP(i, v)
+#define GBL_PHASE_FLUSH(wave)
 #endif
 
 #ifdef GBL_STAMPS

@@ -932,10 +932,41 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
     const uint32_t plies = A.plies;
     const int64_t cell0 = (sub >> SH) * A.tile_stride + (sub & (LPB - 1)) * BPS;
     constexpr bool PAIR = LPB > 1;  // the lanes of a board split the winner test (winner_of_pair)
+    // The scalars role's per-lane output arrays (NULL: this lane stores nothing there), at ply 0's cell of its board:
+    //   4 lanes per board: lane 0 action + next mover, 1 reward, 2 winner, 3 done  (one byte store serves three arrays)
+    //   2 lanes:           lane 0 action + next mover + winner, 1 reward + done
+    //   1 lane:            everything
+    int32_t *sc_act = nullptr;
+    uint16_t *sc_rw = nullptr;
+    int8_t *sc_b0 = nullptr, *sc_b1 = nullptr, *sc_b2 = nullptr;
+    bool b0_is_mover = false, b0_is_winner = false;
+    if (SC && valid) {
+        const int64_t at0 = cell0 + bq;
+        if (j == 0 && A.actions_t) sc_act = A.actions_t + at0;
+        if (j == (LPB > 1 ? 1 : 0) && A.reward_t) sc_rw = reinterpret_cast<uint16_t *>(A.reward_t) + at0;
+        if constexpr (LPB == 4) {
+            b0_is_mover = j == 0;
+            b0_is_winner = j == 2;
+            int8_t *const arr = j == 0 ? A.to_move_t : j == 2 ? A.winner_t : j == 3 ? A.done_t : nullptr;
+            if (arr) sc_b0 = arr + at0;
+        } else if constexpr (LPB == 2) {
+            b0_is_mover = j == 0;
+            int8_t *const arr = j == 0 ? A.to_move_t : A.done_t;
+            if (arr) sc_b0 = arr + at0;
+            if (j == 0 && A.winner_t) sc_b1 = A.winner_t + at0;
+        } else {
+            if (A.winner_t) sc_b0 = A.winner_t + at0;
+            if (A.done_t) sc_b1 = A.done_t + at0;
+            if (A.to_move_t) sc_b2 = A.to_move_t + at0;
+        }
+    }
+    GBL_PHASE_DECL;
     for (uint32_t t = 0; t < plies; ++t) {
         const uint32_t ply = A.ply0 + t;
+        GBL_PHASE(0);  // loop overhead, the previous ply's tail
         if constexpr (LPB == 1) word = draw_word(block, ply);
         int action = pick54(legal, word);
+        GBL_PHASE_DEP(1, action);  // the pick
         if (t + 1 < plies) {  // the next ply's word (nothing here depends on the game)
             if constexpr (LPB == 1) {
                 if (((ply + 1) & 3u) == 0) block = draw_block(A.seed, A.env_base + (uint64_t)b, ply + 1);
@@ -964,6 +995,7 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
             else
                 y = play_ply<true, PAIR>(p, NoRow{}, mover, legal, action, A.illegal_mode, j);
         }
+        GBL_PHASE_DEP(2, (uint32_t)y.winner + p.nz);  // the next word, move, winner
         dn = y.terminal ? 1 : 0;
         if (y.terminal) {  // raw_env.reset, gobblet.py:275-290
             p = Planes{0u, 0u, 0u};
@@ -971,6 +1003,7 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
             if (SC) row.reset();
         }
         const int64_t cell = (int64_t)t * A.ply_stride + cell0;
+        GBL_PHASE_DEP(3, p.nz);  // reset
         if (t && full) {  // ply t - 1's rows
             if constexpr (OB) sub_store<kObs, kRowPolicy, BPS>(odst, vo, lane);
             if constexpr (MK) sub_store<kActions, kRowPolicy, BPS>(mdst, vm, lane);
@@ -983,37 +1016,23 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
                 w1 += __popcll(__ballot(valid && j == 0 && y.winner == 1));
                 w2 += __popcll(__ballot(valid && j == 0 && y.winner == -1));
             }
-            if (valid) {  // the five scalars of a board, dealt over its lanes
-                const int64_t at = cell + bq;
+            // the five scalars of a board, dealt over its lanes: per-lane array pointers fixed before the loop (sc_*), no branch
+            // on the lane's index inside it
+            {
+                const int64_t at = (int64_t)t * A.ply_stride;
                 const uint16_t rw = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
-                if constexpr (LPB == 4) {
-                    if (j == 0) {
-                        if (A.actions_t) A.actions_t[at] = action;
-                    } else if (j == 1) {
-                        if (A.reward_t) reinterpret_cast<uint16_t *>(A.reward_t)[at] = rw;
-                    }
-                    int8_t *const sp = j == 0 ? A.to_move_t : j == 2 ? A.winner_t : j == 3 ? A.done_t : nullptr;
-                    const int sv = j == 0 ? mover : j == 2 ? y.winner : dn;
-                    if (sp) sp[at] = (int8_t)sv;  // (one byte store serves three arrays)
-                } else if constexpr (LPB == 2) {
-                    if (j == 0) {
-                        if (A.actions_t) A.actions_t[at] = action;
-                        if (A.winner_t) A.winner_t[at] = (int8_t)y.winner;
-                    } else {
-                        if (A.reward_t) reinterpret_cast<uint16_t *>(A.reward_t)[at] = rw;
-                    }
-                    int8_t *const sp = j == 0 ? A.to_move_t : A.done_t;
-                    const int sv = j == 0 ? mover : dn;
-                    if (sp) sp[at] = (int8_t)sv;
-                } else {
-                    if (A.actions_t) A.actions_t[at] = action;
-                    if (A.winner_t) A.winner_t[at] = (int8_t)y.winner;
-                    if (A.reward_t) reinterpret_cast<uint16_t *>(A.reward_t)[at] = rw;
-                    if (A.done_t) A.done_t[at] = (int8_t)dn;
-                    if (A.to_move_t) A.to_move_t[at] = (int8_t)mover;
+                if (sc_act) sc_act[at] = action;
+                if (sc_rw) sc_rw[at] = rw;
+                if (sc_b0) sc_b0[at] = (int8_t)(LPB == 1 ? y.winner : b0_is_mover ? mover : b0_is_winner ? y.winner : dn);
+                if constexpr (LPB <= 2) {
+                    if (sc_b1) sc_b1[at] = (int8_t)(LPB == 1 ? dn : y.winner);
+                }
+                if constexpr (LPB == 1) {
+                    if (sc_b2) sc_b2[at] = (int8_t)mover;
                 }
             }
         }
+        GBL_PHASE(4);  // the previous ply's row stores, this ply's scalars
         if constexpr (OB) {
             sub_obs_zero<BPS>(obs_img, lane);
             wave_lds_fence();
@@ -1024,7 +1043,9 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
             else sub_out_ragged(odst, obs_img, lane, rows * kObs);
             wave_lds_fence();
         }
+        GBL_PHASE(5);  // the observation image
         legal = legal54(p, mover);  // the next mover's: stored now, sampled from next ply
+        GBL_PHASE_DEP(6, (uint32_t)legal);  // the next legal mask
         if constexpr (MK) {
             mask_row_part<LPB>(reinterpret_cast<uint8_t *>(mask_img) + bq * kActions, legal, j);
             wave_lds_fence();
@@ -1033,7 +1054,10 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
             else sub_out_ragged(mdst, mask_img, lane, rows * kActions);
             wave_lds_fence();
         }
+        GBL_PHASE(7);  // the mask image
     }
+    GBL_PHASE(7);  // (the last ply's mask image; phase 7 = the mask image of every ply but the last, see below)
+    GBL_PHASE_FLUSH(wave_index());
     if (full) {  // the last ply's rows
         if constexpr (OB) sub_store<kObs, kRowPolicy, BPS>(odst, vo, lane);
         if constexpr (MK) sub_store<kActions, kRowPolicy, BPS>(mdst, vm, lane);

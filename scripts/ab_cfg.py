@@ -48,6 +48,28 @@ for cfg in cfgs:
     g.replay()
     graphs.append(g)
 torch.cuda.synchronize()
+# every form leaves the same trajectory and the same boards as the first one of the list (one launch each from one saved position)
+saved = (env.squares.clone(), env.to_move.clone(), env.done.clone())
+ref = None
+for cfg in cfgs:
+    env.squares.copy_(saved[0]); env.to_move.copy_(saved[1]); env.done.copy_(saved[2])
+    for k in keys:
+        if k in f:
+            f[k].fill_(99)
+    L.gbl_ab_collect_cfg(cfg)
+    rc = L.gbl_collect(env.squares.data_ptr(), env.to_move.data_ptr(), env.done.data_ptr(), P["actions"], P["winner"],
+                       P["rewards"], P["done"], P["to_move"], P["action_mask"], P["observation"], n, buf["_ply_stride"],
+                       buf["_tile_stride"], 0, 0, 5000, None, T, 0, None, None, nat.current_stream(torch.device("cuda:0")))
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = {k: f[k].clone() for k in keys if k in f}
+    got["squares"], got["to_move_env"], got["done_env"] = env.squares.clone(), env.to_move.clone(), env.done.clone()
+    if ref is None:
+        ref = got
+    else:
+        bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+        assert not bad, (cfg, bad)
+print(f"boards {n}: {len(cfgs)} forms leave identical trajectories and boards", flush=True)
 res = [[] for _ in cfgs]
 for rnd in range(7):
     for i, g in enumerate(graphs):
