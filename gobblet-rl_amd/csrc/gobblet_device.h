@@ -584,7 +584,7 @@ struct MoveCells {
 
 __device__ __forceinline__ MoveCells move_planes(Planes &p, int mover, uint32_t a)
 {
-    uint32_t pi = (a * 57u) >> 9;  // a / 9 for a < 54
+    uint32_t pi = __umul24(a, 57u) >> 9;  // a / 9 for a < 54 (a 24-bit multiply: full rate)
     uint32_t q = a - 9u * pi;
     uint32_t k = pi >> 1;
     uint32_t first = (~pi) & 1u;   // piece number odd
@@ -684,32 +684,22 @@ __device__ __forceinline__ void obs_scatter(uint32_t *img, int lane, const Plane
     obs_scatter_row(reinterpret_cast<uint8_t *>(img) + lane * kObs, p, observer);
 }
 
-// row: the board's 117 observation bytes, zero on entry
+// row: the board's 117 observation bytes, zero on entry.  Straight-line code: a piece that is not on the board writes a 0 to square
+// 8 of its own channel, which no other piece can set, and channel 12 is written whoever observes (round 5: the predicated form --
+// one EXEC round trip per piece -- cost the latency-bound kernels 10-15 % of a ply; the HBM-bound ones do not care, +-1-2 %).
 __device__ __forceinline__ void obs_scatter_row(uint8_t *row, const Planes &p, int observer)
 {
     uint32_t pos = p.nz & ~p.neg, ngv = p.nz & p.neg;
     uint32_t own = observer ? ngv : pos, opp = observer ? pos : ngv;
     uint32_t X[4] = {own & p.odd, own & ~p.odd, opp & p.odd, opp & ~p.odd};  // A B C D
-    uint32_t one = 1;
-#ifndef GBL_HOST_EMU
-    asm volatile("" : "+v"(one));  // one register for the 21 stores (else the constant is re-materialised per store)
-#endif
 #pragma unroll
     for (int ch = 0; ch < 12; ++ch) {
         int k = (ch % 6) / 2;
         uint32_t grp = (X[(ch < 6 ? 0 : 2) + (ch & 1)] >> (9 * k)) & 0x1FFu;
-#ifdef GBL_X_OBS_UNCOND
-        // branch-free: a piece that is not on the board writes a 0 to square 8 of its own channel, which
-        // no other piece can set
-        row[13 * __builtin_ctz(grp | 0x100u) + ch] = (uint8_t)(grp < 1u ? grp : 1u);
-#else
-        if (grp) row[13 * __builtin_ctz(grp) + ch] = (uint8_t)one;
-#endif
+        row[13 * __builtin_ctz(grp | 0x100u) + ch] = (uint8_t)(grp ? 1u : 0u);
     }
-    if (observer) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) row[13 * q + 12] = (uint8_t)one;
-    }
+    for (int q = 0; q < 9; ++q) row[13 * q + 12] = (uint8_t)observer;
 }
 
 // Lane j (of the LPB of a board) drops channels j, j + LPB, ... and the channel-12 bytes of squares j, j + LPB, ... of the board's

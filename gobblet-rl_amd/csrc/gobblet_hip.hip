@@ -101,8 +101,9 @@ inline int small_cfg(int64_t n, bool with_mask, bool with_obs)
 #ifdef GBL_FORCE_COLLECT_SMALL  // A/B builds: 0 = never, else the form
     return (GBL_FORCE_COLLECT_SMALL);
 #else
-    if (!with_obs) return n <= 65536 ? 111 : 0;  // MASK_ONLY: scalars + mask rows on one wavefront per tile
-    return n <= 4096 ? 410 : n <= 8192 ? 140 : n <= 16384 ? 141 : n <= 40960 ? 121 : 0;
+    // (round 5, scripts/ab_roles.sh; DESIGN.md 5.2 has the table)
+    if (!with_obs) return n <= 8192 ? 210 : n <= 16384 ? 110 : n <= 40960 ? 210 : 0;
+    return n <= 8192 ? 220 : n <= 16384 ? 120 : n <= 40960 ? 110 : 0;
 #endif
 }
 
@@ -630,8 +631,9 @@ __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__r
         int action = pick54(legal, draw_word(block, ply));
         if (first_actions && t == 0) action = given;
         if (t + 1 < plies && ((ply + 1) & 3u) == 0) block = draw_block(seed, env_base + (uint64_t)L.b, ply + 1);
-        {  // step_lane with the mover's mask at hand
-            y = play_ply(p, row, mover, legal, action, illegal_mode);
+        {  // step_lane with the mover's mask at hand (a sampled action is legal by construction: only gbl_collect_from's given ones are tested)
+            if (first_actions && t == 0) y = play_ply(p, row, mover, legal, action, illegal_mode);
+            else y = play_ply<true>(p, row, mover, legal, action, illegal_mode);
             dn = y.terminal ? 1 : 0;
             if (y.terminal) {  // raw_env.reset, gobblet.py:275-290
                 p = Planes{0u, 0u, 0u};
@@ -772,7 +774,8 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
         int action = pick54(legal, draw_word(block, ply));
         if (first_actions && t == 0) action = given;
         if (t + 1 < plies && ((ply + 1) & 3u) == 0) block = draw_block(seed, env_base + (uint64_t)L.b, ply + 1);
-        y = play_ply(p, row, mover, legal, action, illegal_mode);
+        if (first_actions && t == 0) y = play_ply(p, row, mover, legal, action, illegal_mode);
+        else y = play_ply<true>(p, row, mover, legal, action, illegal_mode);  // (sampled: legal by construction)
         dn = y.terminal ? 1 : 0;
         if (y.terminal) {  // raw_env.reset, gobblet.py:275-290
             p = Planes{0u, 0u, 0u};
@@ -862,11 +865,18 @@ struct SmallArgs {
     const int32_t *first_actions;
 };
 
-// a ragged last sub-tile's rows, byte by byte (inline: a real call would give the kernel a dynamic stack, i.e. scratch)
+// a ragged last sub-tile's rows: whole 16-byte vectors (a sub-tile starts 16-byte aligned), then the last few bytes one by one
+// (byte by byte all the way, a ragged sub-tile of 15 observation rows took 28 round trips per ply: 1.3 instead of 0.8 us per ply
+// for the whole launch at 4 095 boards).  Inline: a real call would give the kernel a dynamic stack, i.e. scratch.
 __device__ __forceinline__ void sub_out_ragged(int8_t *__restrict__ g, const uint32_t *lds, int lane, int bytes)
 {
+    const int nv = bytes >> 4;
+    const uint4 *lv = reinterpret_cast<const uint4 *>(lds);
+    uint4 *gv = reinterpret_cast<uint4 *>(g);
+    for (int i = lane; i < nv; i += 64) gv[i] = lv[i];
     const int8_t *lb = reinterpret_cast<const int8_t *>(lds);
-    for (int i = lane; i < bytes; i += 64) g[i] = lb[i];
+    const int i = (nv << 4) + lane;
+    if (i < bytes) g[i] = lb[i];
 }
 
 template <int ROLE, int LPB, bool SYNC>
@@ -1853,17 +1863,17 @@ bool launch_small(int cfg, int8_t *state, int8_t *to_move, int8_t *done, const i
         else { GBL_SMALL_D(false, false, LA, KO, MG); }                                                        \
         return true;                                                                                           \
     }
+    GBL_SMALL_CFG(2, 2, false)
+    GBL_SMALL_CFG(1, 2, false)
+    GBL_SMALL_CFG(1, 1, false)
+    GBL_SMALL_CFG(2, 1, false)
+#ifdef GBL_AB_COLLECT_CFG
     GBL_SMALL_CFG(4, 1, false)
     GBL_SMALL_CFG(1, 4, false)
     GBL_SMALL_CFG(1, 4, true)
     GBL_SMALL_CFG(1, 2, true)
     GBL_SMALL_CFG(1, 1, true)
-#ifdef GBL_AB_COLLECT_CFG
-    GBL_SMALL_CFG(2, 1, false)
-    GBL_SMALL_CFG(1, 1, false)
-    GBL_SMALL_CFG(2, 2, false)
     GBL_SMALL_CFG(2, 2, true)
-    GBL_SMALL_CFG(1, 2, false)
     GBL_SMALL_CFG(2, 1, true)
     GBL_SMALL_CFG(4, 1, true)
 #endif

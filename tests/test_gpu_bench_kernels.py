@@ -6,9 +6,10 @@ instantiation each one reaches.  Bit-exact (integer / byte work).
     bench record                  entry point (as bench.py calls it)        kernel instantiation
     ----------------------------  ----------------------------------------  -------------------------------------------
     headline (2^20, collect)      gbl_collect, ply index on the device      k_collect<mask, obs, DEV_PLY, NT>, 8 and 20 plies per launch
-    c2_4096                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 4>  (<= 8 192 boards)
-    c_16384                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 2>  (<= 16 384 boards)
-    c_32768, c_65536              gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 1>  (<= 65 536 boards)
+    c2_4096                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 2, 2, false>  (<= 8 192 boards)
+    c_16384                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 1, 2, false>  (<= 16 384 boards)
+    c_32768                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 1, 1, false>  (<= 40 960 boards)
+    c_65536                       gbl_collect                               k_collect2<mask, obs, DEV_PLY>
     c3_262144                     gbl_collect                               k_collect<mask, obs, DEV_PLY, NT>
     c4_shard_131072               gbl_collect                               k_collect2<mask, obs, DEV_PLY>  (2048 tiles)
     large_4194304                 gbl_collect                               k_collect<mask, obs, DEV_PLY, NT>, identity tile map
@@ -273,10 +274,9 @@ def test_collect_from_external_first_ply_vs_oracle(G, n, T, illegal, with_obs):
 # ---- the role kernel (k_collect_small<LA, KO, MERGE>: role wavefronts that share nothing, GBL_COLLECT_ROLES(la, ko, merge)) ----
 # every form the dispatch can pick, with ragged last groups (1, 15, 17, 33, 63 rows: observation wavefronts whose share of the
 # group is partial, or empty) and whole ones
-SMALL_SIZES = [1, 15, 16, 17, 63, 65, 4096,          # <4,1,0>: 16 boards per wavefront
-               4097, 4129, 4145, 8192,               # <1,4,0>: a tile per scalars / mask wavefront, four observation wavefronts of 16
-               8193, 8209, 12321, 16384,             # <1,4,1>: the same with the mask rows on the scalars wavefront
-               16385, 16417, 16447, 32768, 40960]    # <1,2,1>: two observation wavefronts of 32 boards
+SMALL_SIZES = [1, 15, 16, 17, 31, 33, 63, 65, 4096, 4099, 8192,   # FULL <2,2>: groups of 32 boards, two observation wavefronts of 16; MASK_ONLY <2,1>
+               8193, 8209, 8241, 12321, 16384,                   # FULL <1,2>: a tile per scalars / mask wavefront, two observation wavefronts of 32; MASK_ONLY <1,1>
+               16385, 16447, 32768, 40960]                       # FULL <1,1>: three wavefronts per tile; MASK_ONLY <2,1>
 
 
 @pytest.mark.parametrize("with_obs", [True, False], ids=["full", "maskonly"])
