@@ -121,6 +121,7 @@ inline int collect_variant(int64_t n, uint32_t plies, bool with_mask, bool with_
     const bool pair = (n + kTile - 1) / kTile <= kCollect2MaxTiles && nt && (with_mask || with_obs);
 #endif
     const int cfg = nt ? small_cfg(n, with_mask, with_obs) : 0;
+    if (cfg == 3) return (with_mask || with_obs) ? GBL_COLLECT_TRIO : GBL_COLLECT_STREAM;
     return cfg ? GBL_COLLECT_ROLES(cfg / 100, (cfg / 10) % 10, cfg % 10) : pair ? GBL_COLLECT_PAIR : nt ? GBL_COLLECT_STREAM : GBL_COLLECT_CACHED;
 }
 
@@ -1088,6 +1089,159 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
             if (w1) atomicAdd(c + 2, (unsigned long long)w1);
             if (w2) atomicAdd(c + 3, (unsigned long long)w2);
         }
+    }
+}
+
+// gbl_collect between the role kernel and the HBM-bound regime: k_collect3 -- ONE wavefront plays a tile's game, and hands every
+// ply's position (planes, mover, next legal mask: six dwords per board, double-buffered in LDS, ONE barrier per ply) to a mask-row
+// wavefront and an observation-row wavefront, which build, read back and store their rows.  Against k_collect2 (one wavefront
+// plays AND builds both images, one takes them over and stores: two barriers per ply, ~360 against ~60 instructions per ply) the
+// work is dealt evenly -- player ~235 (chain + scalars), mask ~80, observation ~200 -- and nothing is played twice, so it keeps
+// paying where the role kernel's redundant chains run out of idle SIMDs (from ~32 768 boards, three wavefronts per tile and SIMD).
+// Bit for bit the trajectories of k_collect.
+template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY>
+__global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))) void k_collect3(
+    int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n, int64_t ntiles, uint64_t seed, uint64_t env_base,
+    const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies, int8_t *__restrict__ done, int64_t ply_stride,
+    int64_t tile_stride, int32_t *__restrict__ actions_t, int8_t *__restrict__ winner_t, int8_t *__restrict__ reward_t,
+    int8_t *__restrict__ done_t, int8_t *__restrict__ to_move_t, int8_t *__restrict__ mask_t, int8_t *__restrict__ obs_t,
+    int illegal_mode, int64_t *__restrict__ counters, int32_t *__restrict__ turn, const int32_t *__restrict__ first_actions)
+{
+    constexpr int WAVES = 1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0);
+    __shared__ uint32_t s_state[image_words<kCells>()];
+    __shared__ uint32_t s_obs[WITH_OBS ? image_words<kObs>() : 4];
+    __shared__ uint32_t s_mask[WITH_MASK ? image_words<kActions>() : 4];
+    __shared__ uint4 s_hand[2][kTile];      // per ply parity and board: nz, neg, odd, mover
+    __shared__ uint2 s_legal[2][kTile];     // ... and the next mover's legal mask
+    if (DEV_PLY) ply0 += *ply_dev;
+    const int role = WAVES > 1 ? wave_index() : 0;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int64_t tile = (int64_t)blockIdx.x;
+    if (tile >= ntiles) return;  // (the same for every wavefront of the workgroup)
+    const int64_t left = n - tile * kTile;
+    const int rows = left < kTile ? (int)left : kTile;
+    const bool valid = lane < rows, full = rows == kTile;
+    const int64_t b = tile * kTile + lane;
+    constexpr int kPolicy = kStoreStreamDrop;
+    const int64_t cell0 = tile * tile_stride;
+    if (role != 0) {
+        // ---- a row wavefront: the mask rows (role 1 when there are any) or the observation rows -----------------------------
+        const bool is_mask = WITH_MASK && role == 1;
+        SubVecs<WITH_MASK ? sub_vectors<kActions, kTile>() : 0> vm{};
+        SubVecs<WITH_OBS ? sub_vectors<kObs, kTile>() : 0> vo{};
+        int8_t *dst = nullptr;
+        for (uint32_t t = 0; t < plies; ++t) {
+            pair_barrier();  // ply t's positions are in s_hand[t & 1] (and the player is free to go on with ply t + 1)
+            const int64_t cell = (int64_t)t * ply_stride + cell0;
+            if (t && full) {  // ply t - 1's rows, read back at the end of the last iteration
+                if constexpr (WITH_MASK) {
+                    if (is_mask) sub_store<kActions, kPolicy, kTile>(dst, vm, lane);
+                }
+                if constexpr (WITH_OBS) {
+                    if (!is_mask) sub_store<kObs, kPolicy, kTile>(dst, vo, lane);
+                }
+            }
+            if constexpr (WITH_MASK) {
+                if (is_mask) {
+                    const uint2 lg = s_legal[t & 1u][lane];
+                    mask_row_part<1>(reinterpret_cast<uint8_t *>(s_mask) + lane * kActions, ((uint64_t)lg.y << 32) | lg.x, 0);
+                    wave_lds_fence();
+                    dst = mask_t + cell * kActions;
+                    if (full) sub_fetch<kActions, kTile>(s_mask, lane, vm);
+                    else sub_out_ragged(dst, s_mask, lane, rows * kActions);
+                    wave_lds_fence();
+                }
+            }
+            if constexpr (WITH_OBS) {
+                if (!is_mask) {
+                    const uint4 h = s_hand[t & 1u][lane];
+                    sub_obs_zero<kTile>(s_obs, lane);
+                    wave_lds_fence();
+                    obs_scatter_row(reinterpret_cast<uint8_t *>(s_obs) + lane * kObs, Planes{h.x, h.y, h.z}, (int)h.w);
+                    wave_lds_fence();
+                    dst = obs_t + cell * kObs;
+                    if (full) sub_fetch<kObs, kTile>(s_obs, lane, vo);
+                    else sub_out_ragged(dst, s_obs, lane, rows * kObs);
+                    wave_lds_fence();
+                }
+            }
+        }
+        if (full) {  // the last ply's rows
+            if constexpr (WITH_MASK) {
+                if (is_mask) sub_store<kActions, kPolicy, kTile>(dst, vm, lane);
+            }
+            if constexpr (WITH_OBS) {
+                if (!is_mask) sub_store<kObs, kPolicy, kTile>(dst, vo, lane);
+            }
+        }
+        return;
+    }
+    // ---- the playing wavefront: k_collect's loop with the scalars, without the rows -----------------------------------------
+    Lane L;
+    L.tile = tile; L.lane = lane; L.rows = rows; L.valid = valid; L.b = b;
+    int mover = to_move[valid ? b : n - 1];
+    int given = first_actions ? first_actions[valid ? b : n - 1] : 0;  // (gbl_collect_from, see k_collect)
+    uint32_t r[7];
+    Draw4 block{{0u, 0u, 0u, 0u}};
+    load_state(state, s_state, L, r, [&] { block = draw_block(seed, env_base + (uint64_t)b, ply0); });
+    mover = valid && mover != 0;
+    Planes p = planes_of(L, r);
+    const ImageRow row{reinterpret_cast<uint8_t *>(s_state) + lane * kCells};
+    uint32_t games = 0, w1 = 0, w2 = 0;
+    Ply y{0, 0, 0, false, false};
+    int dn = 0, tcount = 0;
+    bool treset = false;
+    uint64_t legal = legal54(p, mover);
+    for (uint32_t t = 0; t < plies; ++t) {
+        const uint32_t ply = ply0 + t;
+        int action = pick54(legal, draw_word(block, ply));
+        if (t + 1 < plies && ((ply + 1) & 3u) == 0) block = draw_block(seed, env_base + (uint64_t)b, ply + 1);
+        if (first_actions && t == 0) {
+            action = given;
+            y = play_ply(p, row, mover, legal, action, illegal_mode);
+        } else {
+            y = play_ply<true>(p, row, mover, legal, action, illegal_mode);  // (sampled: legal by construction)
+        }
+        dn = y.terminal ? 1 : 0;
+        if (y.terminal) {  // raw_env.reset, gobblet.py:275-290
+            p = Planes{0u, 0u, 0u};
+            mover = 0;
+            row.reset();
+        }
+        legal = legal54(p, mover);  // the next mover's: stored now, sampled from next ply
+        s_hand[t & 1u][lane] = uint4{p.nz, p.neg, p.odd, (uint32_t)mover};
+        s_legal[t & 1u][lane] = uint2{(uint32_t)legal, (uint32_t)(legal >> 32)};
+        if (WAVES > 1) pair_barrier();  // ply t handed over
+        tcount = next_turn(tcount, y, 1);
+        treset = treset || y.terminal;
+        if (counters) {
+            games += __popcll(__ballot(valid && y.terminal));
+            w1 += __popcll(__ballot(valid && y.winner == 1));
+            w2 += __popcll(__ballot(valid && y.winner == -1));
+        }
+        if (valid) {
+            const int64_t at = (int64_t)t * ply_stride + cell0 + lane;
+            if (actions_t) actions_t[at] = action;
+            if (winner_t) winner_t[at] = (int8_t)y.winner;
+            if (reward_t) reinterpret_cast<uint16_t *>(reward_t)[at] = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
+            if (done_t) done_t[at] = (int8_t)dn;
+            if (to_move_t) to_move_t[at] = (int8_t)mover;
+        }
+    }
+    wave_lds_fence();
+    tile_out<kCells>(state + tile * (kTile * kCells), s_state, lane, rows);
+    if (valid) {
+        to_move[b] = (int8_t)mover;
+        done[b] = (int8_t)dn;
+        if (turn) turn[b] = treset ? tcount : turn[b] + tcount;
+    }
+    if (counters && lane == 0) {
+        unsigned long long *c = reinterpret_cast<unsigned long long *>(counters) +
+                                (size_t)(tile % GBL_COUNTER_STRIPES) * GBL_COUNTER_STRIDE;
+        atomicAdd(c + 0, (unsigned long long)rows * plies);
+        if (games) atomicAdd(c + 1, (unsigned long long)games);
+        if (w1) atomicAdd(c + 2, (unsigned long long)w1);
+        if (w2) atomicAdd(c + 3, (unsigned long long)w2);
     }
 }
 
@@ -2252,6 +2406,21 @@ int gbl_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int32_t
     const int variant = collect_variant(n, plies, mask_traj != nullptr, obs_traj != nullptr);
     const bool pair = variant == GBL_COLLECT_PAIR;
     [[maybe_unused]] const bool nt = variant != GBL_COLLECT_CACHED;
+    if (variant == GBL_COLLECT_TRIO) {
+#define GBL_TRIO_K(M, O, D)                                                                                                       \
+    hipLaunchKernelGGL((k_collect3<M, O, D>), dim3((uint32_t)g.ntiles), dim3(64 * (1 + (M ? 1 : 0) + (O ? 1 : 0))), 0, s, state, to_move, \
+                       n, g.ntiles, seed, env_base, ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj, \
+                       reward_traj, done_traj, to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn, first_actions)
+#define GBL_TRIO(M, O)                                          \
+    if (ply_dev) { GBL_TRIO_K(M, O, true); }                    \
+    else { GBL_TRIO_K(M, O, false); }
+        if (mask_traj && obs_traj) { GBL_TRIO(true, true); }
+        else if (mask_traj) { GBL_TRIO(true, false); }
+        else { GBL_TRIO(false, true); }
+#undef GBL_TRIO
+#undef GBL_TRIO_K
+        GBL_LAUNCHED("gbl_collect");
+    }
     if (GBL_COLLECT_IS_ROLES(variant)) {
         if (!launch_small(variant - GBL_COLLECT_ROLES(0, 0, 0), state, to_move, done, first_actions, actions_traj, winner_traj, reward_traj,
                           done_traj, to_move_traj, mask_traj, obs_traj, n, ply_stride, tile_stride, seed, env_base, ply0, ply_dev, plies,
