@@ -101,9 +101,9 @@ inline int small_cfg(int64_t n, bool with_mask, bool with_obs)
 #ifdef GBL_FORCE_COLLECT_SMALL  // A/B builds: 0 = never, else the form
     return (GBL_FORCE_COLLECT_SMALL);
 #else
-    // (round 5, scripts/ab_roles.sh; DESIGN.md 5.2 has the table)
-    if (!with_obs) return n <= 8192 ? 210 : n <= 16384 ? 110 : n <= 40960 ? 210 : 0;
-    return n <= 8192 ? 220 : n <= 16384 ? 120 : n <= 40960 ? 110 : 0;
+    // (round 5, scripts/ab_roles.sh; DESIGN.md 5.2 has the table; 3 = k_collect3)
+    if (!with_obs) return n <= 8192 ? 210 : n <= 57344 ? 3 : 0;
+    return n <= 8192 ? 220 : n <= 16384 ? 120 : n <= 36864 ? 3 : 0;
 #endif
 }
 
@@ -708,6 +708,9 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
     __shared__ uint32_t s_mask[WITH_MASK ? image_words<kActions>() : 4];
     __shared__ uint32_t s_small[kTile][2];  // per board: the action; winner | reward << 8 | done << 24 | to_move << 25
     if (DEV_PLY) ply0 += *ply_dev;
+    // (Round 5 tried to alternate the playing wavefront between the workgroups that share a CU -- wavefront 0 in workgroups w and
+    //  w + 256, wavefront 1 in w + 512 and w + 768 -- on the theory that all players of a CU sit on two of its four SIMDs: WORSE,
+    //  MASK_ONLY 0.92 -> 1.16 us per ply at 65 536 boards, 1.29 -> 1.91 at 131 072; FULL +0 ... +6 %: profiles/r05/pair_flip.txt.)
     const int role = wave_index();
     Lane L;
     L.tile = (int64_t)blockIdx.x;
@@ -2019,9 +2022,9 @@ bool launch_small(int cfg, int8_t *state, int8_t *to_move, int8_t *done, const i
     }
     GBL_SMALL_CFG(2, 2, false)
     GBL_SMALL_CFG(1, 2, false)
-    GBL_SMALL_CFG(1, 1, false)
     GBL_SMALL_CFG(2, 1, false)
 #ifdef GBL_AB_COLLECT_CFG
+    GBL_SMALL_CFG(1, 1, false)
     GBL_SMALL_CFG(4, 1, false)
     GBL_SMALL_CFG(1, 4, false)
     GBL_SMALL_CFG(1, 4, true)

@@ -8,7 +8,7 @@ instantiation each one reaches.  Bit-exact (integer / byte work).
     headline (2^20, collect)      gbl_collect, ply index on the device      k_collect<mask, obs, DEV_PLY, NT>, 8 and 20 plies per launch
     c2_4096                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 2, 2, false>  (<= 8 192 boards)
     c_16384                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 1, 2, false>  (<= 16 384 boards)
-    c_32768                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 1, 1, false>  (<= 40 960 boards)
+    c_32768                       gbl_collect                               k_collect3<mask, obs, DEV_PLY>  (<= 36 864 boards)
     c_65536                       gbl_collect                               k_collect2<mask, obs, DEV_PLY>
     c3_262144                     gbl_collect                               k_collect<mask, obs, DEV_PLY, NT>
     c4_shard_131072               gbl_collect                               k_collect2<mask, obs, DEV_PLY>  (2048 tiles)
@@ -231,7 +231,8 @@ def test_bench_step_mode_vs_oracle(G):
 
 @pytest.mark.parametrize("n,T,illegal,with_obs", [(131072, 2, "noop", True), (262144, 2, "terminate", True),
                                                   (4099, 3, "terminate", False), (131073, 2, "noop", True), (70, 1, "noop", True),
-                                                  (12001, 2, "noop", True), (40001, 1, "terminate", True), (40001, 3, "noop", False)])
+                                                  (12001, 2, "noop", True), (40001, 1, "terminate", True), (40001, 3, "noop", False),
+                                                  (20001, 2, "terminate", True), (5001, 2, "terminate", True)])
 def test_collect_from_external_first_ply_vs_oracle(G, n, T, illegal, with_obs):
     """gbl_collect_from (bench records step_reply_*): the first ply plays caller-supplied actions -- an external policy's,
     some of them illegal or out of range -- the rest are sampled; k_collect2 at 131 072 boards, k_collect beyond.  Three
@@ -275,17 +276,32 @@ def test_collect_from_external_first_ply_vs_oracle(G, n, T, illegal, with_obs):
 # every form the dispatch can pick, with ragged last groups (1, 15, 17, 33, 63 rows: observation wavefronts whose share of the
 # group is partial, or empty) and whole ones
 SMALL_SIZES = [1, 15, 16, 17, 31, 33, 63, 65, 4096, 4099, 8192,   # FULL <2,2>: groups of 32 boards, two observation wavefronts of 16; MASK_ONLY <2,1>
-               8193, 8209, 8241, 12321, 16384,                   # FULL <1,2>: a tile per scalars / mask wavefront, two observation wavefronts of 32; MASK_ONLY <1,1>
-               16385, 16447, 32768, 40960]                       # FULL <1,1>: three wavefronts per tile; MASK_ONLY <2,1>
+               8193, 8209, 8241, 12321, 16384]                   # FULL <1,2>: a tile per scalars / mask wavefront, two observation wavefronts of 32
+TRIO_SIZES = [16385, 16447, 32768, 36864, 57344]                 # k_collect3 (FULL up to 36 864 boards; MASK_ONLY 8 193 ... 57 344)
 
 
 @pytest.mark.parametrize("with_obs", [True, False], ids=["full", "maskonly"])
 @pytest.mark.parametrize("n", SMALL_SIZES)
 def test_small_batch_collect_vs_oracle(G, n, with_obs):
-    """gbl_collect on batches that do not fill the chip (GBL_COLLECT_SMALL / _HALF / _ROLES: four, two, one lane per board)
+    """gbl_collect on batches that do not fill the chip (the role kernel's forms, GBL_COLLECT_ROLES(la, ko, merge))
     directly against the oracle, FULL and MASK_ONLY, time- and tile-major slots, both illegal modes, ply index by value and on
     the device, tallies and turn counters; ragged last sub-tiles and whole ones of every form."""
-    assert G._native.lib().gbl_collect_variant(n, 7, 1, int(with_obs)) >= 1000  # GBL_COLLECT_ROLES(...)
+    variant = G._native.lib().gbl_collect_variant(n, 7, 1, int(with_obs))
+    assert variant >= 1000 or (variant == 3 and not with_obs and n > 8192)  # GBL_COLLECT_ROLES(...) (MASK_ONLY beyond 8 192 boards: k_collect3)
+    small_batch_case(G, n, with_obs)
+
+
+@pytest.mark.parametrize("with_obs", [True, False], ids=["full", "maskonly"])
+@pytest.mark.parametrize("n", TRIO_SIZES)
+def test_trio_collect_vs_oracle(G, n, with_obs):
+    """gbl_collect where k_collect3 runs (one playing wavefront per tile hands every ply's position to a mask-row and an
+    observation-row wavefront: GBL_COLLECT_TRIO), against the oracle as above; ragged last tiles (1 and 63 rows) and whole ones."""
+    variant = G._native.lib().gbl_collect_variant(n, 7, 1, int(with_obs))
+    assert variant == (3 if (n <= 36864 or not with_obs) else 2)  # (FULL beyond 36 864 boards: k_collect2, covered here too)
+    small_batch_case(G, n, with_obs)
+
+
+def small_batch_case(G, n, with_obs):
     T, seed, base, warm = (7 if n <= 8192 else 5), 29, 123_456_789_012, 6
     for layout, illegal, device_ply in (("time", "noop", True), ("tile", "terminate", False)):
         env, s, tm, dn = warm_pair(G, n, seed, base, warm, with_observation=with_obs, illegal_mode=illegal, track_turn=True)
