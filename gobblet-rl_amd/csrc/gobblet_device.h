@@ -1267,24 +1267,21 @@ __device__ __forceinline__ GreedyHead greedy_head(const Planes &p, int me, uint6
     outcomes54_root(p, me, win1, lose1);
     win1 &= tried;
     lose1 &= tried;
-    // walk the decisive results in order; everything before the stop is in `results`
-    uint64_t seen = tried;
-    for (uint64_t ev = win1 | lose1; ev;) {
-        int a = __builtin_ctzll(ev);
-        ev &= ev - 1;
-        if ((win1 >> a) & 1ull) {  // :92-94
-            h.chosen = a;
-            seen = tried & below_eq(a);
-            break;
-        }
-        if (h.ncands > 1) {        // :95-99
-            h.cands &= ~(1ull << a);
-            --h.ncands;
-        } else {                   // :100-101
-            seen = tried & below_eq(a);
-            break;
-        }
-    }
+    // The walk over the decisive results in order (:92-101), in CLOSED FORM (round 5: the loop ran as long as the busiest lane's
+    // count of decisive moves, on the owners' path of the greedy kernels' B phase).  Let fw be the first winning move.  Every
+    // losing move before it takes itself off actions_depth1 while more than one action is left (:95-99) -- and since the losing
+    // moves are candidates themselves, the list can only run down to one if EVERY candidate loses (no win before the last one):
+    // then the walk stops at the last of them (:100-101) with that one left.  Otherwise all losing moves before fw go, and the
+    // walk ends at fw (chosen, :92-94) or runs through.  Everything before the stop is in `results`.
+    const uint64_t before_fw = win1 ? (1ull << __builtin_ctzll(win1)) - 1ull : ~0ull;
+    const uint64_t lb = lose1 & before_fw;                    // the losing moves the walk meets
+    const int m = __popcll(lb);
+    const bool all_lose = m > 0 && m == h.ncands;             // (then there is no win among the tried moves either)
+    const int last = all_lose ? 63 - __builtin_clzll(lb) : 0;
+    h.cands = all_lose ? (1ull << last) : (h.cands & ~lb);
+    h.ncands = all_lose ? 1 : h.ncands - m;
+    h.chosen = win1 ? __builtin_ctzll(win1) : -1;
+    uint64_t seen = win1 ? (tried & (before_fw | (before_fw + 1ull))) : all_lose ? (tried & below_eq(last)) : tried;
     // :103; depth 3 adds :160-208, whose only assignment repeats :157 -- no effect
     h.todo = depth > 1 ? (seen & ~win1 & ~lose1) : 0ull;
     // The two pieces of a size are interchangeable: while both are still in hand, placing piece 2k+1 on q

@@ -1413,7 +1413,7 @@ struct GreedyLds {
     uint16_t item[kBoards * kRootItems];              // (board << 8) | j of every member of a root's replies that is dealt out
     uint32_t board[kBoards][4];            // planes nz, neg, odd; bit 0: the agent to move, bit 1: the board wants depth 2
     uint64_t legal[kBoards];               // its legal moves on the root position
-    unsigned long long work[kBoards];      // the candidates of a board that are evaluated
+    unsigned long long work[kBoards];      // w0 = todo & ~dup: the candidates of a board that want a reply summary (see plan_of)
     unsigned long long replies[kBoards];   // the opponent's winning moves on the root (greedy_root); after the plan: those dealt out
     uint32_t risky[kBoards];               // 9 bits: squares where a placement from hand has to be evaluated (greedy_root)
     int npairs, nitems;                    // npairs: fast pairs in the low, ordered pairs in the high 16 bits
@@ -1423,7 +1423,6 @@ struct GreedyLds {
     unsigned long long second[kBoards];    // (the sets greedy_replay_closed works on)
     unsigned long long block[kBoards];
     unsigned long long flegal[kBoards];
-    unsigned long long workx[kBoards];     // the candidates of a board that are evaluated in the ordered form (work: in the fast form)
     unsigned long long nonplain[kBoards];  // greedy_nonplain of the board
     int job;                               // the next chunk of 64 pairs / items to hand out
     // The pair list is dead between two decisions (written after the third barrier of greedy_tile, read before its last one): a
@@ -1512,10 +1511,17 @@ __device__ __forceinline__ void list_append2(uint16_t *list, uint16_t *listx, in
 // loop in closed form over the sets (greedy_replay_closed).
 // Safe to call in a loop: what the owners read last (replay) and write first (heads) is their own wavefront's business,
 // and everybody else's reads of an iteration lie before its last barrier.
+// FLOOR builds (scripts/greedy_floor.sh; results are WRONG, timing only): -DGBL_X_GREEDY_SKIP=bits leaves phases of the decision
+// out -- 1 the owners' tail (merge, replay), 2 the chunk phase (the evaluations), 4 the list phase, 8 the B phase (depth-1 walk,
+// root, nonplain set), 16 the candidate rows of gbl_greedy's output -- so that what a block cannot go below is measured, not argued.
+#ifndef GBL_X_GREEDY_SKIP
+#define GBL_X_GREEDY_SKIP 0
+#endif
 template <int NT, int W>
 __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const Planes &p, int me, uint64_t mask, int depth,
                                                     bool deep, uint32_t prev3, TileStamps &ts)
 {
+    constexpr int kSkip = GBL_X_GREEDY_SKIP;
     const int lane = (int)(threadIdx.x & 63u), wave = wave_index();
     const bool owner = wave < NT;
     const int bi = (owner ? wave : wave - NT) * kTile + lane;  // the board this thread owns, or helps with (wave < 2 NT)
@@ -1543,7 +1549,7 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
         pool_fence<W>();
         GBL_WAVE_STAMP(9);
         // (B) the helpers look at the root from the OPPONENT's side (as expensive as the depth-1 walk itself)
-        if (wave >= NT && wave < 2 * NT && (S.board[bi][3] & 2u)) {
+        if (!(kSkip & 8) && wave >= NT && wave < 2 * NT && (S.board[bi][3] & 2u)) {
             const Planes q{S.board[bi][0], S.board[bi][1], S.board[bi][2]};
             const GreedyRoot g = greedy_root(q, (int)(S.board[bi][3] & 1u));
             S.replies[bi] = g.replies;
@@ -1552,14 +1558,14 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
         // ... and a wavefront that would idle (blocks without one: the helpers, on top) finds the moves of ours after which
         // a reply could expose a line of ours: those pairs take the ordered form of the evaluation, all others the fast one
         constexpr int kPlainWave0 = W >= 3 * NT ? 2 * NT : NT;
-        if (wave >= kPlainWave0 && wave < kPlainWave0 + NT) {
+        if (!(kSkip & 8) && wave >= kPlainWave0 && wave < kPlainWave0 + NT) {
             const int bn = (wave - kPlainWave0) * kTile + lane;
             if (S.board[bn][3] & 2u)
                 S.nonplain[bn] = greedy_nonplain(Planes{S.board[bn][0], S.board[bn][1], S.board[bn][2]}, (int)(S.board[bn][3] & 1u));
         }
     }
     if (owner) {
-        h = greedy_head(p, me, mask, depth);  // empty mask: nothing to do
+        if (!(kSkip & 8)) h = greedy_head(p, me, mask, depth);  // empty mask: nothing to do
         if (deep) {
             S.legal[bi] = h.legal_me;
             S.threat[bi] = 0ull;
@@ -1569,22 +1575,45 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
             S.flegal[bi] = 0ull;
         }
     }
-    if (deep) {
-        GBL_WAVE_STAMP(10);
-        pool_fence<W>();  // the helpers' findings are in
-        if (owner) {
-            // (C) twin placements are not evaluated a second time; placements from hand on non-risky squares not at all
-            if (two) plan = greedy_root_plan(h, p, me, GreedyRoot{S.replies[bi], S.risky[bi]});
-            const unsigned long long slow = two ? S.nonplain[bi] : 0ull;
-            S.work[bi] = plan.eval & ~slow;
-            S.workx[bi] = plan.eval & slow;
-            S.replies[bi] = plan.items;
-        }
-    }
+    // (C) The split of a board's candidates -- twin placements are not evaluated a second time; placements from hand on non-risky
+    // squares not at all, they are settled from the root's replies; the rest in the fast or the ordered form -- needs the owner's
+    // depth-1 result (w0 = todo & ~dup) and the helpers' findings.  Round 4 had the owners compute it alone between two barriers
+    // (1.7 k cycles of a 21.8 k block with one wavefront per SIMD at work); round 5: the owners publish w0 with their other results
+    // before barrier B, and whoever needs the split of a board afterwards -- the listing wavefronts for the boards they list, the
+    // owners for their own -- derives it from LDS (~40 instructions, in the throughput-bound list phase): one barrier less.
+    // Measured (scripts/ab_greedy.py, in-process, us per launch old -> new): <1,16> at 4 096 boards 8.96 -> 8.25, <2,8> at 32 768:
+    // 10.65 -> 10.02 (gbl_collect_policy 10.67 -> 10.10 per ply); <4,16> at 65 536: 12.05 -> 12.25 and <1,4> at 2^20: 143.3 -> 144.8
+    // -- blocks that fill their SIMDs pay for the sixteen (four) copies of the split more than the barrier cost them: they keep
+    // round 4's flow (kListerPlan false).
+#ifndef GBL_X_LISTER_PLAN
+    constexpr bool kListerPlan = (NT == 1 && W >= 8) || (NT == 2);
+#else
+    constexpr bool kListerPlan = (GBL_X_LISTER_PLAN) != 0;
+#endif
+    if (kListerPlan && owner && deep) S.work[bi] = two ? (h.todo & ~h.dup) : 0ull;
+    auto plan_of = [&](int bn) {
+        const unsigned long long w0 = S.work[bn];
+        const Planes q{S.board[bn][0], S.board[bn][1], S.board[bn][2]};
+        const GreedyRoot gr{S.replies[bn], S.risky[bn]};
+        const bool rule = __popcll(gr.replies) <= kRootItems;
+        const uint64_t resolved = rule ? (w0 & greedy_from_hand(q, (int)(S.board[bn][3] & 1u)) & ~spread9(gr.risky)) : 0ull;
+        return GreedyRootPlan{w0 & ~resolved, resolved, resolved ? gr.replies : 0ull};
+    };
     GBL_TILE_STAMP(ts, 0);
     if (deep) {
-        GBL_WAVE_STAMP(0);
-        pool_fence<W>();
+        GBL_WAVE_STAMP(10);
+        pool_fence<W>();  // the helpers' findings and the owners' depth-1 results are in
+        if constexpr (kListerPlan) {
+            if (two) plan = plan_of(bi);
+        } else {
+            if (owner) {  // the owners alone, between two barriers: S.work = the split's `eval` set itself
+                if (two) plan = greedy_root_plan(h, p, me, GreedyRoot{S.replies[bi], S.risky[bi]});
+                S.work[bi] = plan.eval;
+                S.replies[bi] = plan.items;
+            }
+            GBL_WAVE_STAMP(0);
+            pool_fence<W>();
+        }
         GBL_WAVE_STAMP(1);
         // (D) the work lists: W / NT wavefronts share a tile's 54 candidate steps, and the owners take their tile's 6 rank
         // steps on top
@@ -1593,24 +1622,28 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
 #define GBL_X_LISTERS 64
 #endif
         constexpr int kWavesPerTile = W / NT < GBL_X_LISTERS ? W / NT : GBL_X_LISTERS, kSteps = (kActions + kWavesPerTile - 1) / kWavesPerTile;
-        if (const int lw = wave - (W - NT * kWavesPerTile); lw >= 0) {  // (the last wavefronts: the owners come out of the plan last)
+        if (const int lw = wave - (W - NT * kWavesPerTile); lw >= 0 && !(kSkip & 4)) {  // (the last wavefronts: the owners come out of the plan last)
             const int g = lw / kWavesPerTile, c0 = (lw % kWavesPerTile) * kSteps;  // (a wavefront's steps stay inside one tile)
             if (c0 < kActions) {
                 const int steps = kActions - c0 < kSteps ? kActions - c0 : kSteps;
-                const uint64_t wk = (S.work[g * kTile + lane] >> c0) & ((1ull << steps) - 1ull);
-                const uint64_t wx = (S.workx[g * kTile + lane] >> c0) & ((1ull << steps) - 1ull);
+                const int bn = g * kTile + lane;
+                const uint64_t ev = kListerPlan ? plan_of(bn).eval : (uint64_t)S.work[bn];
+                const uint64_t slow = ev ? S.nonplain[bn] : 0ull;  // (the nonplain set exists for boards that take part)
+                const uint64_t wk = ((ev & ~slow) >> c0) & ((1ull << steps) - 1ull);
+                const uint64_t wx = ((ev & slow) >> c0) & ((1ull << steps) - 1ull);
                 list_append2<kSteps>(S.pair, S.pair + (GreedyLds<NT, W>::kBoards * kActions - 1), &S.npairs,
-                                     ((uint32_t)(g * kTile + lane) << 8) + (uint32_t)c0, lane, wk, wx);
+                                     ((uint32_t)bn << 8) + (uint32_t)c0, lane, wk, wx);
             }
         }
         GBL_WAVE_STAMP(6);
         // (blocks of tiles: by the owners -- the oldest wavefronts on their SIMDs win the issue arbitration and are through
         // first; a lone tile: by its helper, the owner's own path being the longest there)
         constexpr int kItemWave0 = NT * kWavesPerTile < W ? 0 : NT == 1 ? 1 : 0;  // (wavefronts that list no pairs, if any)
-        if (wave >= kItemWave0 && wave < kItemWave0 + NT) {
-            const int g = wave - kItemWave0;
-            const uint32_t nr = (uint32_t)__popcll(S.replies[g * kTile + lane]);
-            list_append<kRootItems>(S.item, &S.nitems, (uint32_t)(g * kTile + lane) << 8, lane, (1u << nr) - 1u);
+        if (!(kSkip & 4) && wave >= kItemWave0 && wave < kItemWave0 + NT) {
+            const int g = wave - kItemWave0, bn = g * kTile + lane;
+            // (the owners list their own boards; a lone tile's helper reads, or derives, its board's)
+            const uint32_t nr = (uint32_t)__popcll(!kListerPlan ? (uint64_t)S.replies[bn] : (kItemWave0 == 0 ? plan : plan_of(bn)).items);
+            list_append<kRootItems>(S.item, &S.nitems, (uint32_t)bn << 8, lane, (1u << nr) - 1u);
         }
         GBL_WAVE_STAMP(7);
         pool_fence<W>();
@@ -1631,6 +1664,7 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
             if (sum >> 15) atomicOr(&S.allwin[o], 1ull << a);
         };
         for (;;) {
+            if (kSkip & 2) break;
             int j = 0;
             if (lane == 0) j = atomicAdd(&S.job, 1);
             j = __builtin_amdgcn_readfirstlane(j);
@@ -1667,7 +1701,7 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
     }
     GBL_TILE_STAMP(ts, 2);
     if (!owner) return GreedyResult{-1, 0ull, false};
-    if (two) {  // :103-157 on the owner's lane, in closed form over the candidate sets
+    if (two && !(kSkip & 1)) {  // :103-157 on the owner's lane, in closed form over the candidate sets
         ReplySets r{S.threat[bi], S.allwin[bi], S.second[bi], S.block[bi], S.flegal[bi]};
         uint64_t undef[kRootItems] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
         const int nitems_b = __popcll(plan.items);
@@ -1785,7 +1819,7 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
     GBL_STAMP_VAL(2, ts.t[1]);
     GBL_STAMP_VAL(3, ts.t[2]);
     if (!owner || L.rows == 0) return;
-    if (cand_out) {
+    if (cand_out && !(GBL_X_GREEDY_SKIP & 16)) {
         uint32_t d[14];
         mask_row(g.cands, d);
         row_stage<kActions>(s_mask, L.lane, d);
@@ -2650,7 +2684,8 @@ int greedy_shape(int depth, int64_t n)
     (void)n;
     return depth == 1 ? 11 : GBL_FORCE_GREEDY_SHAPE;
 #else
-    return depth == 1 ? 11 : n <= 16384 ? 26 : n <= 32768 ? 28 : n <= 65536 ? 56 : n <= 262144 && whole_generations(n) ? 56 : 14;
+    // (round 5, scripts/ab_greedy.py: at 262 144 boards <1,4> 39.8 us against <4,16>'s 40.8 since the depth-1 walk is a closed form)
+    return depth == 1 ? 11 : n <= 16384 ? 26 : n <= 32768 ? 28 : n <= 65536 ? 56 : n <= 196608 && whole_generations(n) ? 56 : 14;
 #endif
 }
 
