@@ -18,8 +18,8 @@ import torch  # noqa: F401  (must precede loading the HIP library, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-# GOBBLET_HIP_LIB: load a differently built library of the same ABI (kernel A/B experiments)
-LIB_PATH = os.environ.get("GOBBLET_HIP_LIB") or os.path.join(CSRC, "libgobblet_hip.so")
+LIB_PATH = os.path.join(CSRC, "libgobblet_hip.so")
+_FOREIGN = False  # use_library() was called: LIB_PATH is somebody's own build, never rebuilt from here
 SOURCES = [os.path.join(CSRC, "gobblet_hip.hip"), os.path.join(CSRC, "gobblet_device.h"), os.path.join(CSRC, "gobblet_diag.h"),
            os.path.join(_HERE, "..", "include", "gobblet_hip.h")]
 # -amdgpu-kernarg-preload-count: the first 16 dwords of a kernel's arguments arrive in SGPRs with the wave
@@ -85,8 +85,18 @@ class GobbletHipError(RuntimeError):
     pass
 
 
+def use_library(path: str) -> None:
+    """Load a differently built library of the same ABI instead of csrc/libgobblet_hip.so (kernel A/B experiments, diagnostic
+    builds: scripts/, tests/conftest.py).  Call it before anything else of the package touches the library.  The product reads
+    no environment variable: the experiment scripts do, and call this."""
+    global LIB_PATH, _FOREIGN, _lib
+    if _lib is not None:
+        raise GobbletHipError("use_library() after the library has been loaded")
+    LIB_PATH, _FOREIGN = os.path.abspath(path), True
+
+
 def needs_build() -> bool:
-    if os.environ.get("GOBBLET_HIP_LIB"):
+    if _FOREIGN:
         return not os.path.exists(LIB_PATH)
     if not os.path.exists(LIB_PATH):
         return True

@@ -44,10 +44,7 @@ __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t
 // Measured (fused kernel): -2.5 % time at 2^20 boards, where the working set lives in the Infinity
 // Cache, but +7 % at 2^22, where eight far-apart write fronts cost more in HBM than the shared
 // lines save -- so batches beyond 2^21 boards keep the identity map.
-#ifndef GBL_XCD_REMAP_MAX_TILES
-#define GBL_XCD_REMAP_MAX_TILES ((int64_t)1 << 15)
-#endif
-constexpr int64_t kXcdRemapMaxTiles = GBL_XCD_REMAP_MAX_TILES;
+constexpr int64_t kXcdRemapMaxTiles = (int64_t)1 << 15;
 
 __device__ __forceinline__ int64_t xcd_tile(uint32_t bid, int64_t ntiles)
 {

@@ -58,10 +58,7 @@ inline Geometry block_geometry(int64_t n, int nt)
 
 // Wavefronts per workgroup of the step kernels.  The wavefronts of a workgroup are independent (a tile and an LDS
 // image each, no barrier); a workgroup is only the unit of dispatch.
-#ifndef GBL_WG_WAVES
-#define GBL_WG_WAVES 1
-#endif
-constexpr int kStepWaves = GBL_WG_WAVES;
+constexpr int kStepWaves = 1;  // (128- and 256-thread workgroups: +-1-2 %, round 1)
 
 // Non-temporal store policy of the step kernels (see store_rows): stream the observation always, the
 // mask too once one ply's footprint exceeds the 256 MiB Infinity Cache.  A pure function of the batch size: the
@@ -580,16 +577,13 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_rollout(int8_t *__restrict_
 // lane's bit planes for all plies, and is stored once; a wavefront's stores of ply t drain while it computes
 // ply t + 1, there is no kernel boundary, no launch ramp and no state traffic between plies, and the legal mask
 // stored for the next mover is the one the next ply samples from (computed once).
-#ifndef GBL_X_COLLECT_WAVES
-#define GBL_X_COLLECT_WAVES 1
-#endif
 // NT: the trajectory rows are stored with the non-temporal hint (a trajectory larger than the Infinity Cache is a
 // write-once stream to HBM: 2^20 boards x 8 plies 34.6 vs 45.0 us per ply) or plainly (a trajectory that fits the
 // 256 MiB cache stays there for whoever reads it next and is overwritten there by the next launch: 131 072 boards x 8
 // plies 4.15 vs 4.76 us per ply, 262 144 x 4: 8.5 vs 9.5 -- but 65 536 x 16: 2.44 vs 2.12); the host decides by the
 // footprint in A/B builds only (gpurun_out/ab5, scripts/sweep_sizes.py with -DGBL_FORCE_COLLECT_NT=0|1); the product streams.
 template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY, bool NT>
-__global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n,
+__global__ __launch_bounds__(64) void k_collect(int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n,
                                                 int64_t ntiles, uint64_t seed, uint64_t env_base,
                                                 const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies,
                                                 int8_t *__restrict__ done, int64_t ply_stride, int64_t tile_stride,
@@ -606,13 +600,9 @@ __global__ __launch_bounds__(64, GBL_X_COLLECT_WAVES) void k_collect(int8_t *__r
     GBL_STAMP_REAL(0);
     if (DEV_PLY) ply0 += *ply_dev;
     Lane L;
-#ifdef GBL_X_COLLECT_REMAP
-    if (!lane_setup(L, n, ntiles)) return;
-#else
     // identity block -> tile map: the trajectory is written once and streams to HBM, where ONE write front per
     // array beats eight (one per XCD) -- unlike the single-ply kernels, whose outputs are rewritten every launch
     if (!lane_setup<1, false>(L, n, ntiles)) return;
-#endif
     int mover = to_move[L.valid ? L.b : n - 1];
     // gbl_collect_from: the first ply plays the caller's actions (an external policy), the others are sampled
     int given = first_actions ? first_actions[L.valid ? L.b : n - 1] : 0;
@@ -1249,6 +1239,7 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
 }
 
 // wavefronts of a workgroup of the role kernel: the scalars wavefront, the mask wavefront unless merged, KO observation wavefronts
+// (KO = 0, MERGE: ONE wavefront per group holds all three roles -- A/B builds only, see scripts/ab_oneply.py)
 template <bool WITH_MASK, bool WITH_OBS, int KO, bool MERGE>
 constexpr int small_waves() { return 1 + ((WITH_MASK && !MERGE) ? 1 : 0) + (WITH_OBS ? KO : 0); }
 
@@ -1263,12 +1254,12 @@ __global__ __launch_bounds__((64 * small_waves<WITH_MASK, WITH_OBS, KO, MERGE>()
     int8_t *__restrict__ done_t, int8_t *__restrict__ to_move_t, int8_t *__restrict__ mask_t, int8_t *__restrict__ obs_t,
     int illegal_mode, int64_t *__restrict__ counters, int32_t *__restrict__ turn, const int32_t *__restrict__ first_actions)
 {
-    static_assert(LA * KO <= 4, "at most four lanes per board");
+    static_assert(LA * KO <= 4 && (KO > 0 || MERGE), "at most four lanes per board");
     constexpr int WAVES = small_waves<WITH_MASK, WITH_OBS, KO, MERGE>(), NA = WAVES - (WITH_OBS ? KO : 0);
-    constexpr int GB = kTile / LA, LO = LA * KO, OBB = kTile / LO;  // boards per group; observation wavefronts: LO lanes per board, OBB boards
+    constexpr int GB = kTile / LA, LO = LA * (KO ? KO : 1), OBB = kTile / LO;  // boards per group; observation wavefronts: LO lanes per board, OBB boards
     constexpr int kStateWords = GB * kCells / 4 + 4, kObsWords = OBB * kObs / 4 + 4, kMaskWords = GB * kActions / 4 + 4;
     __shared__ uint32_t s_state[WAVES][kStateWords];
-    __shared__ uint32_t s_obs[WITH_OBS ? KO : 1][WITH_OBS ? kObsWords : 4];
+    __shared__ uint32_t s_obs[WITH_OBS && KO ? KO : 1][WITH_OBS ? kObsWords : 4];
     __shared__ uint32_t s_mask[WITH_MASK ? kMaskWords : 4];
     __shared__ uint4 s_draw[LO > 1 ? WAVES : 1][LO > 1 ? 64 : 1];  // the sampler's words of 4 LPB plies, 16 bytes per lane
     if (DEV_PLY) ply0 += *ply_dev;
@@ -1279,8 +1270,8 @@ __global__ __launch_bounds__((64 * small_waves<WITH_MASK, WITH_OBS, KO, MERGE>()
                       done_t, to_move_t, mask_t, obs_t, illegal_mode, counters, turn, first_actions};
     constexpr bool SYNC = WAVES > 1;
     if (wave == 0) {
-        small_role<kRoleScalars | ((WITH_MASK && MERGE) ? kRoleMask : 0), LA, SYNC>(A, s_state[0], s_mask, nullptr,
-                                                                                    reinterpret_cast<uint32_t *>(s_draw[0]), group);
+        small_role<kRoleScalars | ((WITH_MASK && MERGE) ? kRoleMask : 0) | ((WITH_OBS && KO == 0) ? kRoleObs : 0), LA, SYNC>(
+            A, s_state[0], s_mask, s_obs[0], reinterpret_cast<uint32_t *>(s_draw[0]), group);
         return;
     }
     if constexpr (WITH_MASK && !MERGE) {
@@ -1289,7 +1280,7 @@ __global__ __launch_bounds__((64 * small_waves<WITH_MASK, WITH_OBS, KO, MERGE>()
             return;
         }
     }
-    if constexpr (WITH_OBS)
+    if constexpr (WITH_OBS && KO > 0)
         small_role<kRoleObs, LO, SYNC>(A, s_state[wave], nullptr, s_obs[wave - NA], reinterpret_cast<uint32_t *>(s_draw[LO > 1 ? wave : 0]),
                                        group * KO + (wave - NA));
 }
@@ -1585,11 +1576,7 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
     // 10.65 -> 10.02 (gbl_collect_policy 10.67 -> 10.10 per ply); <4,16> at 65 536: 12.05 -> 12.25 and <1,4> at 2^20: 143.3 -> 144.8
     // -- blocks that fill their SIMDs pay for the sixteen (four) copies of the split more than the barrier cost them: they keep
     // round 4's flow (kListerPlan false).
-#ifndef GBL_X_LISTER_PLAN
     constexpr bool kListerPlan = (NT == 1 && W >= 8) || (NT == 2);
-#else
-    constexpr bool kListerPlan = (GBL_X_LISTER_PLAN) != 0;
-#endif
     if (kListerPlan && owner && deep) S.work[bi] = two ? (h.todo & ~h.dup) : 0ull;
     auto plan_of = [&](int bn) {
         const unsigned long long w0 = S.work[bn];
@@ -1618,10 +1605,7 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
         // (D) the work lists: W / NT wavefronts share a tile's 54 candidate steps, and the owners take their tile's 6 rank
         // steps on top
         // (fewer listers with longer per-lane loops lose: two per tile +2 %, one per tile +12 % at 65 536 boards)
-#ifndef GBL_X_LISTERS
-#define GBL_X_LISTERS 64
-#endif
-        constexpr int kWavesPerTile = W / NT < GBL_X_LISTERS ? W / NT : GBL_X_LISTERS, kSteps = (kActions + kWavesPerTile - 1) / kWavesPerTile;
+        constexpr int kWavesPerTile = W / NT, kSteps = (kActions + kWavesPerTile - 1) / kWavesPerTile;
         if (const int lw = wave - (W - NT * kWavesPerTile); lw >= 0 && !(kSkip & 4)) {  // (the last wavefronts: the owners come out of the plan last)
             const int g = lw / kWavesPerTile, c0 = (lw % kWavesPerTile) * kSteps;  // (a wavefront's steps stay inside one tile)
             if (c0 < kActions) {
@@ -1855,9 +1839,6 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
 // The owner wavefronts do everything but the shared depth-2 work.
 // (Register budget: four wavefronts per SIMD = 128 VGPRs.  Left alone the compiler takes ~160 -- the ply loop keeps the
 // decision's literal constants live across iterations -- which costs a wavefront of occupancy for nothing.)
-#ifndef GBL_X_POLICY16_CALL
-#define GBL_X_POLICY16_CALL 0  // (A/B: <4,16> behind greedy_tile_call; inlined it holds exactly its 128 VGPRs and is 5 % faster)
-#endif
 #ifndef GBL_CP_WAVES_PER_EU
 #define GBL_CP_WAVES_PER_EU 4
 #endif
@@ -1926,7 +1907,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
         // (one tile per workgroup: behind a call, see greedy_tile_call -- 12.6 -> 11.6 us per ply at 16 384 boards, 79 -> 71 at
         // 262 144; blocks of tiles inlined: <2,8> has the registers, <4,16> exactly its 128 since round 4 -- table above policy_shape)
         GreedyResult g;
-        if constexpr ((NT == 1 && W > 1) || (W >= 16 && GBL_X_POLICY16_CALL))
+        if constexpr (NT == 1 && W > 1)  // (<4,16> inlined holds exactly its 128 VGPRs and is 5 % faster than behind the call)
             g = greedy_tile_call<NT, W>(S, p, mover, gre ? legal : 0ull, pol, deep, prev3);
         else
             g = greedy_tile<NT, W>(S, p, mover, gre ? legal : 0ull, pol, deep, prev3, ts);
@@ -2067,6 +2048,9 @@ bool launch_small(int cfg, int8_t *state, int8_t *to_move, int8_t *done, const i
     GBL_SMALL_CFG(2, 2, true)
     GBL_SMALL_CFG(2, 1, true)
     GBL_SMALL_CFG(4, 1, true)
+    GBL_SMALL_CFG(4, 0, true)
+    GBL_SMALL_CFG(2, 0, true)
+    GBL_SMALL_CFG(1, 0, true)
 #endif
 #undef GBL_SMALL_CFG
 #undef GBL_SMALL_D

@@ -12,6 +12,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gobblet_rl_amd as G  # noqa: E402
 
+if os.environ.get("GOBBLET_HIP_LIB"):  # an experiment's own build of the library (scripts/build_variant.sh)
+    G._native.use_library(os.environ["GOBBLET_HIP_LIB"])
+
 n = int(sys.argv[1])
 paths = sys.argv[2:]
 nat = G._native
@@ -44,14 +47,31 @@ for i in range(1, len(libs)):
         print(paths[i], "boards with another decision:", int((outs[0][0] != outs[i][0]).sum()), flush=True)
     else:
         assert all(torch.equal(x, y) for x, y in zip(outs[0], outs[i])), paths[i]
+# `iters` launches per library as one hipGraph (AB_EAGER=1: eager launches, as rounds 2-4 timed it -- a floor build's kernel is
+# shorter than the host's launch rate of ~7 us, which eager timing then reports instead)
+graphs = []
+for i in range(len(libs)):
+    if os.environ.get("AB_EAGER"):
+        graphs.append(None)
+        continue
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            run(i)
+    g.replay()
+    graphs.append(g)
+torch.cuda.synchronize()
 res = [[] for _ in libs]
 for rnd in range(7):
     for i in range(len(libs)):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         run(i)
         a.record()
-        for _ in range(iters):
-            run(i)
+        if graphs[i] is None:
+            for _ in range(iters):
+                run(i)
+        else:
+            graphs[i].replay()
         b.record()
         torch.cuda.synchronize()
         res[i].append(a.elapsed_time(b) * 1e3 / iters)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Build a differently configured library of the same ABI for A/B runs (GOBBLET_HIP_LIB=build/lib_NAME.so):
+# Build a differently configured library of the same ABI for A/B runs (the scripts under scripts/ load it when GOBBLET_HIP_LIB=build/lib_NAME.so is set):
 #   scripts/build_variant.sh NAME [-DGBL_... ...]
 set -e
 name=$1; shift

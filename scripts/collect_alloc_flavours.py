@@ -13,6 +13,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gobblet_rl_amd as G  # noqa: E402
 
+if os.environ.get("GOBBLET_HIP_LIB"):  # an experiment's own build of the library (scripts/build_variant.sh)
+    G._native.use_library(os.environ["GOBBLET_HIP_LIB"])
+
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 nat, L = G._native, G._native.lib()

@@ -2,6 +2,9 @@ import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, '/root/repo')
 import gobblet_rl_amd as G
+
+if os.environ.get("GOBBLET_HIP_LIB"):  # an experiment's own build of the library (scripts/build_variant.sh)
+    G._native.use_library(os.environ["GOBBLET_HIP_LIB"])
 boards=65536
 nat, L = G._native, G._native.lib()
 env = G.BatchedGobblet(boards, "cuda:0", auto_reset=True, seed=0); env.rollout(64)

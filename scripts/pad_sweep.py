@@ -11,6 +11,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gobblet_rl_amd as G  # noqa: E402
 
+if os.environ.get("GOBBLET_HIP_LIB"):  # an experiment's own build of the library (scripts/build_variant.sh)
+    G._native.use_library(os.environ["GOBBLET_HIP_LIB"])
+
 n, T = int(sys.argv[1]), int(sys.argv[2])
 env = G.BatchedGobblet(n, "cuda:0", auto_reset=True, seed=0)
 env.rollout(64)

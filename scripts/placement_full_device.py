@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 import gobblet_rl_amd as G  # noqa: E402
 
+if os.environ.get("GOBBLET_HIP_LIB"):  # an experiment's own build of the library (scripts/build_variant.sh)
+    G._native.use_library(os.environ["GOBBLET_HIP_LIB"])
+
 taken = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 dev = torch.device("cuda:0")
 hog = torch.empty(taken << 30, dtype=torch.uint8, device=dev)

@@ -20,6 +20,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gobblet_rl_amd as G  # noqa: E402
 
+if os.environ.get("GOBBLET_HIP_LIB"):  # an experiment's own build of the library (scripts/build_variant.sh)
+    G._native.use_library(os.environ["GOBBLET_HIP_LIB"])
+
 
 def main():
     ap = argparse.ArgumentParser()
