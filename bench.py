@@ -170,9 +170,39 @@ def cpu_baseline(boards, warmup, target_s):
     oracle.batch_greedy(s[:k].copy(), tm[:k].copy(), depth=2)
     dg = time.perf_counter() - t0
     tests, leaves = oracle.greedy_work()
+    # ... and the build's own CPU TWIN: the host flavour of the ABI (gbl_cpu_collect: the device header compiled
+    # for the host, include/gobblet_cpu.h), the same pipeline with every ply materialised, all cores and one
+    twin = {}
+    try:
+        import torch  # noqa: F401
+
+        import gobblet_rl_amd as G
+        raw = G._native.cpu_raw()
+        nt = min(n, 1 << 17)
+        tenv = G.BatchedGobblet(nt, "cpu", auto_reset=True, seed=0)
+        tenv.rollout(warmup)
+        T = 8
+        tbuf = tenv.trajectory_buffers(T, placement="any")
+        raw.gbl_cpu_set_threads(cores)
+        tenv.collect(T, out=tbuf, refresh=False)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < max(1.0, target_s / 4):
+            tenv.collect(T, out=tbuf, refresh=False)
+            reps += 1
+        dtw = time.perf_counter() - t0
+        raw.gbl_cpu_set_threads(1)
+        t0 = time.perf_counter()
+        tenv.collect(T, out=tbuf, refresh=False)
+        d1w = time.perf_counter() - t0
+        raw.gbl_cpu_set_threads(0)
+        twin = {"twin_value": nt * T * reps / dtw, "twin_value_1core": nt * T / d1w,
+                "twin_sample": f"{nt} boards x {T * reps} plies, gbl_cpu_collect (host flavour of the ABI), {cores} threads"}
+    except Exception as e:  # noqa: BLE001  (no C++ compiler on the box: the port's numbers stand alone)
+        twin = {"twin_value": None, "twin_error": str(e)[:200]}
     return {"value": n * plies / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{n} boards x {plies} plies (sample+step+mask+obs, auto-reset), C oracle, {cores} threads",
-            "value_1core": n1 * 4 / d1,
+            "value_1core": n1 * 4 / d1, **twin,
             "greedy_depth2": {"decisions_per_s_1core": k / dg, "sample": f"{k} positions, 1 thread",
                               "legality_tests_per_decision": tests / k, "leaf_evaluations_per_decision": leaves / k}}
 
@@ -528,7 +558,7 @@ def greedy_collect_run(G, torch, dev, boards=65536, T=16, launches=8, policies=(
 COMPACT_LIMIT = 4096  # bytes: the driver keeps the tail of stdout only; the contract line must fit it with room to spare
 ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel",
                  "algorithmic_bytes_per_env_step", "algorithmic_bytes_per_launch", "mean_launch_us", "launches_timed", "timing")
-CPU_BASELINE_KEYS = ("value", "unit", "cores", "kind", "sample", "value_1core")
+CPU_BASELINE_KEYS = ("value", "unit", "cores", "kind", "sample", "value_1core", "twin_value", "twin_value_1core")
 
 
 def contract_record(args, p, roof, total, boards, world, K, W, elapsed, local_elapsed, nlaunch, graphed, per_rank_us,

@@ -174,5 +174,103 @@ def ptr(t) -> int | None:
     return None if t is None else t.data_ptr()
 
 
-def current_stream(device) -> int:
+def current_stream(device):
+    """The caller's HIP stream on `device` as a plain pointer (None on the host flavour: its calls are synchronous)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return None
     return torch.cuda.current_stream(device).cuda_stream
+
+
+# ---- the HOST flavour of the ABI (include/gobblet_cpu.h, csrc/gobblet_cpu.cpp): gbl_cpu_* -------------------------------------
+# A flavour the caller ASKS for (device="cpu": BASELINE config 1 "on CPU", bench.py's CPU twin), never a fallback of the HIP
+# path: a "cuda" device without the HIP library still raises.  Built with g++ from the same device header.
+CPU_LIB_PATH = os.path.join(CSRC, "libgobblet_cpu.so")
+CPU_SOURCES = [os.path.join(CSRC, "gobblet_cpu.cpp"), os.path.join(CSRC, "gobblet_device.h"),
+               os.path.join(_HERE, "..", "include", "gobblet_cpu.h"), os.path.join(_HERE, "..", "include", "gobblet_hip.h")]
+CPU_CXX_FLAGS = ["-O3", "-std=c++17", "-mpopcnt", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", "-Wno-attributes"]
+_NO_HOST_FLAVOUR = ("gbl_pinned_alloc", "gbl_pinned_free", "gbl_block_alloc", "gbl_block_free", "gbl_device_memory",
+                    "gbl_placement_probe", "gbl_collect_variant")
+CPU_SIGNATURES = {"gbl_cpu_" + k[4:]: v for k, v in SIGNATURES.items() if k not in _NO_HOST_FLAVOUR}
+CPU_SIGNATURES["gbl_cpu_set_threads"] = (_int, [_int])
+
+
+def build_cpu(force: bool = False) -> str:
+    """Compile the host flavour in-tree (g++; no GPU toolchain needed)."""
+    def stale():
+        return not os.path.exists(CPU_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(CPU_LIB_PATH) for s in CPU_SOURCES)
+    if not force and not stale():
+        return CPU_LIB_PATH
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise GobbletHipError("no C++ compiler found: cannot build csrc/libgobblet_cpu.so")
+    with open(CPU_LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or stale():
+                tmp = f"{CPU_LIB_PATH}.{os.getpid()}.tmp"
+                try:
+                    subprocess.check_call([cxx, *CPU_CXX_FLAGS, "-o", tmp, CPU_SOURCES[0]], cwd=CSRC, env=_compiler_env())
+                    os.replace(tmp, CPU_LIB_PATH)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return CPU_LIB_PATH
+
+
+_cpu_raw = None
+
+
+def cpu_raw() -> C.CDLL:
+    """libgobblet_cpu.so with typed gbl_cpu_* entry points (plain return codes)."""
+    global _cpu_raw
+    if _cpu_raw is None:
+        L = C.CDLL(build_cpu())
+        for name, (res, args) in CPU_SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _cpu_raw = L
+    return _cpu_raw
+
+
+class _HostFlavour:
+    """The host library under the DEVICE entry points' names (``gbl_step`` -> ``gbl_cpu_step``), so that the Python layer above
+    is the same code for either flavour.  A failing call raises here, with the host library's own message."""
+
+    def __init__(self, raw):
+        self._raw = raw
+
+    def __getattr__(self, name):
+        if not name.startswith("gbl_"):
+            raise AttributeError(name)
+        if name in _NO_HOST_FLAVOUR:
+            raise GobbletHipError(f"{name} has no host flavour (device-memory helper)")
+        fn = getattr(self._raw, "gbl_cpu_" + name[4:])
+        if fn.restype is not _int:
+            return fn
+
+        def call(*args):
+            rc = fn(*args)
+            if rc != OK:
+                raise GobbletHipError(f"{name} (host flavour) failed (code {rc}): "
+                                      f"{self._raw.gbl_cpu_last_error().decode('utf-8', 'replace')}")
+            return rc
+        setattr(self, name, call)
+        return call
+
+
+_cpu = None
+
+
+def lib_for(device):
+    """The library that serves `device`: the HIP library for a GPU, the host flavour for "cpu" (asked for, never fallen back to)."""
+    global _cpu
+    if torch.device(device).type == "cuda":
+        return lib()
+    if torch.device(device).type != "cpu":
+        raise GobbletHipError(f"no flavour of the library serves device {device!r}")
+    if _cpu is None:
+        _cpu = _HostFlavour(cpu_raw())
+    return _cpu

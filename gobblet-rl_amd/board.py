@@ -45,10 +45,10 @@ class BatchedBoard:
         if num_envs < 1:
             raise ValueError("num_envs must be >= 1")
         self.device = torch.device(device)
-        if self.device.type != "cuda":
-            raise nat.GobbletHipError("BatchedBoard needs a GPU device (there is no CPU fallback)")
+        # "cuda": the HIP library (it raises if it cannot be built or loaded: no fallback); "cpu": the host flavour of the same
+        # ABI (include/gobblet_cpu.h), which a caller has to ask for
         self.num_envs = int(num_envs)
-        self._lib = nat.lib()
+        self._lib = nat.lib_for(self.device)
         # board.py:33: np.zeros(27)
         self._squares = torch.zeros((self.num_envs, nat.CELLS), dtype=torch.int8, device=self.device)
         if squares is not None:

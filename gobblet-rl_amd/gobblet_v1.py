@@ -192,15 +192,44 @@ class _HipBoardEngine:
             return {k: v.copy() for k, v in self._fields.items()}
 
 
+class _HostBoardEngine:
+    """The same one-board engine on the HOST flavour of the ABI (``gbl_cpu_board_eval``, include/gobblet_cpu.h) -- what
+    ``env(device="cpu")`` runs on: BASELINE config 1 ("1 env ... on CPU, no GPU").  A flavour the caller asks for, never a
+    fallback of the HIP path."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._lib = nat.lib_for(self.device)
+        self._block = np.zeros(_HipBoardEngine._BYTES, np.int8)
+        self._record = self._block[:nat.REC_BYTES]
+        self._state = self._block[_HipBoardEngine._STATE:_HipBoardEngine._STATE + 27]
+        self._action = self._block[_HipBoardEngine._ACTION:_HipBoardEngine._ACTION + 4].view(np.int32)
+        self._agent = self._block[_HipBoardEngine._AGENT:_HipBoardEngine._AGENT + 1]
+        self._fields = {k: self._record[o:o + size] for k, (o, size) in nat.REC_FIELDS.items()}
+        self._lock = threading.Lock()
+
+    def evaluate(self, squares, agent_index=None, action=None) -> dict:
+        with self._lock:
+            self._state[:] = squares
+            base = self._block.ctypes.data
+            if action is None:
+                self._lib.gbl_board_eval(base + _HipBoardEngine._STATE, None, None, base, 1, None)
+            else:
+                self._action[0], self._agent[0] = action, agent_index
+                self._lib.gbl_board_eval(base + _HipBoardEngine._STATE, base + _HipBoardEngine._AGENT,
+                                         base + _HipBoardEngine._ACTION, base, 1, None)
+            return {k: v.copy() for k, v in self._fields.items()}
+
+
 _ENGINES: dict = {}
 
 
 def _new_backend(device):
-    """The engine of a ``Board``: always the HIP library, one per device.  (Module-level so that the CPU-only
-    host-logic tests can monkeypatch it; nothing in the package does.)"""
+    """The engine of a ``Board``: the HIP library for a GPU device, the host flavour of the same ABI for "cpu" -- one per
+    device.  (Module-level so that the host-logic tests can monkeypatch it; nothing in the package does.)"""
     key = str(torch.device(device))
     if key not in _ENGINES:
-        _ENGINES[key] = _HipBoardEngine(device)
+        _ENGINES[key] = _HipBoardEngine(device) if torch.device(device).type == "cuda" else _HostBoardEngine(device)
     return _ENGINES[key]
 
 

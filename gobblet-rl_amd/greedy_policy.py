@@ -36,9 +36,7 @@ class GreedyGobbletPolicy:
         self.seed = int(seed or 0)
         self.env_base = int(env_base)
         self.device = torch.device(device)
-        if self.device.type != "cuda":
-            raise nat.GobbletHipError("GreedyGobbletPolicy needs a GPU device (there is no CPU fallback)")
-        self._lib = nat.lib()
+        self._lib = nat.lib_for(self.device)  # ("cpu": the host flavour of the ABI, asked for -- never a fallback)
         self.prev_actions = None  # int8 (N, 2, 3) on device: last three own actions per agent, -1 = none
         self._calls, self._calls_dev = 0, None  # call index (keys the fallback draw); see device_calls()
         # outputs of the last call (device tensors): chosen-or--1, candidate set, fallback flag

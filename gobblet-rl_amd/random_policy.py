@@ -13,9 +13,7 @@ class RandomAdmissiblePolicy:
     def __init__(self, seed: int = 0, device="cuda:0", env_base: int = 0):
         self.seed, self.env_base = int(seed), int(env_base)
         self.device = torch.device(device)
-        if self.device.type != "cuda":
-            raise nat.GobbletHipError("RandomAdmissiblePolicy needs a GPU device (there is no CPU fallback)")
-        self._lib = nat.lib()
+        self._lib = nat.lib_for(self.device)  # ("cpu": the host flavour of the ABI, asked for -- never a fallback)
         self._calls, self._calls_dev = 0, None
 
     def device_calls(self, enable: bool = True) -> None:

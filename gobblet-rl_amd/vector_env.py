@@ -40,7 +40,7 @@ class BatchedGobblet:
         self.board = BatchedBoard(num_envs, device)
         self.device = self.board.device
         self.num_envs = self.board.num_envs
-        self._lib = nat.lib()
+        self._lib = nat.lib_for(self.device)
         modes = {"noop": nat.ILLEGAL_NOOP, "terminate": nat.ILLEGAL_TERMINATE, 0: 0, 1: 1}
         if illegal_mode not in modes:
             raise ValueError("illegal_mode must be 'noop' or 'terminate'")
@@ -274,7 +274,7 @@ class BatchedGobblet:
             return torch.zeros(lead + (nat.ACTIONS,), dtype=torch.int8, device=dev)
 
         cells = T * ply_stride if layout == "time" else tiles * T * 64
-        probeable = self.observation is not None and cells * nat.ACTIONS >= _placement.MIN_BYTES
+        probeable = dev.type == "cuda" and self.observation is not None and cells * nat.ACTIONS >= _placement.MIN_BYTES
         if placement == "spread" and not probeable:
             raise ValueError("placement='spread' needs an observation trajectory and at least 64 MiB of mask trajectory")
         capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
@@ -305,7 +305,8 @@ class BatchedGobblet:
                 full["observation"] = make_obs()
             full["action_mask"] = make_mask()
             if placement != "any":
-                placed["why"] = "arrays too small to probe" if self.observation is not None else "no observation stream"
+                placed["why"] = ("host memory" if dev.type != "cuda" else
+                                 "arrays too small to probe" if self.observation is not None else "no observation stream")
         extra = ((("chosen", torch.int32, ()), ("how", torch.int8, ())) if policy_outputs else ()) + \
                 ((("candidates", torch.int8, (nat.ACTIONS,)),) if candidates else ())
         for key, dtype, tail in (("actions", torch.int32, ()), ("winner", torch.int8, ()), ("rewards", torch.int8, (2,)),
