@@ -111,8 +111,8 @@ def test_host_flavour_header_symbols_all_exported():
     dev_hdr = open(os.path.join(ROOT, "include", "gobblet_hip.h")).read()
     for name in declared - {"gbl_cpu_set_threads"}:
         dev = "gbl_" + name[len("gbl_cpu_"):]
-        a = re.search(r"\b" + dev + r"\(([^;]*)\);", dev_hdr).group(1)
-        b = re.search(r"\b" + name + r"\(([^;]*)\);", hdr).group(1)
+        a = re.search(r"^(?:const char \*|int )" + dev + r"\(([^;]*)\);", dev_hdr, re.M).group(1)
+        b = re.search(r"^(?:const char \*|int )" + name + r"\(([^;]*)\);", hdr, re.M).group(1)
         assert re.sub(r"\s+", " ", a) == re.sub(r"\s+", " ", b), name
     info = (C.c_int32 * 6)()
     assert L.gbl_cpu_layout_info(info) == 0 and list(info)[:5] == [1, 27, 54, 117, 64]
