@@ -216,7 +216,9 @@ def auto_traj(boards, steps, requested=0):
         return max(1, min(requested, steps))
     if steps <= 32:
         return max(1, steps)
-    return 8 if boards >= (1 << 19) else 16 if boards >= (1 << 18) else 32
+    # (round 5: at 2^22 boards 4 plies per launch run 110.6 us per ply, 8 plies 126.3, 16 plies 122.1 -- with T slots of every array
+    #  open at once, 490 MB apart, the write stream loses DRAM page locality; profiles/r05/large_plies_per_launch.txt)
+    return 4 if boards >= (1 << 21) else 8 if boards >= (1 << 19) else 16 if boards >= (1 << 18) else 32
 
 
 def kernel_source_hash():

@@ -184,6 +184,25 @@ __device__ __forceinline__ Planes planes_of(const Lane &L, const uint32_t (&r)[7
     return p;
 }
 
+// A lane's 54 mask bytes into its row of a tile's LDS image.  STAGED: the row is shifted onto aligned dwords in registers
+// (row_stage: ~45 v_alignbyte / select instructions and a DPP fetch of the neighbour's bytes), every LDS access an aligned dword.
+// Otherwise: 14 nibble expansions and four UNALIGNED LDS stores (rows are 2-byte aligned; gfx950 takes them) -- 45 VALU
+// instructions less, more LDS passes.  Measured (round 5, profiles/r05/ab_maskrow.txt): the one-wavefront kernels, which are bound
+// by what ONE wavefront issues, gain -- k_collect MASK_ONLY at 2^20 boards 10.88 -> 10.06 us per ply (0.80 -> 0.87 of the HBM peak),
+// FULL and the one-ply kernels +-1 % -- while k_collect2, whose storing wavefront reads the image back beside the player's writes,
+// loses (MASK_ONLY 0.92 -> 1.13 us per ply at 65 536 boards, 1.39 -> 1.69 at 131 072): it and the greedy kernels stay staged.
+template <bool STAGED>
+__device__ __forceinline__ void mask_to_image(uint32_t *img, int lane, uint64_t bits)
+{
+    if constexpr (STAGED) {
+        uint32_t d[14];
+        mask_row(bits, d);
+        row_stage<kActions>(img, lane, d);
+    } else {
+        mask_row_part<1>(reinterpret_cast<uint8_t *>(img) + lane * kActions, bits, 0);
+    }
+}
+
 // -------------------------------------------------------------------------------------------
 // Board-level kernels (one reference function each)
 
@@ -198,9 +217,7 @@ __global__ __launch_bounds__(64) void k_legal_mask(const int8_t *__restrict__ st
     load_state(state, s_state, L, r);
     Planes p = planes_of(L, r);
     int mover = L.valid ? to_move[L.b] : 0;
-    uint32_t d[14];
-    mask_row(legal54(p, mover != 0), d);
-    row_stage<kActions>(s_mask, L.lane, d);
+    mask_to_image<false>(s_mask, L.lane, legal54(p, mover != 0));
     wave_lds_fence();
     tile_out<kActions>(mask + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
 }
@@ -414,9 +431,7 @@ __device__ __forceinline__ void store_obs(uint32_t *img, const Lane &L, const Pl
 template <int NT>
 __device__ __forceinline__ void store_mask(uint32_t *img, const Lane &L, uint64_t legal, int8_t *__restrict__ mask_tile)
 {
-    uint32_t d[14];
-    mask_row(legal, d);
-    row_stage<kActions>(img, L.lane, d);
+    mask_to_image<false>(img, L.lane, legal);
     wave_lds_fence();
     tile_out<kActions, NT>(mask_tile, img, L.lane, L.rows);
     wave_lds_fence();
@@ -789,11 +804,7 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
         s_small[L.lane][1] = ((uint32_t)y.winner & 0xFFu) | (((uint32_t)y.r0 & 0xFFu) << 8) | (((uint32_t)y.r1 & 0xFFu) << 16) |
                              ((uint32_t)dn << 24) | ((uint32_t)mover << 25);
         if (WITH_OBS) obs_scatter(s_obs, L.lane, p, mover);  // (into the zeroed image)
-        if (WITH_MASK) {
-            uint32_t d[14];
-            mask_row(legal, d);
-            row_stage<kActions>(s_mask, L.lane, d);
-        }
+        if (WITH_MASK) mask_to_image<true>(s_mask, L.lane, legal);
         pair_barrier();  // images ready
     }
     pair_barrier();  // (the last ply's images taken: pairs with the storing wavefront's second barrier)
@@ -1804,9 +1815,7 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
     GBL_STAMP_VAL(3, ts.t[2]);
     if (!owner || L.rows == 0) return;
     if (cand_out && !(GBL_X_GREEDY_SKIP & 16)) {
-        uint32_t d[14];
-        mask_row(g.cands, d);
-        row_stage<kActions>(s_mask, L.lane, d);
+        mask_to_image<true>(s_mask, L.lane, g.cands);
         wave_lds_fence();
         tile_out<kActions>(cand_out + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
     }
@@ -1967,9 +1976,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
         asm volatile("" : "+v"(ol));
 #endif
         auto mask_rows = [&](uint64_t bits, int8_t *__restrict__ dst) {  // (store_mask / store_obs with few registers)
-            uint32_t d[14];
-            mask_row(bits, d);
-            row_stage<kActions>(s_out, ol, d);
+            mask_to_image<true>(s_out, ol, bits);
             wave_lds_fence();
             tile_out_narrow<kActions, kPolicy, 2>(dst, s_out, ol, L.rows);
             wave_lds_fence();
