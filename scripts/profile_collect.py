@@ -70,12 +70,15 @@ def main():
     khash = kernel_source_hash()
     for name in ("bench_default", "bench_driver_cmd", "bench_single_ply", "bench_stepmode", "bench_maskonly",
                  "bench_c4_shard_131072", "greedy_65536", "greedy_1048576", "greedy_policy", "playouts"):
+        if not os.path.exists(os.path.join(SRC, name + ".json")):  # (a trimmed round: scripts/profile_round.sh r5a / r5b)
+            continue
         shutil.copy(os.path.join(SRC, name + ".json"), os.path.join(dst, name + ".json"))
         if os.path.exists(os.path.join(SRC, name + "_full.json")):  # (bench.py: the full record behind the compact line)
             shutil.copy(os.path.join(SRC, name + "_full.json"), os.path.join(dst, name + "_full.json"))
     for name in ("facade.txt", "valu_rates.txt", "winner_lanes.txt", "write_classes.txt", "placement_probe_check.txt",
                  "placement_ab.txt", "soak_parity.txt", "wave_placement.txt", "valu_mix.txt", "reply_rate.txt",
-                 "greedy_wave_stamps.txt", "icache_cold.txt", "flag_sync.txt", "policy_wave_stamps.txt"):
+                 "greedy_wave_stamps.txt", "icache_cold.txt", "flag_sync.txt", "policy_wave_stamps.txt", "role_phase_stamps.txt",
+                 "greedy_floor.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
     # instruction-cache counters of k_greedy at 65 536 and 2^20 boards: the kernel's rows only
@@ -101,6 +104,10 @@ def main():
     # run name (scripts/profile_round.sh: pmc_runs.txt) -> (key bench.py looks up, kernel name substring)
     runs = {"collect_T8": ("collect:1048576:T8", "k_collect<true, true"), "collect_T20": ("collect:1048576:T20", "k_collect<true, true"),
             "collect_4096_T32": ("collect:4096:T32", "k_collect_small<true, true"),
+            "collect_16384_T32": ("collect:16384:T32", "k_collect_small<true, true"),
+            "collect_32768_T32": ("collect:32768:T32", "k_collect3<true, true"),
+            "collect_65536_T32": ("collect:65536:T32", "k_collect2<true, true"),
+            "collect_4194304_T4": ("collect:4194304:T4", "k_collect<true, true"),
             "collect_131072_T32": ("collect:131072:T32", "k_collect2<true, true"),
             "collect_131072_T20": ("collect:131072:T20", "k_collect2<true, true"),
             "collect_262144_T16": ("collect:262144:T16", "k_collect<true, true"),
@@ -152,7 +159,8 @@ def main():
         print(sq)
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print(open(os.path.join(dst, "pmc_summary.csv")).read())
-    print(open(os.path.join(dst, "kernel_durations_by_size.csv")).read())
+    if os.path.exists(os.path.join(dst, "kernel_durations_by_size.csv")):
+        print(open(os.path.join(dst, "kernel_durations_by_size.csv")).read())
     print(json.dumps({k: v.get("hbm_bytes_per_launch", v.get("SQ_INSTS_VALU")) for k, v in traffic.items()}))
 
 

@@ -15,7 +15,7 @@ for m in valu_rates valu_mix icache_cold winner_lanes write_classes wave_placeme
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scripts/microbench/$m scripts/microbench/$m.hip >> $O/build_$STAGE.log 2>&1   # always rebuilt: a stale binary must never publish numbers
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gobblet-rl_amd/csrc -o scripts/microbench/reply_rate scripts/microbench/reply_rate.hip >> $O/build_$STAGE.log 2>&1
-[ "$STAGE" = b ] || scripts/build_variant.sh stamps -DGBL_STAMPS >> $O/build_$STAGE.log 2>&1   # (diagnostic build for the phase stamps)
+[ "$STAGE" = b ] || scripts/build_variant.sh stamps -DGBL_STAMPS -DGBL_AB_COLLECT_CFG >> $O/build_$STAGE.log 2>&1   # (diagnostic build for the phase stamps)
 bench_lines() {
 # stdout of bench.py is the compact contract line; the full record (sub-records, per-rank lists) goes to --configs-out
 python bench.py --configs-out $O/bench_default_full.json > $O/bench_default.json
@@ -47,10 +47,12 @@ scripts/microbench/reply_rate > $O/reply_rate.txt
 GOBBLET_HIP_LIB=build/lib_stamps.so python scripts/microbench/greedy_wave_stamps.py 65536 2> /dev/null > $O/greedy_wave_stamps.txt
 GOBBLET_HIP_LIB=build/lib_stamps.so python scripts/microbench/greedy_wave_stamps.py 1048576 2> /dev/null >> $O/greedy_wave_stamps.txt
 GOBBLET_HIP_LIB=build/lib_stamps.so python scripts/microbench/policy_wave_stamps.py 2> /dev/null > $O/policy_wave_stamps.txt || true
+for c in 220 120; do AB_LIB=build/lib_stamps.so python scripts/microbench/role_phase_stamps.py 4096 $c; done 2> /dev/null > $O/role_phase_stamps.txt || true
 scripts/microbench/winner_lanes > $O/winner_lanes.txt
 timeout -k 5 60 scripts/microbench/flag_sync > $O/flag_sync.txt
 scripts/microbench/dpp_scan >> $O/flag_sync.txt
 scripts/microbench/wave_placement 1024 28672 > $O/wave_placement.txt
+if [ -z "$SHORT" ]; then
 # ---- placement of the trajectory arrays -------------------------------------------------------
 scripts/microbench/write_classes 160 > $O/write_classes.txt
 scripts/microbench/write_classes 160 131072 32 | grep -v "^  policy" >> $O/write_classes.txt
@@ -71,13 +73,14 @@ done
 for i in 1 2 3; do
   python scripts/placement_full_device.py 200 >> $O/placement_ab.txt 2> /dev/null
 done
-python scripts/soak_parity.py 150 3 > $O/soak_parity.txt 2>&1
+fi   # SHORT
+python scripts/soak_parity.py ${SOAK_SECONDS:-150} 3 > $O/soak_parity.txt 2>&1
 echo "bench lines done"
 # ---- kernel traces (durations) ------------------------------------------------------------------------------
 rocprofv3 --kernel-trace --stats -d $O/collect_stats -o p -- python3 bench.py --steps 320 --no-configs --no-cpu-baseline > $O/collect_stats.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/single_stats -o p -- python3 bench.py --mode fused --steps 300 --no-configs --no-cpu-baseline > $O/single_stats.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/step_stats -o p -- python3 bench.py --mode step --steps 300 --no-configs --no-cpu-baseline > $O/step_stats.log 2>&1
-rocprofv3 --kernel-trace -d $O/sweep_trace -o p -- python3 scripts/sweep_sizes.py --sizes 4096,131072,262144,1048576 --modes full,mask,traj,trajmask --plies 128 --reps 2 > $O/sweep_trace.log 2>&1
+rocprofv3 --kernel-trace -d $O/sweep_trace -o p -- python3 scripts/sweep_sizes.py --sizes 4096,16384,32768,65536,131072,262144,1048576 --modes full,mask,traj,trajmask --plies 128 --reps 2 > $O/sweep_trace.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/greedy_stats -o p -- python3 scripts/run_eager.py greedy 65536 20 > $O/greedy_stats.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/policy_stats -o p -- python3 scripts/run_eager.py policy 65536 8 16 > $O/policy_stats.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/driver_stats -o p -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-configs --no-cpu-baseline > $O/driver_stats.log 2>&1
@@ -92,6 +95,10 @@ cat > $O/pmc_runs.txt <<EOT
 collect_T8 traj 1048576 6 8
 collect_T20 traj 1048576 4 20
 collect_4096_T32 traj 4096 6 32
+collect_16384_T32 traj 16384 6 32
+collect_32768_T32 traj 32768 6 32
+collect_65536_T32 traj 65536 6 32
+collect_4194304_T4 traj 4194304 4 4
 collect_131072_T32 traj 131072 6 32
 collect_131072_T20 traj 131072 6 20
 collect_262144_T16 traj 262144 6 16
