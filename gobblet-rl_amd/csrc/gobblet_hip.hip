@@ -100,7 +100,9 @@ inline int small_cfg(int64_t n, bool with_mask, bool with_obs)
 #else
     // (round 5, scripts/ab_roles.sh; DESIGN.md 5.2 has the table; 3 = k_collect3)
     if (!with_obs) return n <= 8192 ? 210 : n <= 57344 ? 3 : 0;
-    return n <= 8192 ? 220 : n <= 16384 ? 120 : n <= 36864 ? 3 : 0;
+    // (with the trajectory arrays placed across HBM's memory classes: 40 960 boards k_collect3 1.31 against k_collect2's 1.40 us per
+    //  ply, 49 152: 1.49 against 1.41 -- profiles/r05/placed_forms.txt)
+    return n <= 8192 ? 220 : n <= 16384 ? 120 : n <= 45056 ? 3 : 0;
 #endif
 }
 
@@ -1181,6 +1183,8 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
         return;
     }
     // ---- the playing wavefront: k_collect's loop with the scalars, without the rows -----------------------------------------
+    // (s_setprio 3 on the player, so that it wins the issue arbitration against the row wavefronts of its SIMD: no effect at any size,
+    //  profiles/r05/player_prio.txt)
     Lane L;
     L.tile = tile; L.lane = lane; L.rows = rows; L.valid = valid; L.b = b;
     int mover = to_move[valid ? b : n - 1];

@@ -28,7 +28,10 @@ for name in ("gbl_collect", "gbl_counter_add", "gbl_collect_variant"):
 L.gbl_ab_collect_cfg.argtypes = [C.c_int]
 env = G.BatchedGobblet(n, "cuda:0", auto_reset=True, seed=0, with_observation=streams != "mask")
 env.rollout(64)
-buf = env.trajectory_buffers(T, placement="any" if n < (1 << 19) else "auto")
+# (AB_PLACEMENT=auto: the arrays placed across HBM's memory classes as bench.py's are -- from ~49 152 boards x 32 plies the
+#  trajectory is an HBM stream and an unplaced pair costs every form alike 15-20 %)
+buf = env.trajectory_buffers(T, placement=os.environ.get("AB_PLACEMENT", "any" if n < (1 << 19) else "auto"))
+print("placement:", buf["_placement"].get("ratio"), buf["_placement"].get("ended", buf["_placement"].get("why")), flush=True)
 f = buf["_full"]
 scalars = ("actions", "winner", "rewards", "done", "to_move")
 keys = {"all": tuple(f), "mask": scalars + ("action_mask",), "none": (), "scalars": scalars}[streams]

@@ -8,7 +8,7 @@ instantiation each one reaches.  Bit-exact (integer / byte work).
     headline (2^20, collect)      gbl_collect, ply index on the device      k_collect<mask, obs, DEV_PLY, NT>, 8 and 20 plies per launch
     c2_4096                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 2, 2, false>  (<= 8 192 boards)
     c_16384                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 1, 2, false>  (<= 16 384 boards)
-    c_32768                       gbl_collect                               k_collect3<mask, obs, DEV_PLY>  (<= 36 864 boards)
+    c_32768                       gbl_collect                               k_collect3<mask, obs, DEV_PLY>  (<= 45 056 boards)
     c_65536                       gbl_collect                               k_collect2<mask, obs, DEV_PLY>
     c3_262144                     gbl_collect                               k_collect<mask, obs, DEV_PLY, NT>
     c4_shard_131072               gbl_collect                               k_collect2<mask, obs, DEV_PLY>  (2048 tiles)
@@ -277,7 +277,7 @@ def test_collect_from_external_first_ply_vs_oracle(G, n, T, illegal, with_obs):
 # group is partial, or empty) and whole ones
 SMALL_SIZES = [1, 15, 16, 17, 31, 33, 63, 65, 4096, 4099, 8192,   # FULL <2,2>: groups of 32 boards, two observation wavefronts of 16; MASK_ONLY <2,1>
                8193, 8209, 8241, 12321, 16384]                   # FULL <1,2>: a tile per scalars / mask wavefront, two observation wavefronts of 32
-TRIO_SIZES = [16385, 16447, 32768, 36864, 57344]                 # k_collect3 (FULL up to 36 864 boards; MASK_ONLY 8 193 ... 57 344)
+TRIO_SIZES = [16385, 16447, 32768, 45056, 57344]                 # k_collect3 (FULL up to 45 056 boards; MASK_ONLY 8 193 ... 57 344)
 
 
 @pytest.mark.parametrize("with_obs", [True, False], ids=["full", "maskonly"])
@@ -297,7 +297,7 @@ def test_trio_collect_vs_oracle(G, n, with_obs):
     """gbl_collect where k_collect3 runs (one playing wavefront per tile hands every ply's position to a mask-row and an
     observation-row wavefront: GBL_COLLECT_TRIO), against the oracle as above; ragged last tiles (1 and 63 rows) and whole ones."""
     variant = G._native.lib().gbl_collect_variant(n, 7, 1, int(with_obs))
-    assert variant == (3 if (n <= 36864 or not with_obs) else 2)  # (FULL beyond 36 864 boards: k_collect2, covered here too)
+    assert variant == (3 if (n <= 45056 or not with_obs) else 2)  # (FULL beyond 45 056 boards: k_collect2, covered here too)
     small_batch_case(G, n, with_obs)
 
 
