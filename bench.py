@@ -72,8 +72,10 @@ def collect_kernel_name(variant):
 # The sub-records of an N = 1 run: name -> (boards, timed plies, MASK_ONLY, mode).  tests/test_gpu_bench_kernels.py compares
 # the kernel instantiation each one times with the oracle, at the same batch size and through the same entry point.
 CONFIG_RECORDS = {
-    "c2_4096": (4096, 256, False, "collect"), "c_16384": (16384, 256, False, "collect"), "c_32768": (32768, 256, False, "collect"),
-    "c_65536": (65536, 256, False, "collect"), "c3_262144": (262144, 128, False, "collect"),
+    # (the latency-bound sizes replay 2 048 / 1 024 plies: a graph's first launch costs ~10 us, 5 % of a 256-ply replay at 4 096 boards
+    #  -- profiles/r05/burst_length.txt: 0.737 us per ply at 256 plies per replay, 0.703 at 2 048, 0.687 at 16 384)
+    "c2_4096": (4096, 2048, False, "collect"), "c_16384": (16384, 1024, False, "collect"), "c_32768": (32768, 1024, False, "collect"),
+    "c_65536": (65536, 512, False, "collect"), "c3_262144": (262144, 128, False, "collect"),
     "c4_shard_131072": (131072, 256, False, "collect"), "large_4194304": (1 << 22, 64, False, "collect"),
     "maskonly_1048576": (1 << 20, 64, True, "collect"),
     # round 1's pipeline, one launch per ply (gbl_rollout, 234 algorithmic bytes per env-step)

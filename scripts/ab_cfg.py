@@ -37,7 +37,7 @@ scalars = ("actions", "winner", "rewards", "done", "to_move")
 keys = {"all": tuple(f), "mask": scalars + ("action_mask",), "none": (), "scalars": scalars}[streams]
 P = {k: (f[k].data_ptr() if k in keys and k in f else None) for k in ("actions", "winner", "rewards", "done", "to_move", "action_mask", "observation")}
 ctr = torch.zeros(1, dtype=torch.int32, device="cuda:0")
-launches = max(2, 256 // T)
+launches = max(2, int(os.environ.get("AB_PLIES", "256")) // T)  # (AB_PLIES: plies per graph replay; long replays show the clocks' ramp)
 graphs, names = [], []
 for cfg in cfgs:
     L.gbl_ab_collect_cfg(cfg)
