@@ -581,7 +581,15 @@ struct MoveCells {
 
 __device__ __forceinline__ MoveCells move_planes(Planes &p, int mover, uint32_t a)
 {
-    uint32_t pi = __umul24(a, 57u) >> 9;  // a / 9 for a < 54 (a 24-bit multiply: full rate)
+    // a / 9 for a < 54 through a 24-bit multiply (full rate; the compiler turns __umul24 back into the quarter-rate v_mul_lo_u32
+    // wherever it cannot bound `a`, hence the instruction by name)
+#ifndef GBL_HOST_EMU
+    uint32_t a57;
+    asm("v_mul_u32_u24 %0, %1, 57" : "=v"(a57) : "v"(a));
+    uint32_t pi = a57 >> 9;
+#else
+    uint32_t pi = (a * 57u) >> 9;
+#endif
     uint32_t q = a - 9u * pi;
     uint32_t k = pi >> 1;
     uint32_t first = (~pi) & 1u;   // piece number odd
@@ -598,6 +606,12 @@ __device__ __forceinline__ MoveCells move_planes(Planes &p, int mover, uint32_t 
     m.val = (mover ? (0u - (pi + 1u)) : (pi + 1u)) & 0xFFu;
     return m;
 }
+
+// No row: a wavefront that plays the game without writing the state back (the role kernels' row wavefronts) patches nothing.
+struct NoRow {
+    __device__ __forceinline__ void apply(const MoveCells &) const {}
+    __device__ __forceinline__ void reset() const {}
+};
 
 // The row in 7 registers (board-level kernels: the row is re-staged into a fresh image anyway).
 struct RegRow {
@@ -871,6 +885,10 @@ __device__ __forceinline__ uint32_t draw32(uint64_t seed, uint64_t env_id, uint3
     return draw_word(draw_block(seed, env_id, ply, stream), ply);
 }
 
+// legal54 of the empty board, for either mover: every piece on every cell (what a reset leaves; the kernels that live on a
+// lone wavefront's latency take the legal mask of the moved position BESIDE the winner test and swap this in on a reset)
+constexpr uint64_t kLegalEmpty = (1ull << kActions) - 1ull;
+
 __device__ __forceinline__ int pick54(uint64_t m, uint32_t r)
 {
     uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
@@ -913,7 +931,9 @@ __device__ __forceinline__ Ply play_ply(Planes &p, Row row, int &mover, uint64_t
         return y;
     }
     y.stepped = true;
-    if (ok) row.apply(move_planes(p, mover, (uint32_t)action));  // gobblet.py:244 (illegal: silent no-op, board.py:125-126)
+    // gobblet.py:244 (illegal: silent no-op, board.py:125-126).  (Straight-line for the role kernel's row-less wavefronts -- the
+    // planes masked instead of the EXEC round trip: no effect, profiles/r05/ab_legal_ahead.txt)
+    if (ok) row.apply(move_planes(p, mover, (uint32_t)action));
     mover ^= 1;                                          // gobblet.py:246,267
     y.winner = PAIR ? winner_of_pair(p, pair_j) : winner_of(p);  // gobblet.py:248-249
     y.r0 = y.winner;                                     // gobblet.py:253-260

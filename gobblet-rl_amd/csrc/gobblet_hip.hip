@@ -851,11 +851,6 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
 // ONE barrier per launch (not per ply): the roles read the group's state, movers and first actions on their own and the scalars
 // role overwrites them at the end -- the rendezvous behind the loads keeps a late role from reading what an early one wrote back
 // (with one ply per launch the scalars role reaches its write-back after ~300 instructions).
-struct NoRow {  // the state image of a wavefront that does not write the state back is never patched
-    __device__ __forceinline__ void apply(const MoveCells &) const {}
-    __device__ __forceinline__ void reset() const {}
-};
-
 constexpr int kRoleScalars = 1, kRoleMask = 2, kRoleObs = 4;  // (bits: a wavefront may hold several roles)
 
 struct SmallArgs {
@@ -948,6 +943,10 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
     int8_t *mdst = nullptr, *odst = nullptr;
     const uint32_t plies = A.plies;
     const int64_t cell0 = (sub >> SH) * A.tile_stride + (sub & (LPB - 1)) * BPS;
+    // this ply's rows of the two row streams: advanced by a ply's stride per ply (no 64-bit multiply inside the chain)
+    int8_t *obs_at = OB ? A.obs_t + cell0 * kObs : nullptr, *mask_at = MK ? A.mask_t + cell0 * kActions : nullptr;
+    const int64_t obs_step = A.ply_stride * kObs, mask_step = A.ply_stride * kActions;
+    int64_t at = 0;  // ... and this ply's cell of the scalar arrays, relative to ply 0's (sc_* below)
     constexpr bool PAIR = LPB > 1;  // the lanes of a board split the winner test (winner_of_pair)
     // The scalars role's per-lane output arrays (NULL: this lane stores nothing there), at ply 0's cell of its board:
     //   4 lanes per board: lane 0 action + next mover, 1 reward, 2 winner, 3 done  (one byte store serves three arrays)
@@ -1014,12 +1013,15 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
         }
         GBL_PHASE_DEP(2, (uint32_t)y.winner + p.nz);  // the next word, move, winner
         dn = y.terminal ? 1 : 0;
+        // the next mover's legal mask, of the moved position: it does not wait for the winner test (the two interleave on the lone
+        // wavefront); a reset swaps in the empty board's
+        uint64_t legal_next = legal54(p, mover);
         if (y.terminal) {  // raw_env.reset, gobblet.py:275-290
             p = Planes{0u, 0u, 0u};
             mover = 0;
+            legal_next = kLegalEmpty;
             if (SC) row.reset();
         }
-        const int64_t cell = (int64_t)t * A.ply_stride + cell0;
         GBL_PHASE_DEP(3, p.nz);  // reset
         if (t && full) {  // ply t - 1's rows
             if constexpr (OB) sub_store<kObs, kRowPolicy, BPS>(odst, vo, lane);
@@ -1036,7 +1038,6 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
             // the five scalars of a board, dealt over its lanes: per-lane array pointers fixed before the loop (sc_*), no branch
             // on the lane's index inside it
             {
-                const int64_t at = (int64_t)t * A.ply_stride;
                 const uint16_t rw = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
                 if (sc_act) sc_act[at] = action;
                 if (sc_rw) sc_rw[at] = rw;
@@ -1047,6 +1048,7 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
                 if constexpr (LPB == 1) {
                     if (sc_b2) sc_b2[at] = (int8_t)mover;
                 }
+                at += A.ply_stride;
             }
         }
         GBL_PHASE(4);  // the previous ply's row stores, this ply's scalars
@@ -1055,18 +1057,20 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
             wave_lds_fence();
             obs_scatter_part<LPB>(reinterpret_cast<uint8_t *>(obs_img) + bq * kObs, p, mover, j);
             wave_lds_fence();
-            odst = A.obs_t + cell * kObs;
+            odst = obs_at;
+            obs_at += obs_step;
             if (full) sub_fetch<kObs, BPS>(obs_img, lane, vo);
             else sub_out_ragged(odst, obs_img, lane, rows * kObs);
             wave_lds_fence();
         }
         GBL_PHASE(5);  // the observation image
-        legal = legal54(p, mover);  // the next mover's: stored now, sampled from next ply
+        legal = legal_next;  // stored now, sampled from next ply
         GBL_PHASE_DEP(6, (uint32_t)legal);  // the next legal mask
         if constexpr (MK) {
             mask_row_part<LPB>(reinterpret_cast<uint8_t *>(mask_img) + bq * kActions, legal, j);
             wave_lds_fence();
-            mdst = A.mask_t + cell * kActions;
+            mdst = mask_at;
+            mask_at += mask_step;
             if (full) sub_fetch<kActions, BPS>(mask_img, lane, vm);
             else sub_out_ragged(mdst, mask_img, lane, rows * kActions);
             wave_lds_fence();
@@ -1136,9 +1140,11 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
         SubVecs<WITH_MASK ? sub_vectors<kActions, kTile>() : 0> vm{};
         SubVecs<WITH_OBS ? sub_vectors<kObs, kTile>() : 0> vo{};
         int8_t *dst = nullptr;
+        // this ply's rows: advanced by a ply's stride per ply (no 64-bit multiply per ply)
+        int8_t *row_at = is_mask ? mask_t + cell0 * kActions : obs_t + cell0 * kObs;
+        const int64_t row_step = ply_stride * (is_mask ? kActions : kObs);
         for (uint32_t t = 0; t < plies; ++t) {
             pair_barrier();  // ply t's positions are in s_hand[t & 1] (and the player is free to go on with ply t + 1)
-            const int64_t cell = (int64_t)t * ply_stride + cell0;
             if (t && full) {  // ply t - 1's rows, read back at the end of the last iteration
                 if constexpr (WITH_MASK) {
                     if (is_mask) sub_store<kActions, kPolicy, kTile>(dst, vm, lane);
@@ -1152,7 +1158,7 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
                     const uint2 lg = s_legal[t & 1u][lane];
                     mask_row_part<1>(reinterpret_cast<uint8_t *>(s_mask) + lane * kActions, ((uint64_t)lg.y << 32) | lg.x, 0);
                     wave_lds_fence();
-                    dst = mask_t + cell * kActions;
+                    dst = row_at;
                     if (full) sub_fetch<kActions, kTile>(s_mask, lane, vm);
                     else sub_out_ragged(dst, s_mask, lane, rows * kActions);
                     wave_lds_fence();
@@ -1165,12 +1171,13 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
                     wave_lds_fence();
                     obs_scatter_row(reinterpret_cast<uint8_t *>(s_obs) + lane * kObs, Planes{h.x, h.y, h.z}, (int)h.w);
                     wave_lds_fence();
-                    dst = obs_t + cell * kObs;
+                    dst = row_at;
                     if (full) sub_fetch<kObs, kTile>(s_obs, lane, vo);
                     else sub_out_ragged(dst, s_obs, lane, rows * kObs);
                     wave_lds_fence();
                 }
             }
+            row_at += row_step;
         }
         if (full) {  // the last ply's rows
             if constexpr (WITH_MASK) {
@@ -1200,6 +1207,7 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
     int dn = 0, tcount = 0;
     bool treset = false;
     uint64_t legal = legal54(p, mover);
+    int64_t cell = cell0;  // ply t's cell of the tile in the scalar arrays
     for (uint32_t t = 0; t < plies; ++t) {
         const uint32_t ply = ply0 + t;
         int action = pick54(legal, draw_word(block, ply));
@@ -1211,12 +1219,13 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
             y = play_ply<true>(p, row, mover, legal, action, illegal_mode);  // (sampled: legal by construction)
         }
         dn = y.terminal ? 1 : 0;
+        legal = legal54(p, mover);  // the next mover's (beside the winner test, see small_role): stored now, sampled from next ply
         if (y.terminal) {  // raw_env.reset, gobblet.py:275-290
             p = Planes{0u, 0u, 0u};
             mover = 0;
+            legal = kLegalEmpty;
             row.reset();
         }
-        legal = legal54(p, mover);  // the next mover's: stored now, sampled from next ply
         s_hand[t & 1u][lane] = uint4{p.nz, p.neg, p.odd, (uint32_t)mover};
         s_legal[t & 1u][lane] = uint2{(uint32_t)legal, (uint32_t)(legal >> 32)};
         if (WAVES > 1) pair_barrier();  // ply t handed over
@@ -1228,13 +1237,14 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
             w2 += __popcll(__ballot(valid && y.winner == -1));
         }
         if (valid) {
-            const int64_t at = (int64_t)t * ply_stride + cell0 + lane;
+            const int64_t at = cell + lane;
             if (actions_t) actions_t[at] = action;
             if (winner_t) winner_t[at] = (int8_t)y.winner;
             if (reward_t) reinterpret_cast<uint16_t *>(reward_t)[at] = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
             if (done_t) done_t[at] = (int8_t)dn;
             if (to_move_t) to_move_t[at] = (int8_t)mover;
         }
+        cell += ply_stride;
     }
     wave_lds_fence();
     tile_out<kCells>(state + tile * (kTile * kCells), s_state, lane, rows);
