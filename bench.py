@@ -737,6 +737,11 @@ def main():
     nlaunch = len(p.plan(K))
     p.eager(W)  # warm-up plies (untimed): decorrelate game phases, warm caches / code objects
     torch.cuda.synchronize(dev)
+    if dist is not None:
+        # the communicator's one-off costs (RCCL builds its rings inside the first collective) stay out of the timed span: the
+        # barrier that opens it is then an ordinary one
+        dist.barrier()
+        dist.barrier()
 
     # A timed run of ONE launch (the driver's 20 plies) is launched eagerly: a graph of one kernel node + the counter node starts
     # no sooner and carries the counter node inside the timed span (131 072 boards x 20 plies: 90 vs 99 us of wall clock,
