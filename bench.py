@@ -7,7 +7,7 @@
 One "step" = one lockstep ply of the benchmark pipeline over this rank's shard of boards -- masked-uniform
 sampling + raw_env.step + observe of the next mover, with EVERY ply's action, mask, obs, winner, reward, done and
 next mover materialised in HBM where a consumer can read them:
-    mode collect (default): gbl_collect -- T plies (--traj, default 32) per launch, ply t writing slot t of
+    mode collect (default): gbl_collect -- T plies (--traj; default by shard size, auto_traj) per launch, ply t writing slot t of
                  trajectory arrays [T][boards][...] (what a rollout collector hands a trainer); the boards stay in
                  LDS / registers between the plies of a launch, so the state crosses HBM once per T plies.
     mode fused : gbl_rollout(plies=1) -- ONE launch per ply, the ply's outputs overwrite the environment's
@@ -211,16 +211,20 @@ def cpu_baseline(boards, warmup, target_s):
 
 def auto_traj(boards, steps, requested=0):
     """Plies per gbl_collect launch: the requested value; else a timed run of up to 32 plies is ONE launch (the driver's
-    20 plies: one kernel, no boundary inside the timed region); else by shard size (large shards: shorter launches, so
-    that a launch's tail -- its last generation of wavefronts draining -- stays small, and the trajectory arrays stay
-    a few GiB); never more than the timed run."""
+    20 plies: one kernel, no boundary inside the timed region); else by shard size, as measured (profiles/r05/
+    plies_per_launch.txt) -- a launch boundary costs 3-6 us (the grid drains, the next one loads its state and primes its
+    generators), which small shards amortise over long launches (4 096 boards: 0.65 us per ply at 32 plies per launch, 0.57
+    at 256, 0.55 at 1 024), while large shards want SHORT launches: with T slots of every array open at once, hundreds of MB
+    apart, the write stream loses DRAM page locality (2^22 boards: 4 plies per launch 110.6 us per ply, 8 plies 126.3; profiles/
+    r05/large_plies_per_launch.txt).  The trajectory arrays stay <= ~3 GiB; never more than the timed run."""
     if requested > 0:
         return max(1, min(requested, steps))
     if steps <= 32:
         return max(1, steps)
-    # (round 5: at 2^22 boards 4 plies per launch run 110.6 us per ply, 8 plies 126.3, 16 plies 122.1 -- with T slots of every array
-    #  open at once, 490 MB apart, the write stream loses DRAM page locality; profiles/r05/large_plies_per_launch.txt)
-    return 4 if boards >= (1 << 21) else 8 if boards >= (1 << 19) else 16 if boards >= (1 << 18) else 32
+    for limit, plies in ((8192, 1024), (16384, 512), (65536, 256), (131072, 128), (262144, 64), (524288, 32), ((1 << 22) - 1, 8)):
+        if boards <= limit:
+            return min(plies, steps)
+    return 4
 
 
 def kernel_source_hash():

@@ -99,7 +99,10 @@ inline int small_cfg(int64_t n, bool with_mask, bool with_obs)
     return (GBL_FORCE_COLLECT_SMALL);
 #else
     // (round 5, scripts/ab_roles.sh; DESIGN.md 5.2 has the table; 3 = k_collect3)
-    if (!with_obs) return n <= 8192 ? 210 : n <= 57344 ? 3 : 0;
+    // MASK_ONLY is bound by what ONE wavefront issues, so the player + mask-row pair of k_collect3 keeps paying far
+    // into the HBM regime: 163 840 boards 1.79 against k_collect's 2.19 us per ply, 2^20: 10.39 against 10.93, 2^21: 19.9 against
+    // 20.7; 2^22: 45.1 against 44.5 (profiles/r05/ab_roles_long_launches.txt)
+    if (!with_obs) return n <= 8192 ? 210 : n <= 3 * (int64_t)(1 << 20) ? 3 : 0;
     // (with the trajectory arrays placed across HBM's memory classes: 40 960 boards k_collect3 1.31 against k_collect2's 1.40 us per
     //  ply, 49 152: 1.49 against 1.41 -- profiles/r05/placed_forms.txt)
     return n <= 8192 ? 220 : n <= 16384 ? 120 : n <= 45056 ? 3 : 0;

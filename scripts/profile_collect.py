@@ -103,19 +103,19 @@ def main():
     rows = ["kernel,counter,dispatches,mean_value_KB"]
     # run name (scripts/profile_round.sh: pmc_runs.txt) -> (key bench.py looks up, kernel name substring)
     runs = {"collect_T8": ("collect:1048576:T8", "k_collect<true, true"), "collect_T20": ("collect:1048576:T20", "k_collect<true, true"),
-            "collect_4096_T32": ("collect:4096:T32", "k_collect_small<true, true"),
-            "collect_16384_T32": ("collect:16384:T32", "k_collect_small<true, true"),
-            "collect_32768_T32": ("collect:32768:T32", "k_collect3<true, true"),
-            "collect_65536_T32": ("collect:65536:T32", "k_collect2<true, true"),
+            "collect_4096_T1024": ("collect:4096:T1024", "k_collect_small<true, true"),
+            "collect_16384_T512": ("collect:16384:T512", "k_collect_small<true, true"),
+            "collect_32768_T256": ("collect:32768:T256", "k_collect3<true, true"),
+            "collect_65536_T256": ("collect:65536:T256", "k_collect2<true, true"),
             "collect_4194304_T4": ("collect:4194304:T4", "k_collect<true, true"),
-            "collect_131072_T32": ("collect:131072:T32", "k_collect2<true, true"),
+            "collect_131072_T128": ("collect:131072:T128", "k_collect2<true, true"),
             "collect_131072_T20": ("collect:131072:T20", "k_collect2<true, true"),
-            "collect_262144_T16": ("collect:262144:T16", "k_collect<true, true"),
+            "collect_262144_T64": ("collect:262144:T64", "k_collect<true, true"),
             "collect_262144_T20": ("collect:262144:T20", "k_collect<true, true"),
-            "collect_524288_T8": ("collect:524288:T8", "k_collect<true, true"),
+            "collect_524288_T32": ("collect:524288:T32", "k_collect<true, true"),
             "collect_524288_T20": ("collect:524288:T20", "k_collect<true, true"),
             "collect_4194304_T8": ("collect:4194304:T8", "k_collect<true, true"),
-            "collect_noobs_T8": ("collect-noobs:1048576:T8", "k_collect<true, false"),
+            "collect_noobs_T8": ("collect-noobs:1048576:T8", "k_collect3<true, false"),
             "fused_1048576": ("fused:1048576", "k_rollout<true, true"), "fused_262144": ("fused:262144", "k_rollout<true, true"),
             "fused_131072": ("fused:131072", "k_rollout<true, true"), "fused_4096": ("fused:4096", "k_rollout<true, true"),
             "fused_4194304": ("fused:4194304", "k_rollout<true, true"),
@@ -138,7 +138,7 @@ def main():
     open(os.path.join(dst, "pmc_summary.csv"), "w").write("\n".join(rows) + "\n")
     # ---- SQ counters ------------------------------------------------------------------------------------------------
     for m, kernel, what in (("traj", "k_collect<true, true", "gbl_collect FULL, 8 plies per launch, 2^20 boards"),
-                            ("trajmask", "k_collect<true, false", "gbl_collect MASK_ONLY, 8 plies per launch, 2^20 boards"),
+                            ("trajmask", "k_collect3<true, false", "gbl_collect MASK_ONLY (k_collect3: a playing and a mask-row wavefront per tile), 8 plies per launch, 2^20 boards"),
                             ("full", "k_rollout<true, true", "gbl_rollout FULL, one ply per launch, 2^20 boards"),
                             ("mask", "k_rollout<true, false", "gbl_rollout MASK_ONLY, one ply per launch, 2^20 boards"),
                             ("greedy", "k_greedy", "gbl_greedy depth 2, 65536 boards"),

@@ -94,16 +94,16 @@ if [ "$STAGE" != a ]; then
 cat > $O/pmc_runs.txt <<EOT
 collect_T8 traj 1048576 6 8
 collect_T20 traj 1048576 4 20
-collect_4096_T32 traj 4096 6 32
-collect_16384_T32 traj 16384 6 32
-collect_32768_T32 traj 32768 6 32
-collect_65536_T32 traj 65536 6 32
+collect_4096_T1024 traj 4096 3 1024
+collect_16384_T512 traj 16384 3 512
+collect_32768_T256 traj 32768 4 256
+collect_65536_T256 traj 65536 4 256
 collect_4194304_T4 traj 4194304 4 4
-collect_131072_T32 traj 131072 6 32
+collect_131072_T128 traj 131072 4 128
 collect_131072_T20 traj 131072 6 20
-collect_262144_T16 traj 262144 6 16
+collect_262144_T64 traj 262144 4 64
 collect_262144_T20 traj 262144 6 20
-collect_524288_T8 traj 524288 6 8
+collect_524288_T32 traj 524288 4 32
 collect_524288_T20 traj 524288 4 20
 collect_4194304_T8 traj 4194304 4 8
 collect_noobs_T8 trajmask 1048576 6 8

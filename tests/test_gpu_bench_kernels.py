@@ -91,10 +91,10 @@ def check_trajectory(env, tr, T, ply0, s, tm, dn, illegal, with_obs=True, with_m
 COLLECT_RECORDS = {
     "headline_1048576": (1 << 20, 8, True),
     "headline_driver_cmd_1048576": (1 << 20, 20, True),   # `--steps 20`: the whole timed run is ONE launch of 20 plies
-    "c2_4096": (4096, 32, True),
-    "c_16384": (16384, 32, True),
-    "c_32768": (32768, 32, True),
-    "c_65536": (65536, 32, True),
+    "c2_4096": (4096, 1024, True),                         # (the long launches of the small shards: the record's own length)
+    "c_16384": (16384, 128, True),
+    "c_32768": (32768, 64, True),
+    "c_65536": (65536, 48, True),
     "c3_262144": (262144, 16, True),
     "c4_shard_131072": (131072, 32, True),
     "large_4194304": (1 << 22, 3, True),
@@ -124,10 +124,15 @@ def test_bench_collect_record_vs_oracle(G, record):
     (131073, True, "time", "noop", False), (131073, False, "time", "terminate", True),
     (131073, True, "tile", "terminate", True), (131073, False, "tile", "noop", False),
     # 2^20 boards x 4 plies, MASK_ONLY and FULL, both illegal modes
-    (1 << 20, False, "time", "terminate", False), (1 << 20, True, "tile", "noop", False)])
+    (1 << 20, False, "time", "terminate", False), (1 << 20, True, "tile", "noop", False),
+    # MASK_ONLY stays with k_collect3 up to 3 * 2^20 boards (the cases above): the first grid of k_collect<mask>, ragged
+    (3 * (1 << 20) + 1, False, "time", "noop", True)])
 def test_collect_one_wavefront_kernel_vs_oracle(G, n, with_obs, layout, illegal, device_ply):
-    """k_collect (one wavefront per tile: grids above 2 048 tiles) directly against the oracle, FULL and MASK_ONLY, both
-    layouts, both illegal modes, ply index by value and on the device; a ragged last tile at 131 073 boards."""
+    """The large grids of gbl_collect directly against the oracle -- FULL: k_collect (one wavefront per tile: grids above 2 048
+    tiles); MASK_ONLY: k_collect3's playing + mask-row wavefronts up to 3 * 2^20 boards, k_collect beyond -- both layouts, both
+    illegal modes, ply index by value and on the device; ragged last tiles at 131 073 and 3 145 729 boards."""
+    variant = G._native.lib().gbl_collect_variant(n, 4, 1, int(with_obs))
+    assert variant == (0 if with_obs or n > 3 * (1 << 20) else 3)
     T, seed, base, warm = 4, 17, 5_000_000_000, 9
     env, s, tm, dn = warm_pair(G, n, seed, base, warm, with_observation=with_obs, illegal_mode=illegal)
     if device_ply:
@@ -277,7 +282,7 @@ def test_collect_from_external_first_ply_vs_oracle(G, n, T, illegal, with_obs):
 # group is partial, or empty) and whole ones
 SMALL_SIZES = [1, 15, 16, 17, 31, 33, 63, 65, 4096, 4099, 8192,   # FULL <2,2>: groups of 32 boards, two observation wavefronts of 16; MASK_ONLY <2,1>
                8193, 8209, 8241, 12321, 16384]                   # FULL <1,2>: a tile per scalars / mask wavefront, two observation wavefronts of 32
-TRIO_SIZES = [16385, 16447, 32768, 45056, 57344]                 # k_collect3 (FULL up to 45 056 boards; MASK_ONLY 8 193 ... 57 344)
+TRIO_SIZES = [16385, 16447, 32768, 45056, 57344]                 # k_collect3 (FULL up to 45 056 boards; MASK_ONLY 8 193 ... 3 * 2^20)
 
 
 @pytest.mark.parametrize("with_obs", [True, False], ids=["full", "maskonly"])
