@@ -23,9 +23,10 @@ if os.environ.get("GOBBLET_HIP_LIB"):  # an experiment's own build of the librar
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--games", type=int, default=200)
+    ap.add_argument("--device", default="cuda:0", help='"cpu": the host flavour of the ABI (gbl_cpu_*), BASELINE config 1 as written')
     args = ap.parse_args()
     rng = np.random.default_rng(0)
-    env = G.gobblet_v1.env()
+    env = G.gobblet_v1.env(device=args.device)
     steps = 0
     wins = {"player_1": 0, "player_2": 0}
     t0 = None
@@ -45,7 +46,7 @@ def main():
                 env.step(int(legal[rng.integers(len(legal))]))
                 steps += 1
     dt = time.perf_counter() - t0
-    print(f"facade AEC loop: {args.games} games, {steps} env-steps in {dt:.2f} s = {steps / dt:.0f} env-steps/s "
+    print(f"facade AEC loop on {args.device}: {args.games} games, {steps} env-steps in {dt:.2f} s = {steps / dt:.0f} env-steps/s "
           f"(mean game {steps / args.games:.1f} plies; player_1 won {wins['player_1']}, player_2 won {wins['player_2']})")
 
 
