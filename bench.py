@@ -102,8 +102,8 @@ def parse():
     ap.add_argument("--boards-per-gpu", type=int, default=0, help="fixed per-GPU shard instead (weak scaling)")
     ap.add_argument("--mode", choices=["collect", "fused", "step"], default="collect")
     ap.add_argument("--traj", type=int, default=0,
-                    help="plies per launch in mode collect; 0 = by shard size (8 from 2^19 boards per GPU, 16 from 2^18, "
-                         "else 32: small shards amortise the launch over more plies), never more than --steps")
+                    help="plies per launch in mode collect; 0 = by shard size (auto_traj: 1024 for <= 8192 boards per GPU ... 8 "
+                         "at 2^20, 4 from 2^22), never more than --steps")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the K timed plies as one hipGraph; 0: eager launches")
     ap.add_argument("--no-obs", action="store_true",
                     help="MASK_ONLY variant (BASELINE.md: 117 algorithmic bytes per env-step): no observation tensor")
@@ -118,6 +118,10 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the multi-rank path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+    ap.add_argument("--span-barrier", default="local", choices=["local", "dist"],
+                    help="the barrier on both sides of the timed span: local = generation counters of the node's ranks in shared "
+                         "memory (one node is the contract; ~1 us); dist = torch.distributed's (RCCL: an all-reduce + a "
+                         "synchronize per barrier, which at 8 ranks lasts about as long as the shard's 20 plies)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -251,6 +255,43 @@ def committed_counter(key, field):
     return rec[field], f"{rec.get('source', 'profiles/pmc_traffic.json')} @ kernel sources {rec['kernel_source_hash']}"
 
 
+class LocalBarrier:
+    """A barrier of the ranks of ONE node (the contract: one process per GPU of one node): a generation counter per rank, a cache
+    line apart, in a shared-memory block; arrive = publish the next generation, then wait until every rank has.  The contract
+    brackets the timed span with barrier + synchronize; what a barrier costs is harness, not the path measured -- RCCL's is an
+    all-reduce kernel plus a synchronize on every rank."""
+
+    def __init__(self, dist, rank, world):
+        import numpy as np
+        from multiprocessing import resource_tracker, shared_memory
+        self.rank, self.world, self.gen, self.dist = rank, world, 0, dist
+        name = [None]
+        if rank == 0:
+            self.shm = shared_memory.SharedMemory(create=True, size=64 * world)  # (zero-filled)
+            name[0] = self.shm.name
+        dist.broadcast_object_list(name, src=0)
+        if rank != 0:
+            self.shm = shared_memory.SharedMemory(name=name[0])
+            resource_tracker.unregister(self.shm._name, "shared_memory")  # (rank 0 owns the block: it alone unlinks it)
+        self.slots = np.ndarray((world, 8), dtype=np.int64, buffer=self.shm.buf)
+        dist.barrier()  # every rank is attached
+
+    def wait(self, timeout_s=120.0):
+        self.gen += 1
+        self.slots[self.rank, 0] = self.gen
+        col, gen, deadline = self.slots[:, 0], self.gen, time.perf_counter() + timeout_s
+        while int(col.min()) < gen:
+            if time.perf_counter() > deadline:
+                raise RuntimeError(f"bench.py: rank {self.rank} waited {timeout_s:.0f} s at the span barrier (generations {col.tolist()})")
+
+    def close(self):
+        self.slots = None
+        self.dist.barrier()  # nobody is still spinning on the block
+        self.shm.close()
+        if self.rank == 0:
+            self.shm.unlink()
+
+
 class Pipeline:
     """One shard of boards and its launch sequence, with the ply index in device memory."""
 
@@ -263,6 +304,8 @@ class Pipeline:
                       ac=env.actions.data_ptr(), wi=env.winner.data_ptr(), rw=env.rewards.data_ptr(),
                       mk=env.action_mask.data_ptr(), ob=None if no_obs else env.observation.data_ptr())
         self.ctr = torch.zeros(1, dtype=torch.int32, device=dev)  # plies played so far (keys the sampler)
+        self.host_ply = 0      # ... and the host's copy of it: an eager launch can take the ply index BY VALUE
+        self.owed = 0          # plies played by value that the device-resident index has not been told of yet (settle())
         self.traj = None
         if mode == "collect":
             self.traj = env.trajectory_buffers(self.T, placement=placement, far=True)  # (the benchmark owns the device)
@@ -284,10 +327,13 @@ class Pipeline:
             return (per * plies + ALGO_BYTES_COLLECT_LAUNCH) * self.boards
         return (ALGO_BYTES_MASK_ONLY if self.no_obs else ALGO_BYTES_FULL) * self.boards
 
-    def enqueue(self, off, plies, stream, ev=None):
+    def enqueue(self, off, plies, stream, ev=None, by_value=False):
         """Plies (counter + off) .. (counter + off + plies - 1) on `stream`; ev = (start, stop) events bracketing
-        the dominant kernel."""
+        the dominant kernel.  by_value (mode collect, eager launches): the ply index goes in as an argument instead of being read
+        from device memory, so no launch has to advance it afterwards (played(): 7 us of a one-launch span,
+        scripts/span_overhead.py)."""
         P, lib, env, n = self.P, self.lib, self.env, self.boards
+        assert not by_value or (self.mode == "collect" and self.host_ply is not None)
         if self.mode == "step":
             rc = lib.gbl_sample_at(P["mk"], P["ac"], n, env.seed, env.env_base, off, self.ctr.data_ptr(), stream)
             self.nat.check(rc, "gbl_sample_at")
@@ -304,14 +350,27 @@ class Pipeline:
                 ev[0].record()
             T = self.TP
             rc = lib.gbl_collect(P["sq"], P["tm"], P["dn"], T["ac"], T["wi"], T["rw"], T["dn"], T["tm"], T["mk"], T["ob"],
-                                 n, self.traj["_ply_stride"], self.traj["_tile_stride"], env.seed, env.env_base, off,
-                                 self.ctr.data_ptr(), plies, 0, None, None, stream)
+                                 n, self.traj["_ply_stride"], self.traj["_tile_stride"], env.seed, env.env_base,
+                                 off + (self.host_ply if by_value else 0), None if by_value else self.ctr.data_ptr(), plies, 0,
+                                 None, None, stream)
         self.nat.check(rc, "launch")
         if ev:
             ev[1].record()
 
     def advance(self, k, stream):
-        self.nat.check(self.lib.gbl_counter_add(self.ctr.data_ptr(), k, stream), "gbl_counter_add")
+        self.nat.check(self.lib.gbl_counter_add(self.ctr.data_ptr(), k + self.owed, stream), "gbl_counter_add")
+        if self.host_ply is not None:
+            self.host_ply += k
+        self.owed = 0
+
+    def played(self, k):
+        """k plies were launched with the ply index by value: the host's index moves on, the device's is settled later."""
+        self.host_ply += k
+        self.owed += k
+
+    def settle(self, stream):
+        if self.owed:
+            self.advance(0, stream)
 
     def eager(self, k, events=None):
         s = self.nat.current_stream(self.dev)
@@ -324,6 +383,8 @@ class Pipeline:
         g = torch.cuda.CUDAGraph()
         # thread_local: calls made by other threads of this process (e.g. RCCL's watchdog polling its
         # events in the multi-GPU runs) must not invalidate the capture
+        assert not self.owed
+        self.host_ply = None  # (replays move the device-resident index behind the host's back: no by-value launches from here on)
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             cs = self.nat.current_stream(self.dev)
             for off, plies in self.plan(k):
@@ -613,6 +674,8 @@ def contract_record(args, p, roof, total, boards, world, K, W, elapsed, local_el
                    # ranks that took part in the barriers / reductions over RCCL (0: none, or a gloo rehearsal)
                    "rccl_ranks": world if (distributed and args.dist_backend == "nccl") else 0,
                    "dist_backend": (args.dist_backend if distributed else None),
+                   # the barrier on both sides of the timed span (--span-barrier): the node's ranks meet in shared memory
+                   "span_barrier": getattr(args, "span_barrier_used", None),
                    # where the observation / mask trajectory arrays lie (gobblet-rl_amd/placement.py): probe ratio
                    # both / (obs alone + mask alone), ~1.0 = same 96 GiB class of HBM, ~0.8 = different classes;
                    # "unplaced" = some rank's search found no pair in different classes (the headline then runs ~20 % slower)
@@ -667,7 +730,21 @@ def emit(full, configs_out):
             print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
             path = None
     print(json.dumps(full), file=sys.stderr, flush=True)
-    print(compact_line(full, os.path.relpath(path, ROOT) if path else None), flush=True)
+    print(compact_line(full, os.path.relpath(path, ROOT) if path else None), file=CONTRACT_STDOUT or sys.stdout, flush=True)
+
+
+CONTRACT_STDOUT = None  # the process's original stdout, once keep_stdout_for_the_line() has pointed fd 1 at stderr
+
+
+def keep_stdout_for_the_line():
+    """Everything this process -- or a library inside it -- writes to fd 1 from now on goes to stderr; only emit()'s contract line
+    reaches the real stdout.  RCCL prints a five-line version banner to stdout when it builds its first communicator (seen on
+    the pool's image with world 1); a driver that parses stdout must find ONE JSON line there."""
+    global CONTRACT_STDOUT
+    if CONTRACT_STDOUT is None:
+        sys.stdout.flush()
+        CONTRACT_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
 
 
 def spawn_ranks(n):
@@ -721,6 +798,7 @@ def main():
     dist = None
     if world > 1 or os.environ.get("GBL_BENCH_FORCE_DIST"):  # (the env knob rehearses the RCCL path at world 1)
         import torch.distributed as dist
+        keep_stdout_for_the_line()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # RCCL; used only for barriers + small reductions of timings
@@ -757,6 +835,10 @@ def main():
     ev = p.events(1 if use_graph else nlaunch)
     stream = p.nat.current_stream(dev)
 
+    # eager gbl_collect launches take the ply index by value (what BatchedGobblet.collect does without device_ply()): the launch
+    # that would move a device-resident index on is not needed, and not in the span (scripts/span_overhead.py: 7 of its 22 us)
+    by_value = graph is None and args.mode == "collect"
+
     def play_k():
         if graph is not None:
             ev[0][0].record()
@@ -764,11 +846,23 @@ def main():
             ev[0][1].record()
         else:
             for i, (off, plies) in enumerate(p.plan(K)):
-                p.enqueue(off, plies, stream, ev[i])
+                p.enqueue(off, plies, stream, ev[i], by_value=by_value)
 
     def bookkeeping():
-        if graph is None:         # eager: the launch that moves the device-resident ply index on (a graph's last node does it)
+        if by_value:
+            p.played(K)           # (host arithmetic)
+        elif graph is None:       # eager, one ply per launch: the launch that moves the device-resident ply index on
             p.advance(K, stream)
+
+    span_barrier, lb = None, None
+    args.span_barrier_used = None
+    if dist is not None:
+        local = int(os.environ.get("LOCAL_WORLD_SIZE", world)) == world
+        if args.span_barrier == "local" and local:
+            lb = LocalBarrier(dist, rank, world)
+            span_barrier, args.span_barrier_used = lb.wait, "node-local shared memory"
+        else:
+            span_barrier, args.span_barrier_used = dist.barrier, "torch.distributed (%s)" % args.dist_backend
 
     def pass_kernel_us():         # mean launch duration of the dominant kernel over the pass just played (HIP events)
         if graph is None:
@@ -778,16 +872,17 @@ def main():
     play_k()                      # untimed rehearsal: K more warm plies
     bookkeeping()
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
+    if span_barrier is not None:
+        span_barrier()            # (rehearsed too)
+        span_barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     play_k()
     bookkeeping()                 # (inside the timed region, as in the graph)
     torch.cuda.synchronize(dev)
     local_elapsed = time.perf_counter() - t0  # this rank's own span (reported beside the contract's)
-    if dist is not None:
-        dist.barrier()
+    if span_barrier is not None:
+        span_barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0        # the contract's span: barrier + synchronize on both sides
 
@@ -817,6 +912,7 @@ def main():
             bookkeeping()
             torch.cuda.synchronize(dev)
             repeats_us.append(pass_kernel_us())
+    p.settle(stream)  # (plies launched with the index by value: the device-resident index catches up)
     per_rank_us = [mean_kernel_s * 1e6]
     mine_pl = p.traj["_placement"] if p.traj is not None else None
     per_rank_placement = [mine_pl]
@@ -869,6 +965,8 @@ def main():
                 c5["leaf_evaluations_per_s_equivalent"] = c5["value"] * ref["leaf_evaluations_per_decision"]
                 c5["cpu_port_decisions_per_s_1core"] = ref["decisions_per_s_1core"]
         emit(full, args.configs_out)
+    if lb is not None:
+        lb.close()
     if dist is not None:
         dist.destroy_process_group()
 

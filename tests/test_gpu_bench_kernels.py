@@ -109,7 +109,8 @@ def test_bench_collect_record_vs_oracle(G, record):
     n, T, with_obs = COLLECT_RECORDS[record]
     seed, base, warm = 0, 0, 12
     env, s, tm, dn = warm_pair(G, n, seed, base, warm, with_observation=with_obs)
-    env.device_ply()                                  # DEV_PLY instantiation: what the hipGraph replay needs
+    if record != "headline_driver_cmd_1048576":       # (ONE eager launch: bench.py passes the ply index by value there)
+        env.device_ply()                              # DEV_PLY instantiation: what the hipGraph replay needs
     tr = env.trajectory_buffers(T, placement="any")
     env.collect(T, out=tr, refresh=False)
     env.advance_ply()

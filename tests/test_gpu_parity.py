@@ -1070,9 +1070,12 @@ def test_bench_script_runs_and_reports(G):
     # time, all-gather of the per-rank numbers -- rehearsed at world size 1 (an 8-GPU node is the driver's to launch)
     env = dict(os.environ, GBL_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1",
                LOCAL_RANK="0")
-    lines, full, _ = _bench(["--boards", "262144", "--steps", "20", "--warmup", "5", "--no-configs", "--no-cpu-baseline"], env=env)
+    lines, full, out = _bench(["--boards", "262144", "--steps", "20", "--warmup", "5", "--no-configs", "--no-cpu-baseline"], env=env)
+    # (RCCL's version banner and anything else a library prints goes to stderr: ONE line on stdout)
+    assert len(out.stdout.strip().splitlines()) == 1, out.stdout[:600]
     d = json.loads(lines[-1])
     assert d["config"]["rccl_ranks"] == 1 and d["config"]["dist_backend"] == "nccl" and len(full["detail"]["kernel_us_per_rank"]) == 1
+    assert d["config"]["span_barrier"] == "node-local shared memory"
     assert full["detail"]["trajectory_placement_per_rank"][0]["probes"]
     assert d["config"]["kernel_us_max"] == full["detail"]["kernel_us_per_rank"][0] and d["ms_per_step"] >= d["config"]["ms_per_step_own_span"] > 0
 

@@ -85,3 +85,35 @@ def test_two_rank_gloo_on_gpu_equals_single_shard():
     assert np.array_equal(np.concatenate([p["obs"] for p in parts]), ref["obs"])
     for p in parts:
         assert np.array_equal(p["tallies"], ref["counters"])
+
+
+def _barrier_worker(rank, world, initfile, outdir):
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    lb = bench.LocalBarrier(dist, rank, world)
+    before, after = [], []
+    for i in range(50):
+        if (i + rank) % world == 0:
+            time.sleep(0.002)            # a different straggler every round
+        before.append(time.monotonic())  # (CLOCK_MONOTONIC: one clock for all processes of the host)
+        lb.wait()
+        after.append(time.monotonic())
+    np.savez(os.path.join(outdir, f"b{rank}.npz"), before=np.array(before), after=np.array(after))
+    lb.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_span_barrier_of_the_node(world):
+    """bench.py's barrier on both sides of the timed span (LocalBarrier: generation counters of the node's ranks in shared
+    memory): nobody leaves round i before everybody has arrived at it, fifty rounds with a different straggler each."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_barrier_worker, args=(world, os.path.join(d, "init"), d), nprocs=world, join=True)
+        parts = [np.load(os.path.join(d, f"b{r}.npz")) for r in range(world)]
+    before = np.stack([p["before"] for p in parts])
+    after = np.stack([p["after"] for p in parts])
+    assert (after.min(axis=0) >= before.max(axis=0)).all()
