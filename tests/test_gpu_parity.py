@@ -1148,8 +1148,10 @@ def test_bench_script_c4_shape_rehearsal(G):
     lines, full, out = _bench(["--gpus", str(ranks), "--steps", "20", "--warmup", "5", "--boards", str(131072 * ranks),
                                "--dist-backend", "gloo", "--share-device"], launcher_ranks=ranks, timeout=900)
     assert len(lines) == 1 and len(lines[0].encode()) < 4096
+    assert len(out.stdout.strip().splitlines()) == 1, out.stdout[:600]  # the launcher's stdout: rank 0's contract line, nothing else
     d = json.loads(lines[0])
     assert d["n_gpus"] == ranks and d["config"]["boards_per_gpu"] == 131072 and d["config"]["plies_per_launch"] == 20
+    assert d["config"]["span_barrier"] == "node-local shared memory" and d["config"]["launch"] == "eager launches"
     assert d["roofline"]["kernel"].startswith("k_collect2 (20 plies per launch)"), d["roofline"]["kernel"]
     assert len(full["detail"]["kernel_us_per_rank"]) == ranks and all(u > 0 for u in full["detail"]["kernel_us_per_rank"])
     assert d["config"]["kernel_us_max"] >= d["config"]["kernel_us_min"] > 0
