@@ -6,6 +6,8 @@ ply index, and how the host waits for the end.  Variants, wall clock around each
     no-advance      the ply index passed by value: no second launch
     poll            as sync, but the host polls the stop event before it calls synchronize
     no-advance+poll both
+    prebound args   no-advance with the 22 ctypes arguments converted once (nothing: the path is the two event records and the launch)
+  SPAN_SPIN=1|2|4 sets hipDeviceScheduleSpin / Yield / BlockingSync first (nothing either: the wait already spins)
   python scripts/span_overhead.py [BOARDS] [PLIES]"""
 import os
 import statistics
@@ -22,6 +24,11 @@ B = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(B)
 import gobblet_rl_amd as G  # noqa: E402
 
+if os.environ.get("SPAN_SPIN"):  # hipDeviceScheduleSpin (1) / Yield (2) / BlockingSync (4): how hipDeviceSynchronize waits
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    torch.cuda.init()
+    print("hipSetDeviceFlags ->", hip.hipSetDeviceFlags(int(os.environ["SPAN_SPIN"])), flush=True)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 REPS = 25
@@ -44,9 +51,29 @@ def launch(by_value):
     ev[1].record()
 
 
+import ctypes as C  # noqa: E402
+
+_sig = G._native.SIGNATURES["gbl_collect"][1]
+_vals = [P["sq"], P["tm"], P["dn"], T["ac"], T["wi"], T["rw"], T["dn"], T["tm"], T["mk"], T["ob"], n, p.traj["_ply_stride"],
+         p.traj["_tile_stride"], env.seed, env.env_base, 0, None, K, 0, None, None, stream]
+_cargs = [t(v) if v is not None else None for t, v in zip(_sig, _vals)]   # converted once
+_rec0, _rec1, _fn = ev[0].record, ev[1].record, p.lib.gbl_collect
+
+
+def launch_prebound():
+    _cargs[15] = ply[0]
+    _rec0()
+    rc = _fn(*_cargs)
+    _rec1()
+    assert rc == 0
+
+
 def run(by_value, poll):
     t0 = time.perf_counter()
-    launch(by_value)
+    if by_value == "prebound":
+        launch_prebound()
+    else:
+        launch(by_value)
     t1 = time.perf_counter()
     if not by_value:
         p.advance(K, stream)
@@ -61,7 +88,7 @@ def run(by_value, poll):
 
 
 for name, by_value, poll in (("sync", False, False), ("no-advance", True, False), ("poll", False, True), ("no-advance+poll", True, True),
-                             ("sync", False, False)):
+                             ("prebound args", "prebound", False), ("sync", False, False)):
     for _ in range(3):
         run(by_value, poll)
     rows = [run(by_value, poll) for _ in range(REPS)]
