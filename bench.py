@@ -213,7 +213,7 @@ def cpu_baseline(boards, warmup, target_s):
                               "legality_tests_per_decision": tests / k, "leaf_evaluations_per_decision": leaves / k}}
 
 
-def auto_traj(boards, steps, requested=0):
+def auto_traj(boards, steps, requested=0, no_obs=False):
     """Plies per gbl_collect launch: the requested value; else a timed run of up to 32 plies is ONE launch (the driver's
     20 plies: one kernel, no boundary inside the timed region); else by shard size, as measured (profiles/r05/
     plies_per_launch.txt) -- a launch boundary costs 3-6 us (the grid drains, the next one loads its state and primes its
@@ -227,6 +227,9 @@ def auto_traj(boards, steps, requested=0):
         return max(1, steps)
     for limit, plies in ((8192, 1024), (16384, 512), (65536, 256), (131072, 128), (262144, 64), (524288, 32), ((1 << 22) - 1, 8)):
         if boards <= limit:
+            if no_obs and plies == 8:
+                plies = 16  # MASK_ONLY slots are a third of FULL's: 2^20 boards 8 / 12 / 16 / 20 / 24 / 32 plies per launch:
+                #             10.3-10.5 / 10.1 / 9.8-9.9 / 9.9-10.0 / 10.2-10.3 / 12.7 us per ply (plies_per_launch.txt)
             return min(plies, steps)
     return 4
 
@@ -813,7 +816,7 @@ def main():
         env_base, boards = G.shard_bounds(args.boards, world, rank)
         total = args.boards
     K, W = args.steps, args.warmup
-    args.traj = auto_traj(boards, K, args.traj)
+    args.traj = auto_traj(boards, K, args.traj, no_obs=args.no_obs)
     p = Pipeline(G, torch, boards, env_base, dev, no_obs=args.no_obs, mode=args.mode, traj=args.traj,
                  placement=args.placement)
     nlaunch = len(p.plan(K))
@@ -945,7 +948,7 @@ def main():
         if world == 1 and not args.no_configs:
             cfg = {}
             for name, (n, k, noobs, mode) in CONFIG_RECORDS.items():
-                cfg[name] = short_run(G, torch, dev, n, k, W, no_obs=noobs, mode=mode, traj=auto_traj(n, k),
+                cfg[name] = short_run(G, torch, dev, n, k, W, no_obs=noobs, mode=mode, traj=auto_traj(n, k, no_obs=noobs),
                                       placement=args.placement)
             # an external policy's ply + the masked-random reply in one launch, at the C3 / C4-shard sizes (against single_ply_*)
             for n in (131072, 262144):

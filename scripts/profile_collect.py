@@ -115,7 +115,7 @@ def main():
             "collect_524288_T32": ("collect:524288:T32", "k_collect<true, true"),
             "collect_524288_T20": ("collect:524288:T20", "k_collect<true, true"),
             "collect_4194304_T8": ("collect:4194304:T8", "k_collect<true, true"),
-            "collect_noobs_T8": ("collect-noobs:1048576:T8", "k_collect3<true, false"),
+            "collect_noobs_T16": ("collect-noobs:1048576:T16", "k_collect3<true, false"),
             "fused_1048576": ("fused:1048576", "k_rollout<true, true"), "fused_262144": ("fused:262144", "k_rollout<true, true"),
             "fused_131072": ("fused:131072", "k_rollout<true, true"), "fused_4096": ("fused:4096", "k_rollout<true, true"),
             "fused_4194304": ("fused:4194304", "k_rollout<true, true"),

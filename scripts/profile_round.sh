@@ -106,7 +106,7 @@ collect_262144_T20 traj 262144 6 20
 collect_524288_T32 traj 524288 4 32
 collect_524288_T20 traj 524288 4 20
 collect_4194304_T8 traj 4194304 4 8
-collect_noobs_T8 trajmask 1048576 6 8
+collect_noobs_T16 trajmask 1048576 4 16
 fused_1048576 full 1048576 20 1
 fused_262144 full 262144 20 1
 fused_131072 full 131072 20 1

@@ -98,7 +98,7 @@ COLLECT_RECORDS = {
     "c3_262144": (262144, 16, True),
     "c4_shard_131072": (131072, 32, True),
     "large_4194304": (1 << 22, 3, True),
-    "maskonly_1048576": (1 << 20, 8, False),
+    "maskonly_1048576": (1 << 20, 16, False),
 }
 
 
