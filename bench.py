@@ -17,12 +17,13 @@ next mover materialised in HBM where a consumer can read them:
 Workload (BASELINE.json metric / BASELINE.md C4): 2^20 boards IN TOTAL, sharded by contiguous global index
 over the N GPUs (131 072 per GPU at N = 8; "strong" scaling), all reset, W warm-up plies of masked-random play
 with auto-reset (stationary mix of game phases), then K timed plies; synthetic data, RNG keyed (seed=0, global
-board id, ply) so results do not depend on N.  No collective on the step path: RCCL carries the barriers around
-the timed region and one MAX-reduce of the elapsed time.  --boards-per-gpu B fixes the per-GPU shard instead
+board id, ply) so results do not depend on N.  No collective on the step path: RCCL carries the rendezvous, two warm-up
+barriers, one MAX-reduce of the elapsed time and one all-gather of per-rank numbers; the barrier on both sides of the timed
+span is the node's own (LocalBarrier, --span-barrier).  --boards-per-gpu B fixes the per-GPU shard instead
 ("weak" scaling).  For N>1 launch with torchrun (the driver does), one rank per GPU.
 By default K timed plies that take more than one launch are replayed as one hipGraph whose kernel nodes take the
 ply index from a device-resident counter (gbl_rollout_at + gbl_counter_add); a timed run of ONE launch (the
-driver's 20 plies) is launched eagerly.  Either way the K plies are played once UNTIMED through the same code path
+driver's 20 plies) is launched eagerly, with the ply index by value.  Either way the K plies are played once UNTIMED through the same code path
 first and the timed pass plays K fresh plies; --graph 0 launches eagerly always.
 
 Rank 0 prints ONE compact JSON line (< 4 kB; the task's bench contract) as the LAST line of stdout:
