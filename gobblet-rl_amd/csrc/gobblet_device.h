@@ -181,9 +181,22 @@ __device__ __forceinline__ void tile_out(int8_t *__restrict__ g, const uint32_t 
         for (int i = 0; i < FULL; ++i) store16<P>(&gv[lane + 64 * i], v[i]);
         if (REM && lane < REM) store16<P>(&gv[lane + 64 * FULL], v[FULL]);
     } else {
-        int bytes = rows * ROWB;
+        // the ragged last tile: the whole 16-byte vectors of its rows as above, then the last few bytes (byte by byte all the way it
+        // was up to 115 round trips, ~3 us, and a launch lasts as long as its slowest tile: 65 599 boards ran 4.66 us per ply where
+        // 65 536 run 1.70 -- round 5)
+        const int bytes = rows * ROWB, nvec = bytes >> 4;
+        uint4 *gv = reinterpret_cast<uint4 *>(g);
+        const uint4 *lv = reinterpret_cast<const uint4 *>(lds);
+        constexpr int P = NT == kStoreStreamDrop ? kStoreStream : NT;
+        uint4 v[FULL + 1];
+#pragma unroll
+        for (int i = 0; i <= FULL; ++i) v[i] = lv[lane + 64 * i < NV ? lane + 64 * i : NV - 1];
+#pragma unroll
+        for (int i = 0; i <= FULL; ++i)
+            if (lane + 64 * i < nvec) store16<P>(&gv[lane + 64 * i], v[i]);
         const int8_t *lb = reinterpret_cast<const int8_t *>(lds);
-        for (int i = lane; i < bytes; i += 64) g[i] = lb[i];
+        const int i = (nvec << 4) + lane;
+        if (i < bytes) g[i] = lb[i];
     }
 }
 
@@ -238,13 +251,16 @@ __device__ __forceinline__ void tile_fetch(const uint32_t *lds, int lane, uint4 
     v[FULL] = lv[REM && lane < REM ? lane + 64 * FULL : lane];
 }
 
+// `bytes`: what of the image leaves -- the whole tile, or the WHOLE vectors of a ragged last tile's rows (a multiple of 16; its
+// last few bytes go out with sub_tail while the image still stands)
 template <int ROWB, int NT = kStorePlain>
-__device__ __forceinline__ void tile_store(int8_t *__restrict__ g, const uint4 (&v)[kTile * ROWB / 16 / 64 + 1], int lane)
+__device__ __forceinline__ void tile_store(int8_t *__restrict__ g, const uint4 (&v)[kTile * ROWB / 16 / 64 + 1], int lane,
+                                           int bytes = kTile * ROWB)
 {
     constexpr int NV = kTile * ROWB / 16, FULL = NV / 64, REM = NV % 64;
 #ifndef GBL_HOST_EMU
     if constexpr (NT == kStoreStreamDrop) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g, 0, kTile * ROWB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g, 0, bytes, 0x00020000);  // (lanes beyond it: dropped)
 #pragma unroll
         for (int i = 0; i < FULL; ++i) {
             vec4u t = {v[i].x, v[i].y, v[i].z, v[i].w};
@@ -259,9 +275,11 @@ __device__ __forceinline__ void tile_store(int8_t *__restrict__ g, const uint4 (
 #endif
     constexpr int P = NT == kStoreStreamDrop ? kStoreStream : NT;
     uint4 *gv = reinterpret_cast<uint4 *>(g);
+    const int nvec = bytes >> 4;
 #pragma unroll
-    for (int i = 0; i < FULL; ++i) store16<P>(&gv[lane + 64 * i], v[i]);
-    if (REM && lane < REM) store16<P>(&gv[lane + 64 * FULL], v[FULL]);
+    for (int i = 0; i < FULL; ++i)
+        if (lane + 64 * i < nvec) store16<P>(&gv[lane + 64 * i], v[i]);
+    if (REM && lane < REM && lane + 64 * FULL < nvec) store16<P>(&gv[lane + 64 * FULL], v[FULL]);
 }
 
 // ---- sub-tiles: BPS boards per wavefront, LPB = 64 / BPS lanes per board (batches that do not fill the chip) -------------------
@@ -367,28 +385,39 @@ __device__ __forceinline__ void sub_fetch(const uint32_t *lds, int lane, SubVecs
     }
 }
 
+// `bytes`: what of the image leaves -- BPS * ROWB for a whole sub-tile; the WHOLE 16-byte vectors of a ragged one's rows (a multiple
+// of 16; its last few bytes go out with sub_tail, so that a ragged sub-tile takes the same deferred register path as a whole one:
+// the launch of a latency-bound batch lasts as long as its slowest wavefront, and the ragged one used to copy its rows LDS -> HBM
+// vector by vector inside the ply -- 16 447 boards 1.00 us per ply where 16 384 take 0.74 and 20 480 take 0.84).
 template <int ROWB, int NT, int BPS, int I = 0>
-__device__ __forceinline__ void sub_store(int8_t *__restrict__ g, SubVecs<sub_vectors<ROWB, BPS>()> &v, int lane)
+__device__ __forceinline__ void sub_store(int8_t *__restrict__ g, SubVecs<sub_vectors<ROWB, BPS>()> &v, int lane, int bytes = BPS * ROWB)
 {
-    constexpr int NV = BPS * ROWB / 16, N = sub_vectors<ROWB, BPS>();
+    constexpr int N = sub_vectors<ROWB, BPS>();
     if constexpr (I < N) {
         const int i = lane + 64 * I;
         const uint4 &x = v.template at<I>();
 #ifndef GBL_HOST_EMU
         if constexpr (NT == kStoreStreamDrop) {
-            // (no predicate: the descriptor covers exactly this sub-tile's rows, and the hardware drops a lane whose offset lies
-            //  beyond it -- the lanes past the image's last vector)
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g, 0, BPS * ROWB, 0x00020000);
+            // (no predicate: the descriptor covers exactly the bytes that leave, and the hardware drops a lane whose offset lies
+            //  beyond it -- the lanes past the last vector)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g, 0, bytes, 0x00020000);
             vec4u t = {x.x, x.y, x.z, x.w};
             __builtin_amdgcn_raw_buffer_store_b128(t, rs, i * 16, 0, 2 | 16);
         } else
 #endif
         {
             constexpr int P = NT == kStoreStreamDrop ? kStoreStream : NT;
-            if (64 * I + 63 < NV || i < NV) store16<P>(reinterpret_cast<uint4 *>(g) + i, x);
+            if (16 * i + 16 <= bytes) store16<P>(reinterpret_cast<uint4 *>(g) + i, x);
         }
-        sub_store<ROWB, NT, BPS, I + 1>(g, v, lane);
+        sub_store<ROWB, NT, BPS, I + 1>(g, v, lane, bytes);
     }
+}
+
+// the last bytes of a ragged sub-tile's rows, behind its whole vectors (< 16 bytes: one byte per lane, from the LDS image)
+__device__ __forceinline__ void sub_tail(int8_t *__restrict__ g, const uint32_t *lds, int lane, int bytes)
+{
+    const int i = (bytes & ~15) + lane;
+    if (i < bytes) g[i] = reinterpret_cast<const int8_t *>(lds)[i];
 }
 
 // zero image of a sub-tile's BPS observation rows

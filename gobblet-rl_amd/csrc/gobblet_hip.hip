@@ -738,12 +738,11 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
             uint4 vo[kTile * kObs / 16 / 64 + 1], vm[kTile * kActions / 16 / 64 + 1];
             pair_barrier();  // images ready
             const uint32_t act = s_small[L.lane][0], sc = s_small[L.lane][1];
-            if (L.rows == kTile) {
-                if (WITH_OBS) tile_fetch<kObs>(s_obs, L.lane, vo);
-                if (WITH_MASK) tile_fetch<kActions>(s_mask, L.lane, vm);
-            } else {  // the ragged last tile goes out byte by byte, straight from the images
-                if (WITH_OBS) tile_out<kObs, kPolicy>(obs_t + cell * kObs, s_obs, L.lane, L.rows);
-                if (WITH_MASK) tile_out<kActions, kPolicy>(mask_t + cell * kActions, s_mask, L.lane, L.rows);
+            if (WITH_OBS) tile_fetch<kObs>(s_obs, L.lane, vo);
+            if (WITH_MASK) tile_fetch<kActions>(s_mask, L.lane, vm);
+            if (L.rows != kTile) {  // the ragged last tile: the last few bytes of its rows straight from the images, now
+                if (WITH_OBS) sub_tail(obs_t + cell * kObs, s_obs, L.lane, L.rows * kObs);
+                if (WITH_MASK) sub_tail(mask_t + cell * kActions, s_mask, L.lane, L.rows * kActions);
             }
             if (WITH_OBS) {  // hand the observation image back zeroed: off the playing wavefront's path
                 wave_lds_fence();
@@ -758,10 +757,9 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
                 if (done_t) done_t[at] = (int8_t)((sc >> 24) & 1u);
                 if (to_move_t) to_move_t[at] = (int8_t)((sc >> 25) & 1u);
             }
-            if (L.rows == kTile) {
-                if (WITH_OBS) tile_store<kObs, kPolicy>(obs_t + cell * kObs, vo, L.lane);
-                if (WITH_MASK) tile_store<kActions, kPolicy>(mask_t + cell * kActions, vm, L.lane);
-            }
+            // (a ragged tile: the whole vectors of its rows -- the descriptor ends there)
+            if (WITH_OBS) tile_store<kObs, kPolicy>(obs_t + cell * kObs, vo, L.lane, (L.rows * kObs) & ~15);
+            if (WITH_MASK) tile_store<kActions, kPolicy>(mask_t + cell * kActions, vm, L.lane, (L.rows * kActions) & ~15);
         }
         return;
     }
@@ -870,20 +868,6 @@ struct SmallArgs {
     const int32_t *first_actions;
 };
 
-// a ragged last sub-tile's rows: whole 16-byte vectors (a sub-tile starts 16-byte aligned), then the last few bytes one by one
-// (byte by byte all the way, a ragged sub-tile of 15 observation rows took 28 round trips per ply: 1.3 instead of 0.8 us per ply
-// for the whole launch at 4 095 boards).  Inline: a real call would give the kernel a dynamic stack, i.e. scratch.
-__device__ __forceinline__ void sub_out_ragged(int8_t *__restrict__ g, const uint32_t *lds, int lane, int bytes)
-{
-    const int nv = bytes >> 4;
-    const uint4 *lv = reinterpret_cast<const uint4 *>(lds);
-    uint4 *gv = reinterpret_cast<uint4 *>(g);
-    for (int i = lane; i < nv; i += 64) gv[i] = lv[i];
-    const int8_t *lb = reinterpret_cast<const int8_t *>(lds);
-    const int i = (nv << 4) + lane;
-    if (i < bytes) g[i] = lb[i];
-}
-
 template <int ROLE, int LPB, bool SYNC>
 __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, uint32_t *mask_img, uint32_t *obs_img, uint32_t *draw_buf,
                                            int64_t sub)
@@ -944,6 +928,7 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
     SubVecs<MK ? sub_vectors<kActions, BPS>() : 0> vm{};
     SubVecs<OB ? sub_vectors<kObs, BPS>() : 0> vo{};
     int8_t *mdst = nullptr, *odst = nullptr;
+    const int obytes = rows * kObs, mbytes = rows * kActions;  // what leaves of this sub-tile's images per ply
     const uint32_t plies = A.plies;
     const int64_t cell0 = (sub >> SH) * A.tile_stride + (sub & (LPB - 1)) * BPS;
     // this ply's rows of the two row streams: advanced by a ply's stride per ply (no 64-bit multiply inside the chain)
@@ -1026,9 +1011,9 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
             if (SC) row.reset();
         }
         GBL_PHASE_DEP(3, p.nz);  // reset
-        if (t && full) {  // ply t - 1's rows
-            if constexpr (OB) sub_store<kObs, kRowPolicy, BPS>(odst, vo, lane);
-            if constexpr (MK) sub_store<kActions, kRowPolicy, BPS>(mdst, vm, lane);
+        if (t) {  // ply t - 1's rows (a ragged sub-tile's: the whole vectors of its rows)
+            if constexpr (OB) sub_store<kObs, kRowPolicy, BPS>(odst, vo, lane, obytes & ~15);
+            if constexpr (MK) sub_store<kActions, kRowPolicy, BPS>(mdst, vm, lane, mbytes & ~15);
         }
         if constexpr (SC) {
             tcount = next_turn(tcount, y, 1);
@@ -1062,8 +1047,8 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
             wave_lds_fence();
             odst = obs_at;
             obs_at += obs_step;
-            if (full) sub_fetch<kObs, BPS>(obs_img, lane, vo);
-            else sub_out_ragged(odst, obs_img, lane, rows * kObs);
+            sub_fetch<kObs, BPS>(obs_img, lane, vo);
+            if (!full) sub_tail(odst, obs_img, lane, obytes);
             wave_lds_fence();
         }
         GBL_PHASE(5);  // the observation image
@@ -1074,17 +1059,17 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
             wave_lds_fence();
             mdst = mask_at;
             mask_at += mask_step;
-            if (full) sub_fetch<kActions, BPS>(mask_img, lane, vm);
-            else sub_out_ragged(mdst, mask_img, lane, rows * kActions);
+            sub_fetch<kActions, BPS>(mask_img, lane, vm);
+            if (!full) sub_tail(mdst, mask_img, lane, mbytes);
             wave_lds_fence();
         }
         GBL_PHASE(7);  // the mask image
     }
     GBL_PHASE(7);  // (the last ply's mask image; phase 7 = the mask image of every ply but the last, see below)
     GBL_PHASE_FLUSH(wave_index());
-    if (full) {  // the last ply's rows
-        if constexpr (OB) sub_store<kObs, kRowPolicy, BPS>(odst, vo, lane);
-        if constexpr (MK) sub_store<kActions, kRowPolicy, BPS>(mdst, vm, lane);
+    if (plies) {  // the last ply's rows
+        if constexpr (OB) sub_store<kObs, kRowPolicy, BPS>(odst, vo, lane, obytes & ~15);
+        if constexpr (MK) sub_store<kActions, kRowPolicy, BPS>(mdst, vm, lane, mbytes & ~15);
     }
     if constexpr (SC) {
         wave_lds_fence();  // every board's byte patches are in the state image
@@ -1148,12 +1133,12 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
         const int64_t row_step = ply_stride * (is_mask ? kActions : kObs);
         for (uint32_t t = 0; t < plies; ++t) {
             pair_barrier();  // ply t's positions are in s_hand[t & 1] (and the player is free to go on with ply t + 1)
-            if (t && full) {  // ply t - 1's rows, read back at the end of the last iteration
+            if (t) {  // ply t - 1's rows, read back at the end of the last iteration (a ragged tile's: the whole vectors of its rows)
                 if constexpr (WITH_MASK) {
-                    if (is_mask) sub_store<kActions, kPolicy, kTile>(dst, vm, lane);
+                    if (is_mask) sub_store<kActions, kPolicy, kTile>(dst, vm, lane, (rows * kActions) & ~15);
                 }
                 if constexpr (WITH_OBS) {
-                    if (!is_mask) sub_store<kObs, kPolicy, kTile>(dst, vo, lane);
+                    if (!is_mask) sub_store<kObs, kPolicy, kTile>(dst, vo, lane, (rows * kObs) & ~15);
                 }
             }
             if constexpr (WITH_MASK) {
@@ -1162,8 +1147,8 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
                     mask_row_part<1>(reinterpret_cast<uint8_t *>(s_mask) + lane * kActions, ((uint64_t)lg.y << 32) | lg.x, 0);
                     wave_lds_fence();
                     dst = row_at;
-                    if (full) sub_fetch<kActions, kTile>(s_mask, lane, vm);
-                    else sub_out_ragged(dst, s_mask, lane, rows * kActions);
+                    sub_fetch<kActions, kTile>(s_mask, lane, vm);
+                    if (!full) sub_tail(dst, s_mask, lane, rows * kActions);
                     wave_lds_fence();
                 }
             }
@@ -1175,19 +1160,19 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
                     obs_scatter_row(reinterpret_cast<uint8_t *>(s_obs) + lane * kObs, Planes{h.x, h.y, h.z}, (int)h.w);
                     wave_lds_fence();
                     dst = row_at;
-                    if (full) sub_fetch<kObs, kTile>(s_obs, lane, vo);
-                    else sub_out_ragged(dst, s_obs, lane, rows * kObs);
+                    sub_fetch<kObs, kTile>(s_obs, lane, vo);
+                    if (!full) sub_tail(dst, s_obs, lane, rows * kObs);
                     wave_lds_fence();
                 }
             }
             row_at += row_step;
         }
-        if (full) {  // the last ply's rows
+        if (plies) {  // the last ply's rows
             if constexpr (WITH_MASK) {
-                if (is_mask) sub_store<kActions, kPolicy, kTile>(dst, vm, lane);
+                if (is_mask) sub_store<kActions, kPolicy, kTile>(dst, vm, lane, (rows * kActions) & ~15);
             }
             if constexpr (WITH_OBS) {
-                if (!is_mask) sub_store<kObs, kPolicy, kTile>(dst, vo, lane);
+                if (!is_mask) sub_store<kObs, kPolicy, kTile>(dst, vo, lane, (rows * kObs) & ~15);
             }
         }
         return;
