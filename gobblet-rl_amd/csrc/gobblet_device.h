@@ -138,11 +138,24 @@ __device__ __forceinline__ void tile_in(const int8_t *__restrict__ g, uint32_t *
 #pragma unroll
         for (int i = 0; i < FULL; ++i) lv[lane + 64 * i] = v[i];
         if (REM && lane < REM) lv[lane + 64 * FULL] = v[FULL];
-    } else {  // ragged last tile: byte granular
-        between();
-        int bytes = rows * ROWB;
+    } else {
+        // ragged last tile: the whole vectors of its rows in one round trip (clamped to the last whole one: nothing beyond the rows
+        // is read), then the last few bytes -- byte by byte all the way it was up to 27 serial round trips per launch (round 5)
+        const int bytes = rows * ROWB, nvec = bytes >> 4;
+        const uint4 *gv = reinterpret_cast<const uint4 *>(g);
+        uint4 *lv = reinterpret_cast<uint4 *>(lds);
         int8_t *lb = reinterpret_cast<int8_t *>(lds);
-        for (int i = lane; i < bytes; i += 64) lb[i] = g[i];
+        uint4 v[FULL + 1];
+        const int last = nvec > 0 ? nvec - 1 : 0;
+#pragma unroll
+        for (int i = 0; i <= FULL; ++i) v[i] = nvec > 0 ? gv[lane + 64 * i < nvec ? lane + 64 * i : last] : uint4{0u, 0u, 0u, 0u};
+        const int ti = (nvec << 4) + lane;
+        const int8_t tb = ti < bytes ? g[ti] : (int8_t)0;
+        between();
+#pragma unroll
+        for (int i = 0; i <= FULL; ++i)
+            if (lane + 64 * i < nvec) lv[lane + 64 * i] = v[i];
+        if (ti < bytes) lb[ti] = tb;
     }
 }
 
@@ -309,11 +322,22 @@ __device__ __forceinline__ void sub_in(const int8_t *__restrict__ g, uint32_t *l
 #endif
         if (lane < NV) lv[lane] = v[0];
         if (NV > 64 && lane + 64 < NV) lv[lane + 64] = v[1];
-    } else {  // ragged last sub-tile: byte granular
-        between();
-        const int bytes = rows * ROWB;
+    } else {  // ragged last sub-tile: its whole vectors (clamped: nothing beyond the rows is read), then the last few bytes (tile_in)
+        const int bytes = rows * ROWB, nvec = bytes >> 4;
+        const uint4 *gv = reinterpret_cast<const uint4 *>(g);
+        uint4 *lv = reinterpret_cast<uint4 *>(lds);
         int8_t *lb = reinterpret_cast<int8_t *>(lds);
-        for (int i = lane; i < bytes; i += 64) lb[i] = g[i];
+        uint4 v[2];
+        const int last = nvec > 0 ? nvec - 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) v[i] = nvec > 0 ? gv[lane + 64 * i < nvec ? lane + 64 * i : last] : uint4{0u, 0u, 0u, 0u};
+        const int ti = (nvec << 4) + lane;
+        const int8_t tb = ti < bytes ? g[ti] : (int8_t)0;
+        between();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (lane + 64 * i < nvec) lv[lane + 64 * i] = v[i];
+        if (ti < bytes) lb[ti] = tb;
     }
 }
 
