@@ -194,19 +194,15 @@ __device__ __forceinline__ void tile_out(int8_t *__restrict__ g, const uint32_t 
         for (int i = 0; i < FULL; ++i) store16<P>(&gv[lane + 64 * i], v[i]);
         if (REM && lane < REM) store16<P>(&gv[lane + 64 * FULL], v[FULL]);
     } else {
-        // the ragged last tile: the whole 16-byte vectors of its rows as above, then the last few bytes (byte by byte all the way it
-        // was up to 115 round trips, ~3 us, and a launch lasts as long as its slowest tile: 65 599 boards ran 4.66 us per ply where
-        // 65 536 run 1.70 -- round 5)
+        // the ragged last tile: the whole 16-byte vectors of its rows, then the last few bytes (byte by byte all the way it was up
+        // to 115 round trips, ~3 us, and a launch lasts as long as its slowest tile: 65 599 boards ran 4.66 us per ply where 65 536
+        // run 1.70 -- round 5).  A compact loop, NOT the unrolled fetch-then-store of the whole tiles: unrolled, the compiler
+        // re-balanced k_collect around it (111 -> 93 VGPRs) and the 2^20-board launch lost 2 %.
         const int bytes = rows * ROWB, nvec = bytes >> 4;
         uint4 *gv = reinterpret_cast<uint4 *>(g);
         const uint4 *lv = reinterpret_cast<const uint4 *>(lds);
-        constexpr int P = NT == kStoreStreamDrop ? kStoreStream : NT;
-        uint4 v[FULL + 1];
-#pragma unroll
-        for (int i = 0; i <= FULL; ++i) v[i] = lv[lane + 64 * i < NV ? lane + 64 * i : NV - 1];
-#pragma unroll
-        for (int i = 0; i <= FULL; ++i)
-            if (lane + 64 * i < nvec) store16<P>(&gv[lane + 64 * i], v[i]);
+#pragma nounroll
+        for (int i = lane; i < nvec; i += 64) gv[i] = lv[i];
         const int8_t *lb = reinterpret_cast<const int8_t *>(lds);
         const int i = (nvec << 4) + lane;
         if (i < bytes) g[i] = lb[i];

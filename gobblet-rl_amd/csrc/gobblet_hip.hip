@@ -89,6 +89,14 @@ constexpr int64_t kCollect2MaxTiles = 2048;  // 8 workgroups per CU (110 VGPRs: 
 int g_ab_collect_cfg = -1;  // A/B builds only: gbl_ab_collect_cfg() picks the form at run time (one library, many forms)
 #endif
 
+// k_collect's occupancy, pinned: FOUR wavefronts per SIMD.  Until round 5 that was an accident of the register allocation (111
+// VGPRs, most of them the ragged tile's byte loop's); when the ragged paths were rewritten the kernel needed 83, a fifth wavefront
+// fitted, and the 2^20-board launch lost 2 % (27.19 -> 27.69 us per ply at 8 plies per launch, 26.86 -> 27.49 at 20; min 3 / max 3:
+// 27.21 / 26.81; profiles/r05/collect_occupancy.txt) -- more tiles open at once is more write streams for the same DRAM pages.
+#ifndef GBL_COLLECT_WAVES_PER_EU
+#define GBL_COLLECT_WAVES_PER_EU 4, 4
+#endif
+
 inline int small_cfg(int64_t n, bool with_mask, bool with_obs)
 {
     (void)with_mask;
@@ -603,7 +611,7 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_rollout(int8_t *__restrict_
 // plies 4.15 vs 4.76 us per ply, 262 144 x 4: 8.5 vs 9.5 -- but 65 536 x 16: 2.44 vs 2.12); the host decides by the
 // footprint in A/B builds only (gpurun_out/ab5, scripts/sweep_sizes.py with -DGBL_FORCE_COLLECT_NT=0|1); the product streams.
 template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY, bool NT>
-__global__ __launch_bounds__(64) void k_collect(int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GBL_COLLECT_WAVES_PER_EU))) void k_collect(int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n,
                                                 int64_t ntiles, uint64_t seed, uint64_t env_base,
                                                 const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies,
                                                 int8_t *__restrict__ done, int64_t ply_stride, int64_t tile_stride,
