@@ -80,7 +80,10 @@ inline int nt_policy(int64_t n)
 // Which kernel a gbl_collect call runs (also reported by gbl_collect_variant): GBL_COLLECT_PAIR = k_collect2 (grids of up
 // to kCollect2MaxTiles tiles that stream), GBL_COLLECT_STREAM / GBL_COLLECT_CACHED = k_collect with non-temporal / plain
 // stores.  A pure function of the call's shape (and of the -D macros of an A/B build).
-constexpr int64_t kCollect2MaxTiles = 2048;  // 8 workgroups per CU (110 VGPRs: 4 wavefronts per SIMD); 4096 tiles would need two batches: 7.45 -> 7.81 us per ply
+// (round 5: the kernel needs 79 VGPRs since its ragged path stopped costing registers, and ten workgroups per CU are co-resident:
+//  147 456 boards 4.08 against k_collect's 4.24 us per ply, 163 840: 4.39 / 4.53; 196 608 = 3 072 tiles: 5.67 / 5.30 -- until then
+//  the limit was 2 048 tiles, eight workgroups of 122 VGPRs per CU)
+constexpr int64_t kCollect2MaxTiles = 2560;
 
 // Which form of the role kernel (k_collect_small<LA, KO, MERGE>, see there) a batch of n boards runs, as 100 LA + 10 KO + MERGE;
 // 0 = none (k_collect2 / k_collect).  Measured, us per ply, FULL outputs, 32 plies per launch (scripts/ab_roles.sh, round 5):

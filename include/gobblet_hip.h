@@ -304,7 +304,7 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
  * their records with it instead of re-deriving the library's dispatch rule.
  *   GBL_COLLECT_STREAM  k_collect,  one wavefront per tile of 64 boards, trajectory rows stored non-temporally
  *   GBL_COLLECT_CACHED  k_collect with plain stores (does not exist in the product build: A/B builds only)
- *   GBL_COLLECT_PAIR    k_collect2, two wavefronts per tile (one plays, one stores): grids of up to 2048 tiles
+ *   GBL_COLLECT_PAIR    k_collect2, two wavefronts per tile (one plays, one stores): grids of up to 2560 tiles
  *   GBL_COLLECT_TRIO    k_collect3, three wavefronts per tile: one plays and hands every ply's position over (one barrier per
  *                       ply), one builds and stores the mask rows, one the observation rows
  *   GBL_COLLECT_ROLES(la, ko, merge) = 1000 + 100 la + 10 ko + merge:  k_collect_small<la, ko, merge> -- batches that do

@@ -121,9 +121,9 @@ def test_bench_collect_record_vs_oracle(G, record):
 
 
 @pytest.mark.parametrize("n,with_obs,layout,illegal,device_ply", [
-    # one board more than the two-wavefronts-per-tile kernel takes: the first grid of the one-wavefront k_collect
-    (131073, True, "time", "noop", False), (131073, False, "time", "terminate", True),
-    (131073, True, "tile", "terminate", True), (131073, False, "tile", "noop", False),
+    # one board more than the two-wavefronts-per-tile kernel takes (2 560 tiles): the first grid of the one-wavefront k_collect
+    (163841, True, "time", "noop", False), (163841, False, "time", "terminate", True),
+    (163841, True, "tile", "terminate", True), (163841, False, "tile", "noop", False),
     # 2^20 boards x 4 plies, MASK_ONLY and FULL, both illegal modes
     (1 << 20, False, "time", "terminate", False), (1 << 20, True, "tile", "noop", False),
     # MASK_ONLY stays with k_collect3 up to 3 * 2^20 boards (the cases above): the first grid of k_collect<mask>, ragged
@@ -131,7 +131,7 @@ def test_bench_collect_record_vs_oracle(G, record):
 def test_collect_one_wavefront_kernel_vs_oracle(G, n, with_obs, layout, illegal, device_ply):
     """The large grids of gbl_collect directly against the oracle -- FULL: k_collect (one wavefront per tile: grids above 2 048
     tiles); MASK_ONLY: k_collect3's playing + mask-row wavefronts up to 3 * 2^20 boards, k_collect beyond -- both layouts, both
-    illegal modes, ply index by value and on the device; ragged last tiles at 131 073 and 3 145 729 boards."""
+    illegal modes, ply index by value and on the device; ragged last tiles at 163 841 and 3 145 729 boards."""
     variant = G._native.lib().gbl_collect_variant(n, 4, 1, int(with_obs))
     assert variant == (0 if with_obs or n > 3 * (1 << 20) else 3)
     T, seed, base, warm = 4, 17, 5_000_000_000, 9
@@ -145,7 +145,7 @@ def test_collect_one_wavefront_kernel_vs_oracle(G, n, with_obs, layout, illegal,
     check_trajectory(env, tr, T, warm, s, tm, dn, 0 if illegal == "noop" else 1, with_obs=with_obs)
 
 
-@pytest.mark.parametrize("n", [3000, 131073])
+@pytest.mark.parametrize("n", [3000, 163841])
 @pytest.mark.parametrize("null", ["mask", "obs", "both", "scalars"])
 def test_collect_c_abi_null_outputs(G, n, null):
     """gbl_collect called through the C-ABI with mask_traj / obs_traj / both / every scalar array NULL (k_collect and
@@ -236,12 +236,12 @@ def test_bench_step_mode_vs_oracle(G):
 
 
 @pytest.mark.parametrize("n,T,illegal,with_obs", [(131072, 2, "noop", True), (262144, 2, "terminate", True),
-                                                  (4099, 3, "terminate", False), (131073, 2, "noop", True), (70, 1, "noop", True),
+                                                  (4099, 3, "terminate", False), (163841, 2, "noop", True), (70, 1, "noop", True),
                                                   (12001, 2, "noop", True), (40001, 1, "terminate", True), (40001, 3, "noop", False),
                                                   (20001, 2, "terminate", True), (5001, 2, "terminate", True)])
 def test_collect_from_external_first_ply_vs_oracle(G, n, T, illegal, with_obs):
     """gbl_collect_from (bench records step_reply_*): the first ply plays caller-supplied actions -- an external policy's,
-    some of them illegal or out of range -- the rest are sampled; k_collect2 at 131 072 boards, k_collect beyond.  Three
+    some of them illegal or out of range -- the rest are sampled; k_collect2 at 131 072 boards, k_collect beyond 163 840.  Three
     launches in a row (the policy: the library's sampler on the previous launch's last mask, with wild actions thrown
     in), every slot against the oracle: batch_step for the given actions, batch_rollout for the replies."""
     seed, base, warm = 6, 314159, 8

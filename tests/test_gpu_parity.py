@@ -953,9 +953,9 @@ def test_load_state_dict_twice_and_graph_after_load(G):
 
 @pytest.mark.parametrize("n,with_obs,illegal", [(65, True, "noop"), (4099, True, "noop"), (4096, False, "terminate"),
                                                  (1, True, "noop"),
-                                                 # 2048 tiles: the largest grid of the two-wavefronts-per-tile kernel
+                                                 # 2560 tiles: the largest grid of the two-wavefronts-per-tile kernel
                                                  # (k_collect2); one board more: the first of k_collect
-                                                 (131072, True, "noop"), (131073, True, "terminate")])
+                                                 (163840, True, "noop"), (163841, True, "terminate")])
 def test_collect_equals_ply_by_ply_rollout(G, n, with_obs, illegal):
     """gbl_collect: T plies in one launch, every ply materialised in its trajectory slot == T launches of the
     fused single ply (gbl_rollout, plies = 1), which is itself checked against the oracle; state, turn and tallies
