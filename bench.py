@@ -266,19 +266,46 @@ class LocalBarrier:
     all-reduce kernel plus a synchronize on every rank."""
 
     def __init__(self, dist, rank, world):
+        self.rank, self.world, self.gen, self.dist, self.shm, self.slots = rank, world, 0, dist, None, None
+
+    @classmethod
+    def create(cls, dist, rank, world):
+        """The barrier, or None when some rank could not map the block (no usable /dev/shm, ranks that do not share one): every
+        rank learns the outcome, so that all of them fall back to torch.distributed's barrier together."""
         import numpy as np
         from multiprocessing import resource_tracker, shared_memory
-        self.rank, self.world, self.gen, self.dist = rank, world, 0, dist
+        self = cls(dist, rank, world)
         name = [None]
         if rank == 0:
-            self.shm = shared_memory.SharedMemory(create=True, size=64 * world)  # (zero-filled)
-            name[0] = self.shm.name
+            try:
+                self.shm = shared_memory.SharedMemory(create=True, size=64 * world)  # (zero-filled)
+                name[0] = self.shm.name
+            except OSError as e:
+                print(f"bench.py: no shared-memory block for the span barrier ({e}): torch.distributed's instead", file=sys.stderr)
         dist.broadcast_object_list(name, src=0)
-        if rank != 0:
-            self.shm = shared_memory.SharedMemory(name=name[0])
-            resource_tracker.unregister(self.shm._name, "shared_memory")  # (rank 0 owns the block: it alone unlinks it)
+        ok = name[0] is not None
+        if ok and rank != 0:
+            try:
+                self.shm = shared_memory.SharedMemory(name=name[0])
+                resource_tracker.unregister(self.shm._name, "shared_memory")  # (rank 0 owns the block: it alone unlinks it)
+            except OSError as e:
+                print(f"bench.py: rank {rank} cannot map the span barrier's block ({e})", file=sys.stderr)
+                ok = False
+        oks = [None] * world
+        dist.all_gather_object(oks, ok)  # (also: every rank is attached before anybody arrives)
+        if not all(oks):
+            self._release()
+            return None
         self.slots = np.ndarray((world, 8), dtype=np.int64, buffer=self.shm.buf)
-        dist.barrier()  # every rank is attached
+        return self
+
+    def _release(self):
+        self.slots = None
+        if self.shm is not None:
+            self.shm.close()
+            if self.rank == 0:
+                self.shm.unlink()
+            self.shm = None
 
     def wait(self, timeout_s=120.0):
         self.gen += 1
@@ -289,11 +316,8 @@ class LocalBarrier:
                 raise RuntimeError(f"bench.py: rank {self.rank} waited {timeout_s:.0f} s at the span barrier (generations {col.tolist()})")
 
     def close(self):
-        self.slots = None
         self.dist.barrier()  # nobody is still spinning on the block
-        self.shm.close()
-        if self.rank == 0:
-            self.shm.unlink()
+        self._release()
 
 
 class Pipeline:
@@ -863,7 +887,8 @@ def main():
     if dist is not None:
         local = int(os.environ.get("LOCAL_WORLD_SIZE", world)) == world
         if args.span_barrier == "local" and local:
-            lb = LocalBarrier(dist, rank, world)
+            lb = LocalBarrier.create(dist, rank, world)
+        if lb is not None:
             span_barrier, args.span_barrier_used = lb.wait, "node-local shared memory"
         else:
             span_barrier, args.span_barrier_used = dist.barrier, "torch.distributed (%s)" % args.dist_backend

@@ -94,7 +94,8 @@ def _barrier_worker(rank, world, initfile, outdir):
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
-    lb = bench.LocalBarrier(dist, rank, world)
+    lb = bench.LocalBarrier.create(dist, rank, world)
+    assert lb is not None
     before, after = [], []
     for i in range(50):
         if (i + rank) % world == 0:
