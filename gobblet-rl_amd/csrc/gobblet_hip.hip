@@ -4,6 +4,7 @@
 
 #include <stdio.h>
 #include <algorithm>
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
@@ -96,6 +97,8 @@ int g_ab_collect_cfg = -1;  // A/B builds only: gbl_ab_collect_cfg() picks the f
 // VGPRs, most of them the ragged tile's byte loop's); when the ragged paths were rewritten the kernel needed 83, a fifth wavefront
 // fitted, and the 2^20-board launch lost 2 % (27.19 -> 27.69 us per ply at 8 plies per launch, 26.86 -> 27.49 at 20; min 3 / max 3:
 // 27.21 / 26.81; profiles/r05/collect_occupancy.txt) -- more tiles open at once is more write streams for the same DRAM pages.
+constexpr int64_t kTrioHandMaxTiles = 8192;  // k_collect3<..., HAND>: the first row wavefront stores the scalars up to 524 288 boards
+
 #ifndef GBL_COLLECT_WAVES_PER_EU
 #define GBL_COLLECT_WAVES_PER_EU 4, 4
 #endif
@@ -116,7 +119,9 @@ inline int small_cfg(int64_t n, bool with_mask, bool with_obs)
     if (!with_obs) return n <= 8192 ? 210 : n <= 3 * (int64_t)(1 << 20) ? 3 : 0;
     // (with the trajectory arrays placed across HBM's memory classes: 40 960 boards k_collect3 1.31 against k_collect2's 1.40 us per
     //  ply, 49 152: 1.49 against 1.41 -- profiles/r05/placed_forms.txt)
-    return n <= 8192 ? 220 : n <= 16384 ? 120 : n <= 45056 ? 3 : 0;
+    // (late round 5: with its scalars stored by the first row wavefront k_collect3 runs 0.634 us per ply at 8 192 ... 16 384 boards,
+    //  256 plies per launch -- <1,2>: 0.643 at 12 288, 0.72 at 16 384; <2,2>: 0.558 at 8 192: profiles/r05/ab_trio_scalars.txt)
+    return n <= 8192 ? 220 : n <= 45056 ? 3 : 0;
 #endif
 }
 
@@ -1108,7 +1113,12 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
 // work is dealt evenly -- player ~235 (chain + scalars), mask ~80, observation ~200 -- and nothing is played twice, so it keeps
 // paying where the role kernel's redundant chains run out of idle SIMDs (from ~32 768 boards, three wavefronts per tile and SIMD).
 // Bit for bit the trajectories of k_collect.
-template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY>
+// HAND: the first row wavefront stores the ply's five scalars, which ride over with the legal mask -- ~25 instructions off the playing
+// wavefront, whose chain the launch waits for (MASK_ONLY 12 288 boards 0.63 -> 0.56 us per ply, 32 768: 0.67 -> 0.61, 262 144: 3.02 -> 2.75,
+// 524 288: 5.6 -> 5.2; FULL 20 480 ... 45 056: -2 ... -3 %).  Not beyond 524 288 boards: there MASK_ONLY runs at the chip's write rate on
+// every wavefront it can get, and the 1 KB of LDS the wider hand-over costs a workgroup is 3 % (786 432 boards 7.48 -> 7.72, 2^20:
+// 9.81 -> 10.07 whoever stores the scalars; profiles/r05/ab_trio_scalars.txt).
+template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY, bool HAND>
 __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))) void k_collect3(
     int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n, int64_t ntiles, uint64_t seed, uint64_t env_base,
     const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies, int8_t *__restrict__ done, int64_t ply_stride,
@@ -1121,7 +1131,10 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
     __shared__ uint32_t s_obs[WITH_OBS ? image_words<kObs>() : 4];
     __shared__ uint32_t s_mask[WITH_MASK ? image_words<kActions>() : 4];
     __shared__ uint4 s_hand[2][kTile];      // per ply parity and board: nz, neg, odd, mover
-    __shared__ uint2 s_legal[2][kTile];     // ... and the next mover's legal mask
+    // ... the next mover's legal mask (x, y) and, HAND, the ply's scalars for the first row wavefront to store: z = the action played,
+    // w = winner | r0 << 8 | r1 << 16 | done << 24 | next mover << 25
+    using LegalSlot = typename std::conditional<HAND, uint4, uint2>::type;
+    __shared__ LegalSlot s_legal[2][kTile];
     if (DEV_PLY) ply0 += *ply_dev;
     const int role = WAVES > 1 ? wave_index() : 0;
     const int lane = (int)(threadIdx.x & 63u);
@@ -1133,6 +1146,7 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
     const int64_t b = tile * kTile + lane;
     constexpr int kPolicy = kStoreStreamDrop;
     const int64_t cell0 = tile * tile_stride;
+    constexpr bool hand_scalars = HAND && WAVES > 1;  // (a launch without mask and observation arrays has nobody to hand them to)
     if (role != 0) {
         // ---- a row wavefront: the mask rows (role 1 when there are any) or the observation rows -----------------------------
         const bool is_mask = WITH_MASK && role == 1;
@@ -1142,8 +1156,22 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
         // this ply's rows: advanced by a ply's stride per ply (no 64-bit multiply per ply)
         int8_t *row_at = is_mask ? mask_t + cell0 * kActions : obs_t + cell0 * kObs;
         const int64_t row_step = ply_stride * (is_mask ? kActions : kObs);
+        int64_t scell = cell0 + lane;  // (role 1) this lane's cell of the scalar arrays at ply t
         for (uint32_t t = 0; t < plies; ++t) {
             pair_barrier();  // ply t's positions are in s_hand[t & 1] (and the player is free to go on with ply t + 1)
+            if constexpr (hand_scalars) {
+                if (role == 1) {  // the ply's five scalars leave from here
+                    const uint4 sc = s_legal[t & 1u][lane];
+                    if (valid) {
+                        if (actions_t) actions_t[scell] = (int32_t)sc.z;
+                        if (winner_t) winner_t[scell] = (int8_t)(sc.w & 0xFFu);
+                        if (reward_t) reinterpret_cast<uint16_t *>(reward_t)[scell] = (uint16_t)((sc.w >> 8) & 0xFFFFu);
+                        if (done_t) done_t[scell] = (int8_t)((sc.w >> 24) & 1u);
+                        if (to_move_t) to_move_t[scell] = (int8_t)((sc.w >> 25) & 1u);
+                    }
+                    scell += ply_stride;
+                }
+            }
             if (t) {  // ply t - 1's rows, read back at the end of the last iteration (a ragged tile's: the whole vectors of its rows)
                 if constexpr (WITH_MASK) {
                     if (is_mask) sub_store<kActions, kPolicy, kTile>(dst, vm, lane, (rows * kActions) & ~15);
@@ -1154,7 +1182,7 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
             }
             if constexpr (WITH_MASK) {
                 if (is_mask) {
-                    const uint2 lg = s_legal[t & 1u][lane];
+                    const LegalSlot lg = s_legal[t & 1u][lane];
                     mask_row_part<1>(reinterpret_cast<uint8_t *>(s_mask) + lane * kActions, ((uint64_t)lg.y << 32) | lg.x, 0);
                     wave_lds_fence();
                     dst = row_at;
@@ -1226,7 +1254,12 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
             row.reset();
         }
         s_hand[t & 1u][lane] = uint4{p.nz, p.neg, p.odd, (uint32_t)mover};
-        s_legal[t & 1u][lane] = uint2{(uint32_t)legal, (uint32_t)(legal >> 32)};
+        if constexpr (HAND)
+            s_legal[t & 1u][lane] = uint4{(uint32_t)legal, (uint32_t)(legal >> 32), (uint32_t)action,
+                                          ((uint32_t)y.winner & 0xFFu) | (((uint32_t)y.r0 & 0xFFu) << 8) | (((uint32_t)y.r1 & 0xFFu) << 16) |
+                                              ((uint32_t)dn << 24) | ((uint32_t)mover << 25)};
+        else
+            s_legal[t & 1u][lane] = uint2{(uint32_t)legal, (uint32_t)(legal >> 32)};
         if (WAVES > 1) pair_barrier();  // ply t handed over
         tcount = next_turn(tcount, y, 1);
         treset = treset || y.terminal;
@@ -1235,7 +1268,7 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
             w1 += __popcll(__ballot(valid && y.winner == 1));
             w2 += __popcll(__ballot(valid && y.winner == -1));
         }
-        if (valid) {
+        if (!hand_scalars && valid) {
             const int64_t at = cell + lane;
             if (actions_t) actions_t[at] = action;
             if (winner_t) winner_t[at] = (int8_t)y.winner;
@@ -2056,9 +2089,9 @@ bool launch_small(int cfg, int8_t *state, int8_t *to_move, int8_t *done, const i
         return true;                                                                                           \
     }
     GBL_SMALL_CFG(2, 2, false)
-    GBL_SMALL_CFG(1, 2, false)
     GBL_SMALL_CFG(2, 1, false)
 #ifdef GBL_AB_COLLECT_CFG
+    GBL_SMALL_CFG(1, 2, false)  // (the product's form for 8 193 ... 16 384 boards until k_collect3's scalars left its playing wavefront)
     GBL_SMALL_CFG(1, 1, false)
     GBL_SMALL_CFG(4, 1, false)
     GBL_SMALL_CFG(1, 4, false)
@@ -2448,10 +2481,14 @@ int gbl_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int32_t
     const bool pair = variant == GBL_COLLECT_PAIR;
     [[maybe_unused]] const bool nt = variant != GBL_COLLECT_CACHED;
     if (variant == GBL_COLLECT_TRIO) {
-#define GBL_TRIO_K(M, O, D)                                                                                                       \
-    hipLaunchKernelGGL((k_collect3<M, O, D>), dim3((uint32_t)g.ntiles), dim3(64 * (1 + (M ? 1 : 0) + (O ? 1 : 0))), 0, s, state, to_move, \
-                       n, g.ntiles, seed, env_base, ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj, \
-                       reward_traj, done_traj, to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn, first_actions)
+#define GBL_TRIO_KH(M, O, D, H)                                                                                                   \
+    hipLaunchKernelGGL((k_collect3<M, O, D, H>), dim3((uint32_t)g.ntiles), dim3(64 * (1 + (M ? 1 : 0) + (O ? 1 : 0))), 0, s, state,   \
+                       to_move, n, g.ntiles, seed, env_base, ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj,   \
+                       winner_traj, reward_traj, done_traj, to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn,      \
+                       first_actions)
+#define GBL_TRIO_K(M, O, D)                                     \
+    if (g.ntiles <= kTrioHandMaxTiles) { GBL_TRIO_KH(M, O, D, true); } \
+    else { GBL_TRIO_KH(M, O, D, false); }
 #define GBL_TRIO(M, O)                                          \
     if (ply_dev) { GBL_TRIO_K(M, O, true); }                    \
     else { GBL_TRIO_K(M, O, false); }
@@ -2460,6 +2497,7 @@ int gbl_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int32_t
         else { GBL_TRIO(false, true); }
 #undef GBL_TRIO
 #undef GBL_TRIO_K
+#undef GBL_TRIO_KH
         GBL_LAUNCHED("gbl_collect");
     }
     if (GBL_COLLECT_IS_ROLES(variant)) {

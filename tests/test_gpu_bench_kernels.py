@@ -282,8 +282,8 @@ def test_collect_from_external_first_ply_vs_oracle(G, n, T, illegal, with_obs):
 # every form the dispatch can pick, with ragged last groups (1, 15, 17, 33, 63 rows: observation wavefronts whose share of the
 # group is partial, or empty) and whole ones
 SMALL_SIZES = [1, 15, 16, 17, 31, 33, 63, 65, 4096, 4099, 8192,   # FULL <2,2>: groups of 32 boards, two observation wavefronts of 16; MASK_ONLY <2,1>
-               8193, 8209, 8241, 12321, 16384]                   # FULL <1,2>: a tile per scalars / mask wavefront, two observation wavefronts of 32
-TRIO_SIZES = [16385, 16447, 32768, 45056, 57344]                 # k_collect3 (FULL up to 45 056 boards; MASK_ONLY 8 193 ... 3 * 2^20)
+               8193, 8209, 8241, 12321, 16384]                   # k_collect3 (until late round 5 FULL ran <1,2> here)
+TRIO_SIZES = [16385, 16447, 32768, 45056, 57344]                 # k_collect3 (FULL 8 193 ... 45 056 boards; MASK_ONLY 8 193 ... 3 * 2^20)
 
 
 @pytest.mark.parametrize("with_obs", [True, False], ids=["full", "maskonly"])
@@ -293,7 +293,7 @@ def test_small_batch_collect_vs_oracle(G, n, with_obs):
     directly against the oracle, FULL and MASK_ONLY, time- and tile-major slots, both illegal modes, ply index by value and on
     the device, tallies and turn counters; ragged last sub-tiles and whole ones of every form."""
     variant = G._native.lib().gbl_collect_variant(n, 7, 1, int(with_obs))
-    assert variant >= 1000 or (variant == 3 and not with_obs and n > 8192)  # GBL_COLLECT_ROLES(...) (MASK_ONLY beyond 8 192 boards: k_collect3)
+    assert (variant >= 1000) if n <= 8192 else variant == 3  # GBL_COLLECT_ROLES(...) up to 8 192 boards, k_collect3 beyond
     small_batch_case(G, n, with_obs)
 
 
