@@ -7,13 +7,12 @@ instantiation each one reaches.  Bit-exact (integer / byte work).
     ----------------------------  ----------------------------------------  -------------------------------------------
     headline (2^20, collect)      gbl_collect, ply index on the device      k_collect<mask, obs, DEV_PLY, NT>, 8 and 20 plies per launch
     c2_4096                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 2, 2, false>  (<= 8 192 boards)
-    c_16384                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 1, 2, false>  (<= 16 384 boards)
-    c_32768                       gbl_collect                               k_collect3<mask, obs, DEV_PLY>  (<= 45 056 boards)
+    c_16384, c_32768              gbl_collect                               k_collect3<mask, obs, DEV_PLY, HAND>  (8 193 ... 45 056 boards)
     c_65536                       gbl_collect                               k_collect2<mask, obs, DEV_PLY>
     c3_262144                     gbl_collect                               k_collect<mask, obs, DEV_PLY, NT>
-    c4_shard_131072               gbl_collect                               k_collect2<mask, obs, DEV_PLY>  (2048 tiles)
+    c4_shard_131072               gbl_collect                               k_collect2<mask, obs, DEV_PLY>  (up to 2560 tiles)
     large_4194304                 gbl_collect                               k_collect<mask, obs, DEV_PLY, NT>, identity tile map
-    maskonly_1048576              gbl_collect, obs_traj = NULL              k_collect<mask, -, DEV_PLY, NT>
+    maskonly_1048576              gbl_collect, obs_traj = NULL              k_collect3<mask, -, DEV_PLY, no HAND>  (MASK_ONLY up to 3 * 2^20 boards)
     single_ply_{1048576,262144,   gbl_rollout_at(plies = 1)                 k_rollout<mask, obs, NT = 1, DEV_PLY, ONE_PLY>
       131072,4096}
     single_ply_large_4194304      gbl_rollout_at(plies = 1)                 k_rollout<mask, obs, NT = 3, DEV_PLY, ONE_PLY>
