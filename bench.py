@@ -2,7 +2,7 @@
 """bench.py -- env-steps/s of the batched Gobblet hot path on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--boards B | --boards-per-gpu B]
-                    [--mode collect|fused|step] [--traj T] [--graph 0|1] [--no-obs] [--no-configs] [--no-cpu-baseline]
+                    [--mode collect|fused|step|step2] [--traj T] [--graph 0|1] [--no-obs] [--no-configs] [--no-cpu-baseline]
 
 One "step" = one lockstep ply of the benchmark pipeline over this rank's shard of boards -- masked-uniform
 sampling + raw_env.step + observe of the next mover, with EVERY ply's action, mask, obs, winner, reward, done and
@@ -12,8 +12,11 @@ next mover materialised in HBM where a consumer can read them:
                  LDS / registers between the plies of a launch, so the state crosses HBM once per T plies.
     mode fused : gbl_rollout(plies=1) -- ONE launch per ply, the ply's outputs overwrite the environment's
                  tensors (round 1's pipeline; 234 algorithmic bytes per env-step).
-    mode step  : gbl_sample (action from the mask buffer) + gbl_step (externally supplied
-                 actions: the drop-in form of raw_env.step + observe) -- two launches per ply.
+    mode step  : gbl_step_ex -- externally supplied actions (the drop-in form of raw_env.step + observe: the action array is READ
+                 from HBM like any policy's output) and, in the same launch, the next mover's masked-uniform draw from the mask the
+                 launch stores, written over the action array: ONE launch per ply (round 6; the sampler's launch and its 58 bytes
+                 per board are gone).
+    mode step2 : gbl_sample (action from the mask buffer) + gbl_step -- two launches per ply (rounds 1-5's `step`).
 Workload (BASELINE.json metric / BASELINE.md C4): 2^20 boards IN TOTAL, sharded by contiguous global index
 over the N GPUs (131 072 per GPU at N = 8; "strong" scaling), all reset, W warm-up plies of masked-random play
 with auto-reset (stationary mix of game phases), then K timed plies; synthetic data, RNG keyed (seed=0, global
@@ -84,8 +87,10 @@ CONFIG_RECORDS = {
     "single_ply_131072": (131072, 200, False, "fused"), "single_ply_4096": (4096, 200, False, "fused"),
     "single_ply_maskonly_1048576": (1 << 20, 200, True, "fused"),
     "single_ply_large_4194304": (1 << 22, 40, False, "fused"),
-    # externally supplied actions: gbl_sample + gbl_step, two launches per ply
-    "step_pipeline_1048576": (1 << 20, 200, False, "step"),
+    # externally supplied actions, the next mover's draw fused into the step's launch (gbl_step_ex): one launch per ply
+    "step_pipeline_1048576": (1 << 20, 200, False, "step"), "step_pipeline_131072": (131072, 200, False, "step"),
+    # ... and rounds 1-5's form of it: gbl_sample + gbl_step, two launches per ply
+    "step_two_launch_1048576": (1 << 20, 200, False, "step2"),
 }
 # ... plus two records with their own drivers: c5_greedy_65536 (greedy_run) and greedy_collect_65536 (greedy_collect_run)
 EXTRA_RECORDS = ("c5_greedy_65536", "greedy_collect_65536", "step_reply_131072", "step_reply_262144")
@@ -101,7 +106,7 @@ def parse():
     ap.add_argument("--boards", "--total-boards", dest="boards", type=int, default=TOTAL_BOARDS,
                     help="TOTAL boards, split over the GPUs (strong scaling: BASELINE.md C4)")
     ap.add_argument("--boards-per-gpu", type=int, default=0, help="fixed per-GPU shard instead (weak scaling)")
-    ap.add_argument("--mode", choices=["collect", "fused", "step"], default="collect")
+    ap.add_argument("--mode", choices=["collect", "fused", "step", "step2"], default="collect")
     ap.add_argument("--traj", type=int, default=0,
                     help="plies per launch in mode collect; 0 = by shard size (auto_traj: 1024 for <= 8192 boards per GPU ... 8 "
                          "at 2^20, 4 from 2^22), never more than --steps")
@@ -190,19 +195,21 @@ def cpu_baseline(boards, warmup, target_s):
         tenv.rollout(warmup)
         T = 8
         tbuf = tenv.trajectory_buffers(T, placement="any")
-        raw.gbl_cpu_set_threads(cores)
-        tenv.collect(T, out=tbuf, refresh=False)
-        t0 = time.perf_counter()
-        reps = 0
-        while time.perf_counter() - t0 < max(1.0, target_s / 4):
+        try:
+            raw.gbl_cpu_set_threads(cores)
             tenv.collect(T, out=tbuf, refresh=False)
-            reps += 1
-        dtw = time.perf_counter() - t0
-        raw.gbl_cpu_set_threads(1)
-        t0 = time.perf_counter()
-        tenv.collect(T, out=tbuf, refresh=False)
-        d1w = time.perf_counter() - t0
-        raw.gbl_cpu_set_threads(0)
+            t0 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t0 < max(1.0, target_s / 4):
+                tenv.collect(T, out=tbuf, refresh=False)
+                reps += 1
+            dtw = time.perf_counter() - t0
+            raw.gbl_cpu_set_threads(1)
+            t0 = time.perf_counter()
+            tenv.collect(T, out=tbuf, refresh=False)
+            d1w = time.perf_counter() - t0
+        finally:
+            raw.gbl_cpu_set_threads(0)  # (the library's thread count is process-wide: later host-flavour calls get the default back)
         twin = {"twin_value": nt * T * reps / dtw, "twin_value_1core": nt * T / d1w,
                 "twin_sample": f"{nt} boards x {T * reps} plies, gbl_cpu_collect (host flavour of the ABI), {cores} threads"}
     except Exception as e:  # noqa: BLE001  (no C++ compiler on the box: the port's numbers stand alone)
@@ -335,6 +342,9 @@ class Pipeline:
         self.host_ply = 0      # ... and the host's copy of it: an eager launch can take the ply index BY VALUE
         self.owed = 0          # plies played by value that the device-resident index has not been told of yet (settle())
         self.traj = None
+        if mode == "step":  # the action array holds the draw for ply 0; every launch leaves the next ply's behind
+            self.nat.check(self.lib.gbl_sample_at(self.P["mk"], self.P["ac"], boards, env.seed, env.env_base, 0, None,
+                                                  self.nat.current_stream(dev)), "gbl_sample_at")
         if mode == "collect":
             self.traj = env.trajectory_buffers(self.T, placement=placement, far=True)  # (the benchmark owns the device)
             f = self.traj["_full"]
@@ -363,6 +373,11 @@ class Pipeline:
         P, lib, env, n = self.P, self.lib, self.env, self.boards
         assert not by_value or (self.mode == "collect" and self.host_ply is not None)
         if self.mode == "step":
+            if ev:
+                ev[0].record()
+            rc = lib.gbl_step_ex(P["sq"], P["tm"], P["dn"], P["ac"], P["wi"], P["rw"], P["mk"], P["ob"], None, None, None, None,
+                                 None, P["ac"], env.seed, env.env_base, off + 1, self.ctr.data_ptr(), n, 0, 1, stream)
+        elif self.mode == "step2":
             rc = lib.gbl_sample_at(P["mk"], P["ac"], n, env.seed, env.env_base, off, self.ctr.data_ptr(), stream)
             self.nat.check(rc, "gbl_sample_at")
             if ev:
@@ -431,9 +446,19 @@ class Pipeline:
         # which form of the kernel the library runs for this shape: asked of the library, not re-derived here
         variant = self.lib.gbl_collect_variant(self.boards, self.T, 1, 0 if self.no_obs else 1)
         collect = collect_kernel_name(variant)
-        name = {"step": "k_step", "fused": "k_rollout (plies=1)", "collect": f"{collect} ({self.T} plies per launch)"}[self.mode]
+        name = {"step": "k_step<EXT> (next draw fused)", "step2": "k_step", "fused": "k_rollout (plies=1)",
+                "collect": f"{collect} ({self.T} plies per launch)"}[self.mode]
+        # SURVEY.md 8(d)'s figure for the same env-steps: 234 (117 MASK_ONLY) bytes per env-step, state and action crossing HBM every
+        # ply.  gbl_collect keeps the board in LDS for the T plies of a launch and WRITES the action instead of reading it, so it
+        # moves fewer bytes than that and the fraction on SURVEY's bytes can exceed 1: it says how far the K-plies-per-launch design
+        #  is ahead of a ply-per-launch pipeline running AT the HBM peak, it is not an achieved bandwidth.
+        survey = ALGO_BYTES_MASK_ONLY if self.no_obs else ALGO_BYTES_FULL
+        frac_survey = survey * self.boards * plies_timed / kernel_s / 1e9 / HBM_PEAK_GBPS
+        accounting = ("SURVEY 8d, every ply: 234 B/board (117 MASK_ONLY); reward 2 B written, not counted" if self.mode != "collect" else
+                      "state once per launch: (178*T+57) B/board (MASK_ONLY 61*T+57); reward 2 B/step written, not counted")
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "algorithmic_bytes_survey": survey, "frac_on_survey_bytes": frac_survey, "accounting": accounting,
                 "kernel": name + ("<mask>" if self.no_obs else "<mask,obs>"),
                 "algorithmic_bytes_per_env_step": total_bytes / (self.boards * plies_timed),
                 "algorithmic_bytes_per_launch": total_bytes / launches,
@@ -450,7 +475,7 @@ def attach_traffic(roof, p, plies_per_launch):
     """roofline.traffic of pipeline p: measured HBM bytes per launch of its dominant kernel (committed PMC passes of the
     same launch shape), and their ratio to the algorithmic bytes of that launch; null (with the reason) when the
     committed counters were taken on other kernel sources or there are none for this shape."""
-    key = traffic_key(p.mode if p.mode != "step" else "step", p.no_obs, p.boards, plies_per_launch)
+    key = traffic_key(p.mode, p.no_obs, p.boards, plies_per_launch)
     roof["traffic"], roof["traffic_source"] = committed_counter(key, "hbm_bytes_per_launch")
     if roof["traffic"] is not None:
         roof["traffic_plies_per_launch"] = plies_per_launch
@@ -480,13 +505,64 @@ def short_run(G, torch, dev, boards, K, W, no_obs=False, mode="collect", traj=32
            "roofline": attach_traffic(p.kernel_roofline(s, K, launches,
                                                         "HIP events around the graph replay (includes kernel boundaries)"),
                                       p, min(p.T, K) if mode == "collect" else 1)}
-    if mode == "step":
+    if mode == "step2":
         rec["roofline"]["note"] = ("two kernels per ply (k_sample 58 B + k_step 234 B algorithmic per board): the fraction is "
                                    "the whole ply's time against k_step's 234 bytes")
+    if mode == "step":
+        rec["roofline"]["note"] = ("one kernel per ply: SURVEY 8(d)'s 234 bytes (the action is read from HBM) + the 4 bytes of the next "
+                                   "action it writes, which the fraction does not count")
     if p.traj is not None:
         rec["trajectory_placement"] = p.traj["_placement"]
     del g, p
     return rec
+
+
+def shard_span_run(G, torch, dev, boards, K, W, placement="auto"):
+    """What ONE rank of an N-GPU run of the driver's command does, timed on this GPU: a shard of `boards` boards, W warm-up plies,
+    the K plies rehearsed once, then the K plies inside a host span with a synchronize on both sides (the contract's span without
+    the barrier, which one process cannot rehearse).  Returns (span seconds, kernel seconds by HIP events)."""
+    T = auto_traj(boards, K)
+    p = Pipeline(G, torch, boards, 0, dev, mode="collect", traj=T, placement=placement)
+    p.eager(W)
+    plan = p.plan(K)
+    graph = p.capture(K) if len(plan) > 1 else None
+    ev = p.events(1 if graph is not None else len(plan))
+    stream = p.nat.current_stream(dev)
+
+    def play():
+        if graph is not None:
+            ev[0][0].record(); graph.replay(); ev[0][1].record()
+        else:
+            for i, (off, plies) in enumerate(plan):
+                p.enqueue(off, plies, stream, ev[i], by_value=True)
+            p.played(K)
+    play()
+    torch.cuda.synchronize(dev)
+    spans, kernels = [], []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        play()
+        torch.cuda.synchronize(dev)
+        spans.append(time.perf_counter() - t0)
+        kernels.append(sum(a.elapsed_time(b) for a, b in ev) / 1e3)
+    p.settle(stream)
+    i = sorted(range(5), key=lambda j: spans[j])[2]  # the median pass
+    return spans[i], kernels[i]
+
+
+def scale_prediction(G, torch, dev, total, K, W, value_n1, placement="auto"):
+    """Predicted 2 / 4 / 8-GPU lines of THIS command from one GPU (no multi-GPU node was ever available to the builder; a SCALE
+    record can be checked against it): the boards shard without a collective, so an N-GPU run is N copies of the total / N-board
+    shard's span side by side; what one GPU cannot show is the span barrier's skew between ranks (bench.py's is node-local shared
+    memory, ~1 us) and host jitter across N processes -- the prediction is an upper bound by those."""
+    out = {}
+    for n in (2, 4, 8):
+        span, kern = shard_span_run(G, torch, dev, total // n, K, W, placement)
+        value = total * K / span
+        out[str(n)] = {"boards_per_gpu": total // n, "span_us": span * 1e6, "kernel_us": kern * 1e6, "value_predicted": value,
+                       "efficiency_predicted": value / (n * value_n1),
+                       "efficiency_kernel_only": (total * K / kern) / (n * value_n1)}
+    return out
 
 
 def step_reply_run(G, torch, dev, boards, K, W):
@@ -654,7 +730,18 @@ def greedy_collect_run(G, torch, dev, boards=65536, T=16, launches=8, policies=(
 
 COMPACT_LIMIT = 4096  # bytes: the driver keeps the tail of stdout only; the contract line must fit it with room to spare
 ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel",
-                 "algorithmic_bytes_per_env_step", "algorithmic_bytes_per_launch", "mean_launch_us", "launches_timed", "timing")
+                 "algorithmic_bytes_per_env_step", "algorithmic_bytes_per_launch", "algorithmic_bytes_survey", "frac_on_survey_bytes",
+                 "accounting", "mean_launch_us", "launches_timed", "timing")
+# The sub-records every driver-parsed line carries as [value, us per step, fraction of the bound's peak]: the
+# other BASELINE configs (C2, C3, C4's shard, C5), the SURVEY-8(d)-clean one-ply kernel (234 B per env-step) and the externally
+# stepped pipeline.  The full records stay in the configs file.
+COMPACT_CONFIGS = ("c2_4096", "c3_262144", "c4_shard_131072", "c5_greedy_65536", "single_ply_1048576", "step_pipeline_1048576",
+                   "step_pipeline_131072", "greedy_collect_65536", "maskonly_1048576")
+
+
+def sig(x, digits=4):
+    """x rounded to `digits` significant digits (the compact line carries numbers, not noise)."""
+    return None if x is None else float(f"{x:.{digits}g}")
 CPU_BASELINE_KEYS = ("value", "unit", "cores", "kind", "sample", "value_1core", "twin_value", "twin_value_1core")
 
 
@@ -688,7 +775,7 @@ def contract_record(args, p, roof, total, boards, world, K, W, elapsed, local_el
                                f"+winner+reward+done) every ply, no collective on the step path",
                    "boards_per_gpu": boards, "total_boards": total, "mode": args.mode,
                    "plies_per_launch": args.traj if args.mode == "collect" else 1,
-                   "launches_timed": nlaunch * (2 if args.mode == "step" else 1),
+                   "launches_timed": nlaunch * (2 if args.mode == "step2" else 1),
                    "launch": "hipGraph replay" if graphed else "eager launches",
                    # the dominant kernel's mean launch duration on the slowest / fastest rank (HIP events), timed pass
                    "kernel_us_max": max(per_rank_us), "kernel_us_min": min(per_rank_us),
@@ -699,6 +786,8 @@ def contract_record(args, p, roof, total, boards, world, K, W, elapsed, local_el
                    # each rank's own span, from the synchronize behind the leading barrier to the synchronize behind its last
                    # launch, without the trailing barrier (MAX over ranks): round 4's `ms_per_step`
                    "ms_per_step_own_span": local_elapsed / K * 1e3,
+                   # both definitions of the headline under stable names: `value` IS value_contract_span
+                   "value_contract_span": total * K / elapsed, "value_own_span": total * K / local_elapsed,
                    # ranks that took part in the barriers / reductions over RCCL (0: none, or a gloo rehearsal)
                    "rccl_ranks": world if (distributed and args.dist_backend == "nccl") else 0,
                    "dist_backend": (args.dist_backend if distributed else None),
@@ -722,7 +811,7 @@ def contract_record(args, p, roof, total, boards, world, K, W, elapsed, local_el
 
 def compact_line(full, configs_path):
     """The ONE line of stdout: the contract's keys, flat `roofline` and `cpu_baseline`, nothing nested deeper and no lists."""
-    line = {k: v for k, v in full.items() if k not in ("configs", "cpu_baseline", "roofline", "detail", "config")}
+    line = {k: v for k, v in full.items() if k not in ("configs", "cpu_baseline", "roofline", "detail", "config", "scale_prediction")}
     line["config"] = dict(full["config"])
     if "configs" in full:
         line["config"]["configs_file"] = configs_path
@@ -734,9 +823,23 @@ def compact_line(full, configs_path):
         line["roofline"]["traffic_source"] = src[:137] + "..."
     if "cpu_baseline" in full:
         line["cpu_baseline"] = {k: full["cpu_baseline"].get(k) for k in CPU_BASELINE_KEYS}
+    if "configs" in full:
+        line["configs_compact"] = {"_": "[value, us_per_step, frac of the bound's peak]"}
+        for name in COMPACT_CONFIGS:
+            rec = full["configs"].get(name)
+            if rec:
+                line["configs_compact"][name] = [sig(rec.get("value")), sig(rec.get("us_per_step")),
+                                                 sig((rec.get("roofline") or {}).get("frac"), 3)]
+    for sub in ("config", "roofline", "cpu_baseline"):  # six significant digits are more than any of these numbers carries
+        for k, v in line.get(sub, {}).items():
+            if isinstance(v, float):
+                line[sub][k] = sig(v, 6)
+    if "scale_prediction" in full:  # [predicted whole-job env-steps/s, predicted efficiency vs N x this line] per N (see scale_prediction)
+        line["scale_prediction"] = {n: [sig(r["value_predicted"]), sig(r["efficiency_predicted"], 3)]
+                                    for n, r in full["scale_prediction"].items()}
     text = json.dumps(line)
     if len(text.encode()) > COMPACT_LIMIT:  # never print a line the driver's tail would cut: drop the prose first
-        for k in ("timing", "sample", "traffic_source"):
+        for k in ("timing", "sample", "traffic_source", "accounting"):
             line["roofline"].pop(k, None)
             line.get("cpu_baseline", {}).pop(k, None)
         text = json.dumps(line)
@@ -775,16 +878,32 @@ def keep_stdout_for_the_line():
         os.dup2(2, 1)
 
 
+def gpus_of_this_node():
+    """GPUs of this node counted WITHOUT torch or HIP (the launcher parent must not initialise the GPU before it starts its
+    children): the KFD topology's nodes with SIMDs.  None when /sys has no KFD topology (the ranks' own check then fires)."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None if os.path.exists("/dev/kfd") else 0  # (no compute device node at all: no ROCm GPU)
+    count = 0
+    for path in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+        except OSError:
+            return None
+        count += int(props.get("simd_count", "0")) > 0
+    return count
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves -- torch.distributed.run as a
-    CHILD process, before this process has imported torch or touched the GPU (nothing is exec'ed after HIP is
-    initialised) -- and pass its exit code on.  Rank 0's JSON line is the child's stdout, i.e. ours."""
+    CHILD process; this parent imports neither torch nor HIP (the devices are counted from /sys) -- and pass its exit code on.
+    Rank 0's JSON line is the child's stdout, i.e. ours."""
     import socket
     import subprocess
     if "--share-device" not in sys.argv:
-        import torch  # (counting devices does not initialise the GPU; the ranks are started as CHILD processes below)
-        ndev = torch.cuda.device_count()
-        if n > ndev:
+        ndev = gpus_of_this_node()
+        if ndev is not None and n > ndev:
             print(f"bench.py: --gpus {n} but this node has {ndev} GPU(s): one rank per GPU is the contract "
                   f"(--share-device + --dist-backend gloo rehearses more ranks on one card)", file=sys.stderr)
             return 2
@@ -814,8 +933,9 @@ def main():
     # FAIL FAST, before any rendezvous: more ranks than devices (e.g. `--gpus 8` under a launcher on a one-GPU box) would
     # otherwise hang in init_process_group / die in set_device on some ranks while the others wait for them
     ndev = torch.cuda.device_count()  # (does not initialise the GPU)
-    if not args.share_device and world > max(ndev, 0):
-        sys.exit(f"bench.py: {world} rank(s) but this node has {ndev} GPU(s): one rank per GPU is the contract "
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))  # (a multi-node launch: this node's ranks only)
+    if not args.share_device and local_world > max(ndev, 0):
+        sys.exit(f"bench.py: {local_world} rank(s) but this node has {ndev} GPU(s): one rank per GPU is the contract "
                  f"(--share-device + --dist-backend gloo rehearses more ranks on one card)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (there is no CPU fallback for the product path)")
@@ -920,7 +1040,7 @@ def main():
     if graph is None:
         kernel_s = sum(a.elapsed_time(b) for a, b in ev) / 1e3
         launches, timing = nlaunch, "HIP event pair around every launch of the dominant kernel"
-    elif args.mode != "step":
+    elif args.mode != "step2":
         kernel_s = ev[0][0].elapsed_time(ev[0][1]) / 1e3
         launches, timing = nlaunch, "HIP events around the graph replay of all launches (includes kernel boundaries)"
     else:
@@ -934,7 +1054,7 @@ def main():
     mean_kernel_s = kernel_s / launches
     # the headline's timed sample may be ONE launch: play the same K plies four more times (rank 0 reports the spread)
     repeats_us = []
-    if args.mode != "step":
+    if args.mode != "step2":
         repeats_us.append(pass_kernel_us())
         for _ in range(4):
             play_k()
@@ -982,6 +1102,8 @@ def main():
             cfg["c5_greedy_65536"] = greedy_run(G, torch, dev)
             cfg["greedy_collect_65536"] = greedy_collect_run(G, torch, dev)
             full["configs"] = cfg
+            if args.mode == "collect" and not args.boards_per_gpu and total % 8 == 0:
+                full["scale_prediction"] = scale_prediction(G, torch, dev, total, K, W, full["value"], args.placement)
         if world == 1 and not args.no_cpu_baseline:
             full["cpu_baseline"] = cpu_baseline(boards, W, args.cpu_seconds)
             ref = full["cpu_baseline"].get("greedy_depth2")

@@ -32,6 +32,7 @@ OK, ERR_ARG, ERR_ALIGN, ERR_HIP = 0, -1, -2, -3
 ILLEGAL_NOOP, ILLEGAL_TERMINATE = 0, 1
 POLICY_RANDOM, POLICY_GREEDY1, POLICY_GREEDY2, POLICY_GREEDY3 = 0, 1, 2, 3  # gbl_collect_policy
 HOW_RANDOM, HOW_GREEDY, HOW_FALLBACK = 0, 1, 2
+STATUS_ILLEGAL, STATUS_OUT_OF_RANGE = 1, 2  # gbl_step_ex / gbl_collect_from_ex status bits
 CELLS, ACTIONS, OBS_BYTES = 27, 54, 117
 COUNTER_STRIPES, COUNTER_STRIDE = 64, 16
 # gbl_board_eval record (include/gobblet_hip.h GBL_REC_*): field -> (byte offset, bytes)
@@ -58,6 +59,7 @@ SIGNATURES = {
     "gbl_pinned_free": (_int, [_vp]),
     "gbl_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
     "gbl_step_into": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
+    "gbl_step_ex": (_int, [_vp] * 14 + [_u64, _u64, _u32, _vp, _i64, _int, _int, _vp]),
     "gbl_sample": (_int, [_vp, _vp, _i64, _u64, _u64, _u32, _vp]),
     "gbl_rollout": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u64, _u64, _u32, _u32, _int, _vp, _vp, _vp]),
     "gbl_decode_obs": (_int, [_vp, _vp, _vp, _i64, _vp]),
@@ -71,6 +73,7 @@ SIGNATURES = {
                            _int, _vp, _vp, _vp]),
     "gbl_collect_from": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _u64, _u64, _u32, _vp, _u32,
                                 _int, _vp, _vp, _vp]),
+    "gbl_collect_from_ex": (_int, [_vp] * 12 + [_i64, _i64, _i64, _u64, _u64, _u32, _vp, _u32, _int, _vp, _vp, _vp]),
     "gbl_collect_policy": (_int, [_vp] * 14 + [_i64, _i64, _i64, _u64, _u64, _u32, _vp, _u32, _int, _int, _int, _int, _vp, _vp, _vp]),
     "gbl_collect_variant": (_int, [_i64, _u32, _int, _int]),
     "gbl_block_alloc": (_int, [_i64, C.POINTER(_vp)]),

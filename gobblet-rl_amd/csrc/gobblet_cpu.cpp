@@ -344,15 +344,17 @@ int gbl_cpu_board_eval(int8_t *state, const int8_t *agent_index, const int32_t *
     return GBL_OK;
 }
 
-int gbl_cpu_step_into(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out, int8_t *reward_out,
-                      int8_t *mask_out, int8_t *obs_out, int32_t *turn, int32_t *actions_out, int8_t *done_out,
-                      int8_t *to_move_out, int64_t n, int illegal_mode, int auto_reset, void *)
+int gbl_cpu_step_ex(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out, int8_t *reward_out,
+                    int8_t *mask_out, int8_t *obs_out, int32_t *turn, int32_t *actions_out, int8_t *done_out, int8_t *to_move_out,
+                    int8_t *status_out, int32_t *next_actions_out, uint64_t seed, uint64_t env_base, uint32_t ply,
+                    const uint32_t *ply_dev, int64_t n, int illegal_mode, int auto_reset, void *)
 {
     GBL_CHECK_N(n);
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done"); GBL_NEED(actions, "actions");
     if (illegal_mode != GBL_ILLEGAL_NOOP && illegal_mode != GBL_ILLEGAL_TERMINATE)
         return fail(GBL_ERR_ARG, "illegal_mode must be GBL_ILLEGAL_NOOP or GBL_ILLEGAL_TERMINATE");
     auto_reset = auto_reset != 0;
+    if (ply_dev) ply += *ply_dev;
     parallel_for(n, [=](int64_t b0, int64_t b1) {
         for (int64_t b = b0; b < b1; ++b) {
             uint32_t r[7];
@@ -369,20 +371,31 @@ int gbl_cpu_step_into(int8_t *state, int8_t *to_move, int8_t *done, const int32_
             if (reward_out) { reward_out[2 * b] = (int8_t)y.r0; reward_out[2 * b + 1] = (int8_t)y.r1; }
             if (turn) turn[b] = next_turn(turn[b], y, auto_reset);
             if (obs_out) write_obs(obs_out + b * kObs, p, mover);
-            if (mask_out) write_mask(mask_out + b * kActions, next_mask(p, mover, dn, auto_reset));
+            const uint64_t legal = next_mask(p, mover, dn, auto_reset);
+            if (mask_out) write_mask(mask_out + b * kActions, legal);
             if (actions_out) actions_out[b] = action;
             if (done_out) done_out[b] = (int8_t)dn;
             if (to_move_out) to_move_out[b] = (int8_t)mover;
+            if (status_out) status_out[b] = (int8_t)(was_done ? 0 : action_status(y.ok, action));  // (a frozen board consumes no action)
+            if (next_actions_out) next_actions_out[b] = sample54(legal, seed, env_base + (uint64_t)b, ply);  // (may alias `actions`)
         }
     });
     return GBL_OK;
 }
 
+int gbl_cpu_step_into(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out, int8_t *reward_out,
+                      int8_t *mask_out, int8_t *obs_out, int32_t *turn, int32_t *actions_out, int8_t *done_out,
+                      int8_t *to_move_out, int64_t n, int illegal_mode, int auto_reset, void *stream)
+{
+    return gbl_cpu_step_ex(state, to_move, done, actions, winner_out, reward_out, mask_out, obs_out, turn, actions_out, done_out,
+                           to_move_out, nullptr, nullptr, 0, 0, 0, nullptr, n, illegal_mode, auto_reset, stream);
+}
+
 int gbl_cpu_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out, int8_t *reward_out,
                  int8_t *mask_out, int8_t *obs_out, int32_t *turn, int64_t n, int illegal_mode, int auto_reset, void *stream)
 {
-    return gbl_cpu_step_into(state, to_move, done, actions, winner_out, reward_out, mask_out, obs_out, turn, nullptr, nullptr, nullptr,
-                             n, illegal_mode, auto_reset, stream);
+    return gbl_cpu_step_ex(state, to_move, done, actions, winner_out, reward_out, mask_out, obs_out, turn, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, 0, 0, 0, nullptr, n, illegal_mode, auto_reset, stream);
 }
 
 int gbl_cpu_sample_at(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply,
@@ -479,9 +492,21 @@ int gbl_cpu_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int
                          int8_t *winner_traj, int8_t *reward_traj, int8_t *done_traj, int8_t *to_move_traj, int8_t *mask_traj,
                          int8_t *obs_traj, int64_t n, int64_t ply_stride, int64_t tile_stride, uint64_t seed, uint64_t env_base,
                          uint32_t ply0, const uint32_t *ply_dev, uint32_t plies, int illegal_mode, int64_t *counters, int32_t *turn,
-                         void *)
+                         void *stream)
+{
+    return gbl_cpu_collect_from_ex(state, to_move, done, first_actions, nullptr, actions_traj, winner_traj, reward_traj, done_traj,
+                                   to_move_traj, mask_traj, obs_traj, n, ply_stride, tile_stride, seed, env_base, ply0, ply_dev, plies,
+                                   illegal_mode, counters, turn, stream);
+}
+
+int gbl_cpu_collect_from_ex(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *first_actions, int8_t *first_status,
+                            int32_t *actions_traj, int8_t *winner_traj, int8_t *reward_traj, int8_t *done_traj, int8_t *to_move_traj,
+                            int8_t *mask_traj, int8_t *obs_traj, int64_t n, int64_t ply_stride, int64_t tile_stride, uint64_t seed,
+                            uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev, uint32_t plies, int illegal_mode,
+                            int64_t *counters, int32_t *turn, void *)
 {
     GBL_CHECK_N(n);
+    if (first_status && !first_actions) return fail(GBL_ERR_ARG, "first_status without first_actions");
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done");
     if (illegal_mode != GBL_ILLEGAL_NOOP && illegal_mode != GBL_ILLEGAL_TERMINATE)
         return fail(GBL_ERR_ARG, "illegal_mode must be GBL_ILLEGAL_NOOP or GBL_ILLEGAL_TERMINATE");
@@ -503,6 +528,7 @@ int gbl_cpu_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int
                 const bool given = first_actions && t == 0;
                 const Ply y = random_ply(p, row, mover, legal, action, given ? first_actions[b] : 0, given, seed, env_base + (uint64_t)b,
                                          ply0 + t, illegal_mode, dn);
+                if (given && first_status) first_status[b] = (int8_t)action_status(y.ok, action);
                 tcount = next_turn(tcount, y, 1);
                 treset = treset || y.terminal;
                 tl.games += y.terminal; tl.w1 += y.winner == 1; tl.w2 += y.winner == -1;

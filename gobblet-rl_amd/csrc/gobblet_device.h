@@ -962,7 +962,22 @@ struct Ply {
     int r0, r1;     // rewards of player_1 / player_2 for this step
     bool terminal;  // the episode ended on this step
     bool stepped;   // raw_env.step ran, i.e. the reference did `self.turn += 1` (gobblet.py:270)
+    bool ok;        // the action was a legal move of the mover and was played (false: illegal or outside [0, 54) -- action_status)
 };
+
+// The status byte of an externally supplied action (gbl_step_ex / gbl_collect_from_ex; include/gobblet_hip.h GBL_STATUS_*):
+// bit 0 = not a legal move of the mover (the reference's silent no-op, board.py:125-126, or TerminateIllegalWrapper's case),
+// bit 1 = outside [0, 54) (where the reference's env() asserts: AssertOutOfBoundsWrapper, gobblet.py:110-117).
+__device__ __forceinline__ int action_status(bool ok, int action)
+{
+    return (ok ? 0 : 1) | ((uint32_t)action < (uint32_t)kActions ? 0 : 2);
+}
+
+// ... of an action against the mover's legal mask (the test play_ply makes)
+__device__ __forceinline__ int action_status_of(uint64_t legal, int action)
+{
+    return action_status((uint32_t)action < (uint32_t)kActions && ((legal >> (action & 63)) & 1ull), action);
+}
 
 // TRUSTED: the action comes from pick54 on `legal` itself (the masked-random sampler inside a T-plies-per-launch kernel): it is
 // legal by construction, or -1 where a board has no legal move at all (none in the game: only outside the state contract) -- the
@@ -972,6 +987,7 @@ __device__ __forceinline__ Ply play_ply(Planes &p, Row row, int &mover, uint64_t
 {
     Ply y{0, 0, 0, false, false};
     bool ok = TRUSTED ? action >= 0 : ((uint32_t)action < (uint32_t)kActions && ((legal >> (action & 63)) & 1ull));
+    y.ok = ok;
     if (!TRUSTED && !ok && illegal_mode == kIllegalTerminate) {
         // gobblet.py:50-51, :114: mover -1, the other 0, everyone terminated, board untouched
         y.r0 = mover ? 0 : -1;
@@ -1001,6 +1017,7 @@ __device__ __forceinline__ void step_lane(Row row, Planes &p, int &mover, int wa
     y = Ply{0, 0, 0, false, false};
     dn = was_done;
     if (was_done) {
+        y.ok = true;              // (no action is consumed)
         y.winner = winner_of(p);  // frozen board (reference: _was_dead_step, gobblet.py:232-236): standing result
     } else {
         y = play_ply(p, row, mover, legal54(p, mover), action, illegal_mode);

@@ -458,10 +458,11 @@ __device__ __forceinline__ void store_mask(uint32_t *img, const Lane &L, uint64_
     wave_lds_fence();
 }
 
+// Returns the 54-bit set behind the mask rows it stored (WITH_MASK; 0 otherwise): gbl_step_ex draws the next action from it.
 template <bool WITH_MASK, bool WITH_OBS, int NT>
-__device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, bool mask_zero, const Planes &p, int observer,
-                                           int8_t *__restrict__ state, int8_t *__restrict__ mask_out,
-                                           int8_t *__restrict__ obs_out)
+__device__ __forceinline__ uint64_t store_rows(uint32_t *img, const Lane &L, bool mask_zero, const Planes &p, int observer,
+                                               int8_t *__restrict__ state, int8_t *__restrict__ mask_out,
+                                               int8_t *__restrict__ obs_out)
 {
     wave_lds_fence();  // every lane's byte patches are in the image
     tile_out<kCells, (NT & 4) ? kStoreStream : kStorePlain>(state + L.tile * (kTile * kCells), img, L.lane, L.rows);
@@ -469,9 +470,12 @@ __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, bool ma
     if (WITH_OBS) store_obs<(NT & 1) ? kStoreStreamDrop : kStorePlain>(img, L, p, observer, obs_out + L.tile * (kTile * kObs));
     // the next mover's legal mask is computed only now, behind the state and observation stores: the
     // sooner a wave's first stores are in flight, the shorter the launch's ramp-up
-    if (WITH_MASK)
-        store_mask<(NT & 2) ? kStoreStreamDrop : kStorePlain>(img, L, mask_zero ? 0ull : legal54(p, observer),
-                                                         mask_out + L.tile * (kTile * kActions));
+    uint64_t legal = 0ull;
+    if (WITH_MASK) {
+        legal = mask_zero ? 0ull : legal54(p, observer);
+        store_mask<(NT & 2) ? kStoreStreamDrop : kStorePlain>(img, L, legal, mask_out + L.tile * (kTile * kActions));
+    }
+    return legal;
 }
 
 // (GBL_STAMP* : per-wavefront phase stamps of the diagnostic build, gobblet_diag.h; they expand to nothing here)
@@ -479,16 +483,26 @@ __device__ __forceinline__ void store_rows(uint32_t *img, const Lane &L, bool ma
 // gbl_step: fused raw_env.step + observe(next mover) over a tile of boards.
 // (argument order: what a wavefront needs first comes first -- the first 16 dwords are preloaded into SGPRs at
 // wave launch, -amdgpu-kernarg-preload-count, so the tile loads do not wait for a kernel-argument fetch)
-// INTO: gbl_step_into -- the ply's scalars also go to a trajectory slot (a template parameter: as run-time tests of
-// three more pointers the plain step paid 0.5 us at 2^20 boards)
-template <bool WITH_MASK, bool WITH_OBS, int NT, bool INTO>
+// EXT: gbl_step_into / gbl_step_ex -- the ply's scalars also go to a trajectory slot, the status byte of every action, and the
+// NEXT mover's masked-uniform draw (the gbl_sample rule on the mask this launch stores: the sampler's own launch and its 58 bytes
+// per board of traffic leave an external policy's pipeline).  A template parameter: as run-time tests of three more pointers the
+// plain step paid 0.5 us at 2^20 boards.
+struct StepExt {
+    int32_t *actions_copy;
+    int8_t *done_copy, *to_move_copy, *status;
+    int32_t *next_actions;       // may alias `actions`: a lane reads its board's action before it writes the next one
+    uint64_t seed, env_base;
+    const uint32_t *ply_dev;
+    uint32_t ply;                // the draw's ply index (+ *ply_dev)
+};
+
+template <bool WITH_MASK, bool WITH_OBS, int NT, bool EXT>
 __global__ __launch_bounds__(64 * kStepWaves) void k_step(int8_t *__restrict__ state, int8_t *__restrict__ to_move,
-                                             int8_t *__restrict__ done, const int32_t *__restrict__ actions,
+                                             int8_t *__restrict__ done, const int32_t *actions,
                                              int64_t n, int64_t ntiles, int illegal_mode, int auto_reset,
                                              int8_t *__restrict__ winner_out, int8_t *__restrict__ reward_out,
                                              int8_t *__restrict__ mask_out, int8_t *__restrict__ obs_out,
-                                             int32_t *__restrict__ turn, int32_t *__restrict__ actions_copy,
-                                             int8_t *__restrict__ done_copy, int8_t *__restrict__ to_move_copy)
+                                             int32_t *__restrict__ turn, StepExt X)
 {
     constexpr int kImg = out_image_words<WITH_MASK, WITH_OBS>();
     __shared__ uint32_t s_imgs[kStepWaves * kImg];
@@ -501,7 +515,13 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_step(int8_t *__restrict__ s
     const int64_t bs = L.valid ? L.b : n - 1;
     int mover = to_move[bs], was_done = done[bs], action = actions[bs];
     uint32_t r[7];
-    load_state(state, s_img, L, r);
+    uint32_t word = 0;  // EXT: the next mover's 32 random bits -- they depend on nothing the tile holds, so they are drawn under its loads
+    load_state(state, s_img, L, r, [&] {
+        if (EXT && X.next_actions) {
+            const uint32_t ply = X.ply + (X.ply_dev ? *X.ply_dev : 0u);
+            word = draw32(X.seed, X.env_base + (uint64_t)L.b, ply);
+        }
+    });
     mover = L.valid && mover != 0;
     was_done = L.valid && !auto_reset && was_done != 0;
     action = L.valid ? action : 0;
@@ -511,7 +531,8 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_step(int8_t *__restrict__ s
     step_lane(ImageRow{reinterpret_cast<uint8_t *>(s_img) + L.lane * kCells}, p, mover, was_done, action, illegal_mode,
               auto_reset, dn, y);
     // gobblet.py:209: the mask belongs to the agent to move; a frozen board has nobody to move
-    store_rows<WITH_MASK, WITH_OBS, NT>(s_img, L, dn && !auto_reset, p, mover, state, mask_out, obs_out);
+    const bool frozen = dn && !auto_reset;
+    const uint64_t stored = store_rows<WITH_MASK, WITH_OBS, NT>(s_img, L, frozen, p, mover, state, mask_out, obs_out);
     if (L.valid) {
         to_move[L.b] = (int8_t)mover;
         done[L.b] = (int8_t)dn;
@@ -519,10 +540,15 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_step(int8_t *__restrict__ s
         if (reward_out)
             reinterpret_cast<uint16_t *>(reward_out)[L.b] = (uint16_t)((y.r0 & 0xFF) | ((y.r1 & 0xFF) << 8));
         if (turn) turn[L.b] = next_turn(turn[L.b], y, auto_reset);
-        if (INTO) {
-            if (actions_copy) actions_copy[L.b] = action;
-            if (done_copy) done_copy[L.b] = (int8_t)dn;
-            if (to_move_copy) to_move_copy[L.b] = (int8_t)mover;
+        if (EXT) {
+            if (X.actions_copy) X.actions_copy[L.b] = action;
+            if (X.done_copy) X.done_copy[L.b] = (int8_t)dn;
+            if (X.to_move_copy) X.to_move_copy[L.b] = (int8_t)mover;
+            if (X.status) X.status[L.b] = (int8_t)(was_done ? 0 : action_status(y.ok, action));  // (a frozen board consumes no action)
+            if (X.next_actions) {  // gbl_sample's rule on the mask just stored (-1 where nobody is to move)
+                const uint64_t legal = WITH_MASK ? stored : (frozen ? 0ull : legal54(p, mover));
+                X.next_actions[L.b] = pick54(legal, word);
+            }
         }
     }
 }
@@ -628,7 +654,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GBL_COLLECT_
                                                 int8_t *__restrict__ to_move_t, int8_t *__restrict__ mask_t,
                                                 int8_t *__restrict__ obs_t, int illegal_mode,
                                                 int64_t *__restrict__ counters, int32_t *__restrict__ turn,
-                                                const int32_t *__restrict__ first_actions)
+                                                const int32_t *__restrict__ first_actions, int8_t *__restrict__ first_status)
 {
     __shared__ uint32_t s_state[image_words<kCells>()];
     __shared__ uint32_t s_out[out_image_words<true, WITH_OBS>()];
@@ -653,6 +679,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GBL_COLLECT_
     int dn = 0, tcount = 0;
     bool treset = false;
     uint64_t legal = legal54(p, mover);
+    if (first_status && L.valid) first_status[L.b] = (int8_t)action_status_of(legal, given);  // (gbl_collect_from_ex; outside the ply loop)
     for (uint32_t t = 0; t < plies; ++t) {
         const uint32_t ply = ply0 + t;
         int action = pick54(legal, draw_word(block, ply));
@@ -727,7 +754,7 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
                                                  int8_t *__restrict__ to_move_t, int8_t *__restrict__ mask_t,
                                                  int8_t *__restrict__ obs_t, int illegal_mode,
                                                  int64_t *__restrict__ counters, int32_t *__restrict__ turn,
-                                                 const int32_t *__restrict__ first_actions)
+                                                 const int32_t *__restrict__ first_actions, int8_t *__restrict__ first_status)
 {
     __shared__ uint32_t s_state[image_words<kCells>()];
     __shared__ uint32_t s_obs[WITH_OBS ? image_words<kObs>() : 4];
@@ -793,6 +820,7 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
     int dn = 0, tcount = 0;
     bool treset = false;
     uint64_t legal = legal54(p, mover);
+    if (first_status && L.valid) first_status[L.b] = (int8_t)action_status_of(legal, given);  // (gbl_collect_from_ex)
     if (WITH_OBS) {  // the first ply's observation image (later ones come back zeroed from the storing wavefront)
         obs_image_zero(s_obs, L.lane);
         wave_lds_fence();
@@ -882,6 +910,7 @@ struct SmallArgs {
     int64_t *counters;
     int32_t *turn;
     const int32_t *first_actions;
+    int8_t *first_status;
 };
 
 template <int ROLE, int LPB, bool SYNC>
@@ -939,6 +968,7 @@ __device__ __forceinline__ void small_role(const SmallArgs &A, uint32_t *img, ui
     int dn = 0, tcount = 0;
     bool treset = false;
     uint64_t legal = legal54(p, mover);
+    if (SC && A.first_status && valid && j == 0) A.first_status[b] = (int8_t)action_status_of(legal, given);  // (gbl_collect_from_ex)
     constexpr int kRowPolicy = kStoreStreamDrop;  // trajectory slots are written once: streamed
     // the images of the previous ply, on their way out
     SubVecs<MK ? sub_vectors<kActions, BPS>() : 0> vm{};
@@ -1124,7 +1154,8 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
     const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies, int8_t *__restrict__ done, int64_t ply_stride,
     int64_t tile_stride, int32_t *__restrict__ actions_t, int8_t *__restrict__ winner_t, int8_t *__restrict__ reward_t,
     int8_t *__restrict__ done_t, int8_t *__restrict__ to_move_t, int8_t *__restrict__ mask_t, int8_t *__restrict__ obs_t,
-    int illegal_mode, int64_t *__restrict__ counters, int32_t *__restrict__ turn, const int32_t *__restrict__ first_actions)
+    int illegal_mode, int64_t *__restrict__ counters, int32_t *__restrict__ turn, const int32_t *__restrict__ first_actions,
+    int8_t *__restrict__ first_status)
 {
     constexpr int WAVES = 1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0);
     __shared__ uint32_t s_state[image_words<kCells>()];
@@ -1234,6 +1265,7 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
     int dn = 0, tcount = 0;
     bool treset = false;
     uint64_t legal = legal54(p, mover);
+    if (first_status && valid) first_status[b] = (int8_t)action_status_of(legal, given);  // (gbl_collect_from_ex)
     int64_t cell = cell0;  // ply t's cell of the tile in the scalar arrays
     for (uint32_t t = 0; t < plies; ++t) {
         const uint32_t ply = ply0 + t;
@@ -1309,7 +1341,8 @@ __global__ __launch_bounds__((64 * small_waves<WITH_MASK, WITH_OBS, KO, MERGE>()
     const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies, int8_t *__restrict__ done, int64_t ply_stride,
     int64_t tile_stride, int32_t *__restrict__ actions_t, int8_t *__restrict__ winner_t, int8_t *__restrict__ reward_t,
     int8_t *__restrict__ done_t, int8_t *__restrict__ to_move_t, int8_t *__restrict__ mask_t, int8_t *__restrict__ obs_t,
-    int illegal_mode, int64_t *__restrict__ counters, int32_t *__restrict__ turn, const int32_t *__restrict__ first_actions)
+    int illegal_mode, int64_t *__restrict__ counters, int32_t *__restrict__ turn, const int32_t *__restrict__ first_actions,
+    int8_t *__restrict__ first_status)
 {
     static_assert(LA * KO <= 4 && (KO > 0 || MERGE), "at most four lanes per board");
     constexpr int WAVES = small_waves<WITH_MASK, WITH_OBS, KO, MERGE>(), NA = WAVES - (WITH_OBS ? KO : 0);
@@ -1324,7 +1357,7 @@ __global__ __launch_bounds__((64 * small_waves<WITH_MASK, WITH_OBS, KO, MERGE>()
     if (group >= ngroups) return;
     const int wave = WAVES > 1 ? wave_index() : 0;
     const SmallArgs A{state, to_move, done, n, seed, env_base, ply0, plies, ply_stride, tile_stride, actions_t, winner_t, reward_t,
-                      done_t, to_move_t, mask_t, obs_t, illegal_mode, counters, turn, first_actions};
+                      done_t, to_move_t, mask_t, obs_t, illegal_mode, counters, turn, first_actions, first_status};
     constexpr bool SYNC = WAVES > 1;
     if (wave == 0) {
         small_role<kRoleScalars | ((WITH_MASK && MERGE) ? kRoleMask : 0) | ((WITH_OBS && KO == 0) ? kRoleObs : 0), LA, SYNC>(
@@ -2066,7 +2099,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
 
 // k_collect_small for a checked call (see gbl_collect_from); cfg = 100 LA + 10 KO + MERGE (collect_variant)
 // (the product build instantiates the forms collect_variant() can return; an A/B build -- GBL_AB_COLLECT_CFG -- a whole menu)
-bool launch_small(int cfg, int8_t *state, int8_t *to_move, int8_t *done, const int32_t *first_actions, int32_t *actions_t, int8_t *winner_t,
+bool launch_small(int cfg, int8_t *state, int8_t *to_move, int8_t *done, const int32_t *first_actions, int8_t *first_status, int32_t *actions_t, int8_t *winner_t,
                   int8_t *reward_t, int8_t *done_t, int8_t *to_move_t, int8_t *mask_t, int8_t *obs_t, int64_t n, int64_t ply_stride,
                   int64_t tile_stride, uint64_t seed, uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev, uint32_t plies,
                   int illegal_mode, int64_t *counters, int32_t *turn, hipStream_t s)
@@ -2076,7 +2109,7 @@ bool launch_small(int cfg, int8_t *state, int8_t *to_move, int8_t *done, const i
 #define GBL_SMALL_K(M, O, D, LA, KO, MG)                                                                                        \
     hipLaunchKernelGGL((k_collect_small<M, O, D, LA, KO, MG>), dim3((uint32_t)ngroups), dim3(64 * small_waves<M, O, KO, MG>()), 0, s, \
                        state, to_move, n, ngroups, seed, env_base, ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_t,      \
-                       winner_t, reward_t, done_t, to_move_t, mask_t, obs_t, illegal_mode, counters, turn, first_actions)
+                       winner_t, reward_t, done_t, to_move_t, mask_t, obs_t, illegal_mode, counters, turn, first_actions, first_status)
 #define GBL_SMALL_D(M, O, LA, KO, MG)                           \
     if (ply_dev) { GBL_SMALL_K(M, O, true, LA, KO, MG); }       \
     else { GBL_SMALL_K(M, O, false, LA, KO, MG); }
@@ -2314,13 +2347,23 @@ int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *action
              int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int64_t n, int illegal_mode,
              int auto_reset, void *stream)
 {
-    return gbl_step_into(state, to_move, done, actions, winner_out, reward_out, mask_out, obs_out, turn, nullptr, nullptr,
-                         nullptr, n, illegal_mode, auto_reset, stream);
+    return gbl_step_ex(state, to_move, done, actions, winner_out, reward_out, mask_out, obs_out, turn, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, 0, 0, 0, nullptr, n, illegal_mode, auto_reset, stream);
 }
 
 int gbl_step_into(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out,
                   int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int32_t *actions_out,
                   int8_t *done_out, int8_t *to_move_out, int64_t n, int illegal_mode, int auto_reset, void *stream)
+{
+    return gbl_step_ex(state, to_move, done, actions, winner_out, reward_out, mask_out, obs_out, turn, actions_out, done_out,
+                       to_move_out, nullptr, nullptr, 0, 0, 0, nullptr, n, illegal_mode, auto_reset, stream);
+}
+
+int gbl_step_ex(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out,
+                int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int32_t *actions_out,
+                int8_t *done_out, int8_t *to_move_out, int8_t *status_out, int32_t *next_actions_out, uint64_t seed,
+                uint64_t env_base, uint32_t ply, const uint32_t *ply_dev, int64_t n, int illegal_mode, int auto_reset,
+                void *stream)
 {
     GBL_CHECK_N(n);
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done"); GBL_NEED(actions, "actions");
@@ -2333,17 +2376,19 @@ int gbl_step_into(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *a
     if (reinterpret_cast<uintptr_t>(actions) & 3u) return fail(GBL_ERR_ALIGN, "actions must be 4-byte aligned");
     if (actions_out && (reinterpret_cast<uintptr_t>(actions_out) & 3u))
         return fail(GBL_ERR_ALIGN, "actions_out must be 4-byte aligned");
+    if (next_actions_out && (reinterpret_cast<uintptr_t>(next_actions_out) & 3u))
+        return fail(GBL_ERR_ALIGN, "next_actions_out must be 4-byte aligned");
     Geometry g = geometry(n, kStepWaves);
     hipStream_t s = (hipStream_t)stream;
     auto_reset = auto_reset != 0;
     const int nt = nt_policy(n);
-    const bool into = actions_out || done_out || to_move_out;
+    const bool ext = actions_out || done_out || to_move_out || status_out || next_actions_out;
+    const StepExt X{actions_out, done_out, to_move_out, status_out, next_actions_out, seed, env_base, ply_dev, ply};
 #define GBL_STEP_I(M, O, NT, I)                                                                                          \
     hipLaunchKernelGGL((k_step<M, O, NT, I>), dim3(g.grid), dim3(64 * kStepWaves), 0, s, state, to_move, done, actions, \
-                       n, g.ntiles, illegal_mode, auto_reset, winner_out, reward_out, mask_out, obs_out, turn,         \
-                       actions_out, done_out, to_move_out)
+                       n, g.ntiles, illegal_mode, auto_reset, winner_out, reward_out, mask_out, obs_out, turn, X)
 #define GBL_STEP_NT(M, O, NT)                                   \
-    if (into) GBL_STEP_I(M, O, NT, true);                       \
+    if (ext) GBL_STEP_I(M, O, NT, true);                        \
     else GBL_STEP_I(M, O, NT, false)
 #define GBL_STEP(M, O)                                          \
     if (nt == 3) { GBL_STEP_NT(M, O, 3); }                      \
@@ -2452,9 +2497,21 @@ int gbl_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int32_t
                      uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev, uint32_t plies, int illegal_mode,
                      int64_t *counters, int32_t *turn, void *stream)
 {
+    return gbl_collect_from_ex(state, to_move, done, first_actions, nullptr, actions_traj, winner_traj, reward_traj, done_traj,
+                               to_move_traj, mask_traj, obs_traj, n, ply_stride, tile_stride, seed, env_base, ply0, ply_dev, plies,
+                               illegal_mode, counters, turn, stream);
+}
+
+int gbl_collect_from_ex(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *first_actions, int8_t *first_status,
+                        int32_t *actions_traj, int8_t *winner_traj, int8_t *reward_traj, int8_t *done_traj, int8_t *to_move_traj,
+                        int8_t *mask_traj, int8_t *obs_traj, int64_t n, int64_t ply_stride, int64_t tile_stride, uint64_t seed,
+                        uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev, uint32_t plies, int illegal_mode,
+                        int64_t *counters, int32_t *turn, void *stream)
+{
     GBL_CHECK_N(n);
     if (first_actions && (reinterpret_cast<uintptr_t>(first_actions) & 3u))
         return fail(GBL_ERR_ALIGN, "first_actions must be 4-byte aligned");
+    if (first_status && !first_actions) return fail(GBL_ERR_ARG, "first_status without first_actions");
     GBL_NEED(state, "state"); GBL_NEED(to_move, "to_move"); GBL_NEED(done, "done");
     if (illegal_mode != GBL_ILLEGAL_NOOP && illegal_mode != GBL_ILLEGAL_TERMINATE)
         return fail(GBL_ERR_ARG, "illegal_mode must be GBL_ILLEGAL_NOOP or GBL_ILLEGAL_TERMINATE");
@@ -2485,7 +2542,7 @@ int gbl_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int32_t
     hipLaunchKernelGGL((k_collect3<M, O, D, H>), dim3((uint32_t)g.ntiles), dim3(64 * (1 + (M ? 1 : 0) + (O ? 1 : 0))), 0, s, state,   \
                        to_move, n, g.ntiles, seed, env_base, ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj,   \
                        winner_traj, reward_traj, done_traj, to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn,      \
-                       first_actions)
+                       first_actions, first_status)
 #define GBL_TRIO_K(M, O, D)                                     \
     if (g.ntiles <= kTrioHandMaxTiles) { GBL_TRIO_KH(M, O, D, true); } \
     else { GBL_TRIO_KH(M, O, D, false); }
@@ -2501,7 +2558,7 @@ int gbl_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int32_t
         GBL_LAUNCHED("gbl_collect");
     }
     if (GBL_COLLECT_IS_ROLES(variant)) {
-        if (!launch_small(variant - GBL_COLLECT_ROLES(0, 0, 0), state, to_move, done, first_actions, actions_traj, winner_traj, reward_traj,
+        if (!launch_small(variant - GBL_COLLECT_ROLES(0, 0, 0), state, to_move, done, first_actions, first_status, actions_traj, winner_traj, reward_traj,
                           done_traj, to_move_traj, mask_traj, obs_traj, n, ply_stride, tile_stride, seed, env_base, ply0, ply_dev, plies,
                           illegal_mode, counters, turn, s))
             return fail(GBL_ERR_ARG, "gbl_collect: this build has no such form of the role kernel");
@@ -2521,12 +2578,12 @@ int gbl_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int32_t
     hipLaunchKernelGGL((k_collect2<M, O, D>), dim3((uint32_t)g.ntiles), dim3(128), 0, s, state, to_move, n, g.ntiles, seed, \
                        env_base, ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj,        \
                        reward_traj, done_traj, to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn,         \
-                       first_actions)
+                       first_actions, first_status)
 #define GBL_COLLECT_KN(M, O, D, N)                                                                                      \
     hipLaunchKernelGGL((k_collect<M, O, D, N>), dim3(g.grid), dim3(64), 0, s, state, to_move, n, g.ntiles, seed, env_base, \
                        ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj, reward_traj,     \
                        done_traj,                                                                                      \
-                       to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn, first_actions)
+                       to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn, first_actions, first_status)
 #define GBL_COLLECT(M, O)                                       \
     if (ply_dev) { GBL_COLLECT_K(M, O, true); }                 \
     else { GBL_COLLECT_K(M, O, false); }

@@ -209,15 +209,45 @@ class BatchedGobblet:
         return {"observation": self.observation.reshape(self.num_envs, -1), "action_mask": self.action_mask}
 
     # -- gobblet.py:231-271 + 179-215 ------------------------------------------------------------------
-    def step(self, actions):
+    def _i8_out(self, t, name):
+        if t is None:
+            return None
+        if t.dtype != torch.int8 or t.device != self.device or t.numel() != self.num_envs or not t.is_contiguous():
+            raise ValueError("%s: a contiguous int8 (N,) tensor on the environment's device" % name)
+        return t
+
+    def _i32_out(self, t, name):
+        if t is None:
+            return None
+        if t.dtype != torch.int32 or t.device != self.device or t.numel() != self.num_envs or not t.is_contiguous():
+            raise ValueError("%s: a contiguous int32 (N,) tensor on the environment's device" % name)
+        return t
+
+    def step(self, actions, status=None, next_actions=None):
         """Apply ``actions`` (int (N,)) for the agents to move.  Returns
-        (obs dict, rewards (N,2), done (N,), winner (N,)) -- views of the attribute tensors."""
+        (obs dict, rewards (N,2), done (N,), winner (N,)) -- views of the attribute tensors.
+
+        ``status`` (int8 (N,), optional): receives what became of every action -- 0 played, 1 (``nat.STATUS_ILLEGAL``) not a
+        legal move of the mover (handled per ``illegal_mode``), 3 (| ``nat.STATUS_OUT_OF_RANGE``) outside [0, 54), where the
+        reference's ``env()`` asserts (gobblet.py:110-117); a frozen board consumes no action: 0.
+        ``next_actions`` (int32 (N,), optional; may be the ``actions`` tensor itself): receives the NEXT mover's masked-uniform
+        draw from the mask this step stores -- what ``sample_actions()`` would return after the step, without its launch
+        (``gbl_step_ex``): the random opponent's reply or an epsilon-greedy policy's exploration move."""
         n = self.num_envs
         a = _as_i32(actions, n, self.device, "actions")
-        nat.check(self._lib.gbl_step(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
-                                     a.data_ptr(), self.winner.data_ptr(), self.rewards.data_ptr(),
-                                     self.action_mask.data_ptr(), nat.ptr(self.observation), nat.ptr(self.turn), n,
-                                     self.illegal_mode, int(self.auto_reset), self._stream()), "gbl_step")
+        status, next_actions = self._i8_out(status, "status"), self._i32_out(next_actions, "next_actions")
+        if status is None and next_actions is None:
+            nat.check(self._lib.gbl_step(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
+                                         a.data_ptr(), self.winner.data_ptr(), self.rewards.data_ptr(),
+                                         self.action_mask.data_ptr(), nat.ptr(self.observation), nat.ptr(self.turn), n,
+                                         self.illegal_mode, int(self.auto_reset), self._stream()), "gbl_step")
+        else:
+            nat.check(self._lib.gbl_step_ex(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
+                                            a.data_ptr(), self.winner.data_ptr(), self.rewards.data_ptr(),
+                                            self.action_mask.data_ptr(), nat.ptr(self.observation), nat.ptr(self.turn),
+                                            None, None, None, nat.ptr(status), nat.ptr(next_actions), self.seed, self.env_base,
+                                            self._ply + 1, nat.ptr(self._ply_dev), n, self.illegal_mode,
+                                            int(self.auto_reset), self._stream()), "gbl_step_ex")
         self._ply += 1
         return self.observe(), self.rewards, self.done, self.winner
 
@@ -326,7 +356,7 @@ class BatchedGobblet:
         return v.reshape((v.shape[0] * 64,) + tuple(v.shape[2:]))[:n]
 
     def collect(self, plies: int, out: dict | None = None, count: bool = False, refresh: bool = True,
-                layout: str = "time", policies=None, opening_plies: int = 0, first_actions=None) -> dict:
+                layout: str = "time", policies=None, opening_plies: int = 0, first_actions=None, first_status=None) -> dict:
         """``plies`` masked-random plies with auto-reset in ONE launch (``gbl_collect``), EVERY ply materialised:
         entry t of the returned tensors -- "actions", "winner", "rewards", "done", "to_move", "action_mask",
         "observation", each (plies, N, ...) in the default time-major layout -- is what ``rollout(1)`` called ``plies``
@@ -348,7 +378,7 @@ class BatchedGobblet:
         ``first_actions`` (int (N,)): the first ply plays these actions -- an external policy's decision -- and the
         remaining plies are sampled (``gbl_collect_from``): ``collect(2, out, first_actions=a)`` is one decision of the
         policy plus the masked-random opponent's reply in one launch; the policy reads ``out["observation"][1]`` /
-        ``out["action_mask"][1]`` next.
+        ``out["action_mask"][1]`` next.  ``first_status`` (int8 (N,), optional): the status byte of those actions, as ``step``'s.
 
         ``policies=(p1, p2)``: how player_1 / player_2 choose their moves INSIDE the launch (``gbl_collect_policy``) --
         "random" (the masked-uniform sampler, the default for both) or "greedy1" / "greedy" (= "greedy2") / "greedy3": the
@@ -386,6 +416,9 @@ class BatchedGobblet:
         if first_actions is not None and policies is not None:
             raise ValueError("first_actions and policies exclude each other")
         fa = None if first_actions is None else _as_i32(first_actions, n, self.device, "first_actions")
+        first_status = self._i8_out(first_status, "first_status")
+        if first_status is not None and fa is None:
+            raise ValueError("first_status needs first_actions")
         if policies is not None:
             try:
                 p0, p1 = (self.POLICIES[x] if isinstance(x, str) else int(x) for x in policies)
@@ -404,15 +437,15 @@ class BatchedGobblet:
                 nat.ptr(self._ply_dev), T, p0, p1, int(opening_plies), self.illegal_mode,
                 self._counters.data_ptr() if count else None, nat.ptr(self.turn), self._stream()), "gbl_collect_policy")
         else:
-            nat.check(self._lib.gbl_collect_from(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
-                                                 nat.ptr(fa), f["actions"].data_ptr(), f["winner"].data_ptr(),
-                                                 f["rewards"].data_ptr(), f["done"].data_ptr(), f["to_move"].data_ptr(),
-                                                 f["action_mask"].data_ptr(),
-                                                 f["observation"].data_ptr() if "observation" in f else None, n,
-                                                 out["_ply_stride"], out["_tile_stride"], self.seed, self.env_base,
-                                                 self._ply, nat.ptr(self._ply_dev), T, self.illegal_mode,
-                                                 self._counters.data_ptr() if count else None, nat.ptr(self.turn),
-                                                 self._stream()), "gbl_collect")
+            nat.check(self._lib.gbl_collect_from_ex(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
+                                                    nat.ptr(fa), nat.ptr(first_status), f["actions"].data_ptr(),
+                                                    f["winner"].data_ptr(), f["rewards"].data_ptr(), f["done"].data_ptr(),
+                                                    f["to_move"].data_ptr(), f["action_mask"].data_ptr(),
+                                                    f["observation"].data_ptr() if "observation" in f else None, n,
+                                                    out["_ply_stride"], out["_tile_stride"], self.seed, self.env_base,
+                                                    self._ply, nat.ptr(self._ply_dev), T, self.illegal_mode,
+                                                    self._counters.data_ptr() if count else None, nat.ptr(self.turn),
+                                                    self._stream()), "gbl_collect")
         self._ply += T
         if not refresh:
             return out
@@ -466,7 +499,7 @@ class BatchedGobblet:
         out["_placement"] = rec
         return rec
 
-    def step_into(self, actions, out: dict, t: int):
+    def step_into(self, actions, out: dict, t: int, status=None, next_actions=None):
         """``step(actions)`` with this ply's outputs written straight into slot ``t`` of time-major trajectory buffers
         (``trajectory_buffers``) -- the collector loop of a policy that lives outside the library (the reference's
         Tianshou / RLlib training loops: policy(obs, mask) -> env.step -> buffer.add), without a copy per ply:
@@ -474,7 +507,8 @@ class BatchedGobblet:
         and so do ``["actions"][t]``, ``["done"][t]``, ``["to_move"][t]`` (``gbl_step_into``: one launch).  Returns the views
         (observation[t], action_mask[t]) the policy reads for the next ply.  The environment's own ``action_mask`` /
         ``observation`` / ``winner`` / ``rewards`` attributes are NOT updated (call ``refresh()`` before stepping by
-        hand again); ``squares`` / ``to_move`` / ``done`` / ``turn`` are, as always."""
+        hand again); ``squares`` / ``to_move`` / ``done`` / ``turn`` are, as always.  ``status`` / ``next_actions``: as ``step``'s
+        (``gbl_step_ex``)."""
         if out["_layout"] != "time":
             raise ValueError("step_into() writes time-major trajectory buffers")
         t = int(t)
@@ -485,11 +519,14 @@ class BatchedGobblet:
             raise ValueError("trajectory buffers do not fit this environment (made by another one?)")
         a = _as_i32(actions, n, self.device, "actions")
         obs_t = f["observation"][t] if "observation" in f else None
-        nat.check(self._lib.gbl_step_into(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
-                                          a.data_ptr(), f["winner"][t].data_ptr(), f["rewards"][t].data_ptr(),
-                                          f["action_mask"][t].data_ptr(), nat.ptr(obs_t), nat.ptr(self.turn),
-                                          f["actions"][t].data_ptr(), f["done"][t].data_ptr(), f["to_move"][t].data_ptr(),
-                                          n, self.illegal_mode, int(self.auto_reset), self._stream()), "gbl_step_into")
+        status, next_actions = self._i8_out(status, "status"), self._i32_out(next_actions, "next_actions")
+        nat.check(self._lib.gbl_step_ex(self.squares.data_ptr(), self.to_move.data_ptr(), self.done.data_ptr(),
+                                        a.data_ptr(), f["winner"][t].data_ptr(), f["rewards"][t].data_ptr(),
+                                        f["action_mask"][t].data_ptr(), nat.ptr(obs_t), nat.ptr(self.turn),
+                                        f["actions"][t].data_ptr(), f["done"][t].data_ptr(), f["to_move"][t].data_ptr(),
+                                        nat.ptr(status), nat.ptr(next_actions), self.seed, self.env_base, self._ply + 1,
+                                        nat.ptr(self._ply_dev), n, self.illegal_mode, int(self.auto_reset), self._stream()),
+                  "gbl_step_into")
         self._ply += 1
         return (out["observation"][t] if obs_t is not None else None), out["action_mask"][t]
 

@@ -41,6 +41,11 @@ int gbl_cpu_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *ac
 int gbl_cpu_step_into(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out,
                       int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int32_t *actions_out,
                       int8_t *done_out, int8_t *to_move_out, int64_t n, int illegal_mode, int auto_reset, void *stream);
+int gbl_cpu_step_ex(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out,
+                    int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int32_t *actions_out,
+                    int8_t *done_out, int8_t *to_move_out, int8_t *status_out, int32_t *next_actions_out, uint64_t seed,
+                    uint64_t env_base, uint32_t ply, const uint32_t *ply_dev, int64_t n, int illegal_mode, int auto_reset,
+                    void *stream);
 int gbl_cpu_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply,
                    void *stream);
 int gbl_cpu_sample_at(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply,
@@ -63,6 +68,11 @@ int gbl_cpu_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int
                          int8_t *obs_traj, int64_t n, int64_t ply_stride, int64_t tile_stride, uint64_t seed,
                          uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev, uint32_t plies, int illegal_mode,
                          int64_t *counters, int32_t *turn, void *stream);
+int gbl_cpu_collect_from_ex(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *first_actions, int8_t *first_status,
+                            int32_t *actions_traj, int8_t *winner_traj, int8_t *reward_traj, int8_t *done_traj,
+                            int8_t *to_move_traj, int8_t *mask_traj, int8_t *obs_traj, int64_t n, int64_t ply_stride,
+                            int64_t tile_stride, uint64_t seed, uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev,
+                            uint32_t plies, int illegal_mode, int64_t *counters, int32_t *turn, void *stream);
 int gbl_cpu_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *hist, int32_t *actions_traj,
                            int8_t *winner_traj, int8_t *reward_traj, int8_t *done_traj, int8_t *to_move_traj, int8_t *mask_traj,
                            int8_t *obs_traj, int32_t *chosen_traj, int8_t *how_traj, int8_t *cand_traj, int64_t n,

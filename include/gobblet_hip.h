@@ -23,7 +23,8 @@
  *   - Return value: 0 = OK, negative = GBL_ERR_*; gbl_last_error() gives the
  *     thread-local message.  No C++ exception crosses the ABI.
  *   - Kernels never trap on bad data: an action outside [0,54) is an illegal
- *     action (handled per `illegal_mode`).
+ *     action (handled per `illegal_mode`) and is flagged in the status byte of
+ *     gbl_step_ex / gbl_collect_from_ex (GBL_STATUS_OUT_OF_RANGE).
  *
  * Data layout in HBM (env-major, int8)
  *   state   int8 [n][27]      Board.squares per board: squares[9*level + pos]
@@ -133,6 +134,27 @@ int gbl_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *action
 int gbl_step_into(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out,
                   int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int32_t *actions_out,
                   int8_t *done_out, int8_t *to_move_out, int64_t n, int illegal_mode, int auto_reset, void *stream);
+
+/* gbl_step_into with two more optional outputs (each may be NULL; all NULL = gbl_step_into):
+ *   status_out int8[n]: what became of actions[b] -- 0 = a legal move, played; GBL_STATUS_ILLEGAL = not a legal move of
+ *     the mover (handled per illegal_mode: raw_env.step's silent no-op, gobblet.py:244-246 / board.py:125-126, or
+ *     TerminateIllegalWrapper's -1, gobblet.py:114); GBL_STATUS_ILLEGAL | GBL_STATUS_OUT_OF_RANGE = outside [0, 54),
+ *     where the reference's env() asserts (AssertOutOfBoundsWrapper, gobblet.py:110-117) -- the kernels never trap, a
+ *     batched caller tells "illegal" from "garbage index" here.  A board that was frozen on entry consumes no action: 0.
+ *   next_actions_out int32[n]: the NEXT mover's masked-uniform draw from the mask this very launch stores -- exactly
+ *     gbl_sample_at(mask_out, next_actions_out, n, seed, env_base, ply, ply_dev) run behind the step (-1 where nobody
+ *     is to move), without the sampler's launch and its 58 bytes per board of traffic: the random opponent's reply /
+ *     an epsilon-greedy policy's exploration move of the reference's trainer loops (examples/example_basic.py:58-61,
+ *     example_tianshou_DQN.py: MultiAgentPolicyManager([agent, RandomPolicy])).  May alias `actions`: a board's action
+ *     is read before its next one is written, so one array can carry a masked-random game from launch to launch.
+ *     mask_out may be NULL (the draw is taken from the same 54-bit set either way). */
+#define GBL_STATUS_ILLEGAL 1
+#define GBL_STATUS_OUT_OF_RANGE 2
+int gbl_step_ex(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *actions, int8_t *winner_out,
+                int8_t *reward_out, int8_t *mask_out, int8_t *obs_out, int32_t *turn, int32_t *actions_out,
+                int8_t *done_out, int8_t *to_move_out, int8_t *status_out, int32_t *next_actions_out, uint64_t seed,
+                uint64_t env_base, uint32_t ply, const uint32_t *ply_dev, int64_t n, int illegal_mode, int auto_reset,
+                void *stream);
 
 /* Host memory that the kernels read and write directly (pinned and mapped into the device's address space), for
  * callers that want a result on the host without a separate copy -- the single-environment facade keeps its
@@ -332,6 +354,13 @@ int gbl_collect_from(int8_t *state, int8_t *to_move, int8_t *done, const int32_t
                      int8_t *obs_traj, int64_t n, int64_t ply_stride, int64_t tile_stride, uint64_t seed,
                      uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev, uint32_t plies, int illegal_mode,
                      int64_t *counters, int32_t *turn, void *stream);
+/* gbl_collect_from with the status byte of the caller's actions (first_status int8[n], GBL_STATUS_* as in gbl_step_ex;
+ * NULL = gbl_collect_from; needs first_actions). */
+int gbl_collect_from_ex(int8_t *state, int8_t *to_move, int8_t *done, const int32_t *first_actions, int8_t *first_status,
+                        int32_t *actions_traj, int8_t *winner_traj, int8_t *reward_traj, int8_t *done_traj,
+                        int8_t *to_move_traj, int8_t *mask_traj, int8_t *obs_traj, int64_t n, int64_t ply_stride,
+                        int64_t tile_stride, uint64_t seed, uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev,
+                        uint32_t plies, int illegal_mode, int64_t *counters, int32_t *turn, void *stream);
 /* *counter += by, enqueued on the stream (device uint32). */
 int gbl_counter_add(uint32_t *counter, uint32_t by, void *stream);
 

@@ -96,6 +96,8 @@ def lib() -> C.CDLL:
         L.gbo_batch_sample_step_mt.restype = None
         L.gbo_batch_sample_step_mt.argtypes = [_i8p, _i8p, _i8p, _i32p, _i8p, _i8p, _i8p, _i8p, C.c_int64, C.c_uint64,
                                                C.c_uint64, C.c_uint32, C.c_int, C.c_int]
+        L.gbo_batch_action_status.restype = None
+        L.gbo_batch_action_status.argtypes = [_i8p, _i8p, _i8p, _i32p, _i8p, C.c_int64, C.c_int]
         L.gbo_batch_sample.restype = None
         L.gbo_batch_sample.argtypes = [_i8p, _i32p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32]
         L.gbo_batch_rollout.restype = None
@@ -257,6 +259,15 @@ def batch_step(state, to_move, done, actions, illegal_mode=ILLEGAL_NOOP, auto_re
                             _p(mask), _p(obs), n, int(illegal_mode), int(bool(auto_reset)), int(threads),
                             _p(turn, C.c_int32))
     return {"winner": winner, "reward": reward, "mask": mask, "obs": obs}
+
+
+def batch_action_status(state, to_move, done, actions, auto_reset=False):
+    """Status byte of `actions` against the position BEFORE the step: bit 0 = not a legal move of the mover, bit 1 = outside
+    [0, 54); 0 for a frozen board.  Call it before batch_step."""
+    n = state.shape[0]; out = np.zeros(n, np.int8)
+    actions = np.ascontiguousarray(actions, np.int32)
+    lib().gbo_batch_action_status(_p(state), _p(to_move), _p(done), _p(actions, C.c_int32), _p(out), n, int(bool(auto_reset)))
+    return out
 
 
 def batch_sample(mask, seed, env_base, ply):

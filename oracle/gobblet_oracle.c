@@ -370,6 +370,23 @@ void gbo_batch_step(int8_t *state, int8_t *to_move, int8_t *done, const int32_t 
     batch_step_range(state, to_move, done, actions, winner, reward, mask, obs, 0, n, illegal_mode, auto_reset, NULL);
 }
 
+/* Status byte of externally supplied actions, taken of the position BEFORE the step (include/gobblet_hip.h GBL_STATUS_*):
+ * bit 0 = not a legal move of the mover -- what Board.play_turn silently ignores (board.py:125-126) and what
+ * TerminateIllegalWrapper punishes (gobblet.py:114); bit 1 = outside [0, 54), where the reference's env() asserts
+ * (AssertOutOfBoundsWrapper, gobblet.py:110-117).  A frozen board (done, no auto-reset) consumes no action
+ * (_was_dead_step, gobblet.py:232-236): 0. */
+void gbo_batch_action_status(const int8_t *state, const int8_t *to_move, const int8_t *done, const int32_t *actions,
+                             int8_t *status, int64_t n, int auto_reset)
+{
+    for (int64_t b = 0; b < n; ++b) {
+        if (!auto_reset && done[b]) { status[b] = 0; continue; }
+        int a = actions[b];
+        int in_range = (a >= 0 && a < GBO_ACTIONS);
+        int legal = in_range ? (gbo_is_legal(state + b * GBO_CELLS, a, to_move[b]) == 1) : 0;
+        status[b] = (int8_t)((legal ? 0 : 1) | (in_range ? 0 : 2));
+    }
+}
+
 /* masked-uniform sampler over a batch (separate-kernel form) */
 void gbo_batch_sample(const int8_t *mask, int32_t *actions, int64_t n, uint64_t seed, uint64_t env_base, uint32_t ply)
 {

@@ -17,7 +17,9 @@ instantiation each one reaches.  Bit-exact (integer / byte work).
       131072,4096}
     single_ply_large_4194304      gbl_rollout_at(plies = 1)                 k_rollout<mask, obs, NT = 3, DEV_PLY, ONE_PLY>
     single_ply_maskonly_1048576   gbl_rollout_at(plies = 1), obs_out = NULL k_rollout<mask, -, NT = 1, DEV_PLY, ONE_PLY>
-    --mode step                   gbl_sample_at + gbl_step                  k_sample, k_step<mask, obs, NT, false>
+    step_two_launch_1048576       gbl_sample_at + gbl_step (--mode step2)   k_sample, k_step<mask, obs, NT, false>
+    step_pipeline_{1048576,       gbl_step_ex, next_actions = actions       k_step<mask, obs, NT, EXT>: the next mover's draw fused
+      131072}                       (--mode step)                             into the step's launch
     c5_greedy_65536               gbl_greedy                                k_greedy<4>  (test_gpu_parity.py::test_greedy_config5_full_size)
     greedy_collect_65536          gbl_collect_policy                        k_collect_policy<W> (test_gpu_policy_collect.py)
 The oracle functions follow gobblet.py:179-271 (observe / step / reset) and board.py:82-220; see oracle/gobblet_oracle.c.
@@ -214,10 +216,12 @@ def test_bench_single_ply_record_vs_oracle(G, record):
     assert env.ply == warm + 3
 
 
-def test_bench_step_mode_vs_oracle(G):
-    """bench.py --mode step at 2^20 boards: gbl_sample_at (ply index on the device) + gbl_step with auto-reset, two
-    plies, every output against the oracle (k_sample, k_step<mask, obs, NT = 1, false>); then MASK_ONLY."""
-    n, seed, base, warm = 1 << 20, 4, 99, 11
+@pytest.mark.parametrize("n", [1 << 20, 131072])
+def test_bench_step_mode_vs_oracle(G, n):
+    """bench.py --mode step2 at 2^20 boards (records step_two_launch_*): gbl_sample_at (ply index on the device) + gbl_step with
+    auto-reset, two plies, every output against the oracle (k_sample, k_step<mask, obs, NT = 1, false>); then --mode step (records
+    step_pipeline_*): gbl_step_ex with the next mover's draw written over the action array, three plies; then MASK_ONLY."""
+    seed, base, warm = 4, 99, 11
     for with_obs in (True, False):
         env, s, tm, dn = warm_pair(G, n, seed, base, warm, with_observation=with_obs)
         env.device_ply()
@@ -232,6 +236,20 @@ def test_bench_step_mode_vs_oracle(G):
             assert np.array_equal(npy(rew), o["reward"]) and np.array_equal(npy(obs["action_mask"]), o["mask"])
             if with_obs:
                 assert np.array_equal(npy(obs["observation"]), o["obs"])
+        # ... and the ONE-launch-per-ply form bench.py times now: gbl_step_ex draws the next mover's action from the mask it stores
+        # (next_actions aliasing actions: one array carries the masked-random game from launch to launch; k_step<mask, obs, NT, EXT>)
+        acts = env.sample_actions().clone()
+        for k in range(2, 5):
+            exp_a = oracle.batch_sample(oracle.batch_legal_mask(s, tm), seed, base, warm + k)
+            assert np.array_equal(npy(acts), exp_a), k
+            obs, rew, done, win = env.step(acts, next_actions=acts)
+            env.advance_ply()
+            o = oracle.batch_step(s, tm, dn, exp_a, auto_reset=True, threads=THREADS, want_obs=with_obs)
+            assert np.array_equal(npy(env.squares), s) and np.array_equal(npy(done), dn) and np.array_equal(npy(win), o["winner"])
+            assert np.array_equal(npy(rew), o["reward"]) and np.array_equal(npy(obs["action_mask"]), o["mask"])
+            if with_obs:
+                assert np.array_equal(npy(obs["observation"]), o["obs"])
+        assert np.array_equal(npy(acts), oracle.batch_sample(oracle.batch_legal_mask(s, tm), seed, base, warm + 5))
 
 
 @pytest.mark.parametrize("n,T,illegal,with_obs", [(131072, 2, "noop", True), (262144, 2, "terminate", True),
@@ -255,8 +273,12 @@ def test_collect_from_external_first_ply_vs_oracle(G, n, T, illegal, with_obs):
         acts = oracle.batch_sample(npy(mask), seed + 1, base, ply0)          # "the external policy"
         wild = rng.random(n) < 0.15
         acts = np.where(wild, rng.integers(-3, 60, n), acts).astype(np.int32)
-        env.collect(T, out=tr, first_actions=torch.from_numpy(acts).to(DEV), refresh=False)
+        exp_status = oracle.batch_action_status(s, tm, dn, acts, auto_reset=True)   # (before the oracle steps)
+        status = torch.full((n,), 77, dtype=torch.int8, device=DEV) if launch else None
+        env.collect(T, out=tr, first_actions=torch.from_numpy(acts).to(DEV), first_status=status, refresh=False)
         torch.cuda.synchronize()
+        if status is not None:   # gbl_collect_from_ex: bit 0 = illegal, bit 1 = outside [0, 54)
+            assert np.array_equal(npy(status), exp_status) and (exp_status == 3).any() == (n > 60), ("status", launch)
         for t_ in range(T):
             if t_ == 0:
                 o = oracle.batch_step(s, tm, dn, acts, illegal_mode=im, auto_reset=True, threads=THREADS, want_obs=with_obs)
@@ -371,7 +393,7 @@ def test_bench_config_keys_are_all_covered(G):
     import bench
     keys = set(bench.CONFIG_RECORDS) | set(bench.EXTRA_RECORDS)
     covered = set(COLLECT_RECORDS) | set(SINGLE_PLY_RECORDS) | {
-        "step_pipeline_1048576",   # test_bench_step_mode_vs_oracle
+        "step_pipeline_1048576", "step_pipeline_131072", "step_two_launch_1048576",   # test_bench_step_mode_vs_oracle
         "c5_greedy_65536",         # test_gpu_parity.py::test_greedy_config5_full_size
         "greedy_collect_65536",    # test_gpu_policy_collect.py::test_policy_collect_config5_size_selfplay
         # gbl_collect_from, T = 2: test_collect_from_external_first_ply_vs_oracle

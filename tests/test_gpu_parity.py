@@ -117,13 +117,25 @@ def test_step_vs_oracle(G, n, illegal, auto_reset, with_obs):
     state, tm, dn = selfplay(n, 24, seed=n % 1000)
     env = vec_env(G, n, state, tm, dn, illegal_mode=illegal, auto_reset=auto_reset, with_observation=with_obs)
     imode = {"noop": 0, "terminate": 1}[illegal]
+    status = torch.full((n,), 77, dtype=torch.int8, device=DEV)
+    nxt = torch.full((n,), 77, dtype=torch.int32, device=DEV)
     for k in range(4 if n > 100000 else 8):
         m = oracle.batch_legal_mask(state, tm)
         a = oracle.batch_sample(m, 5, 0, 100 + k)
         wild = rng.random(n) < 0.12
         a = np.where(wild, rng.integers(-3, 58, n), a).astype(np.int32)
+        exp_status = oracle.batch_action_status(state, tm, dn, a, auto_reset=auto_reset)   # (of the position BEFORE the step)
         o = oracle.batch_step(state, tm, dn, a, illegal_mode=imode, auto_reset=auto_reset, threads=8)
-        obs, rew, done, win = env.step(t(a))
+        if k % 2 == 0:
+            obs, rew, done, win = env.step(t(a))
+        else:
+            # gbl_step_ex (k_step<..., EXT>): the status byte of every action (out-of-range = illegal + flagged) and
+            # the next mover's masked-uniform draw from the mask this launch stores (= gbl_sample behind the step; -1 where
+            # nobody is to move: a frozen board)
+            obs, rew, done, win = env.step(t(a), status=status, next_actions=nxt)
+            assert np.array_equal(npy(status), exp_status), k
+            assert set(np.unique(exp_status)) <= {0, 1, 3} and ((exp_status == 3).any() or n < 1000)
+            assert np.array_equal(npy(nxt), oracle.batch_sample(o["mask"], env.seed, env.env_base, k + 1)), k
         assert np.array_equal(npy(env.squares), state), k
         assert np.array_equal(npy(env.to_move), tm) and np.array_equal(npy(done), dn)
         assert np.array_equal(npy(win), o["winner"]) and np.array_equal(npy(rew), o["reward"])

@@ -1,0 +1,85 @@
+"""Performance guards (-m gpu): the numbers README.md / DESIGN.md quote must still hold on a fresh box.  HIP-event medians of the
+very records bench.py reports (its own `short_run` / `greedy_run` code paths, not a re-implementation), against GENEROUS ceilings
+-- 8-15 % above what rounds 5-6 measured, boxes differ by a few percent -- so a green GPU run means no kernel regressed by more
+than that.  Parity is not checked here: tests/test_gpu_bench_kernels.py compares the same kernel instantiations with the oracle.
+
+    record (bench.py)          kernel                                  measured r05/r06       ceiling
+    headline 2^20 x 8 plies    k_collect<mask, obs>                    27.1-27.4 us per ply   29.5 (placed) / 36 (unplaced)
+    c2_4096                    k_collect_small<2 lanes, 2 obs waves>   0.52-0.55              0.60
+    c4_shard_131072            k_collect2                              3.3-3.5                3.9
+    single_ply_1048576         k_rollout (234 B per env-step)          35.8-36.3              38.0
+    step_pipeline_1048576      k_step<EXT> (next draw fused)           see STEP_CEILING       --
+    c5_greedy_65536            k_greedy<4,16>                          11.4-11.8              12.5
+"""
+import os
+import statistics
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+DEV = "cuda:0"
+STEP_CEILING = 40.0   # us per ply at 2^20 boards: one launch per ply with the action array read from HBM (rounds 1-5: 46.5 in two launches)
+
+
+@pytest.fixture(scope="module")
+def env():
+    import bench
+    import gobblet_rl_amd as G
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    G._native.lib()
+    return bench, G, torch.device(DEV)
+
+
+def median_us(bench, G, dev, boards, plies, mode, passes=3, **kw):
+    """Median over `passes` of a bench sub-record's us per ply (each pass: warm-up, one untimed graph replay, one timed)."""
+    recs = [bench.short_run(G, torch, dev, boards, plies, 16, mode=mode, traj=bench.auto_traj(boards, plies), **kw) for _ in range(passes)]
+    torch.cuda.empty_cache()
+    return statistics.median(r["us_per_step"] for r in recs), recs[-1]
+
+
+def test_headline_collect_kernel(env):
+    bench, G, dev = env
+    # placement "auto" with the far candidates bench.py itself allows (Pipeline: far=True): the record says whether it was found
+    us, rec = median_us(bench, G, dev, 1 << 20, 64, "collect", passes=2)
+    placed = (rec.get("trajectory_placement") or {}).get("ratio", 1.0) <= 0.86
+    assert rec["roofline"]["kernel"].startswith("k_collect (8 plies per launch)")
+    assert us <= (29.5 if placed else 36.0), (us, rec.get("trajectory_placement"))
+    assert rec["roofline"]["frac_on_survey_bytes"] > rec["roofline"]["frac"]       # (both accountings are in every record)
+
+
+def test_c2_small_batch(env):
+    bench, G, dev = env
+    us, rec = median_us(bench, G, dev, 4096, 2048, "collect")
+    assert "k_collect_small" in rec["roofline"]["kernel"] and us <= 0.60, us
+
+
+def test_c4_shard(env):
+    bench, G, dev = env
+    us, rec = median_us(bench, G, dev, 131072, 256, "collect")
+    assert rec["roofline"]["kernel"].startswith("k_collect2") and us <= 3.9, us
+
+
+def test_single_ply_kernel_on_survey_bytes(env):
+    bench, G, dev = env
+    us, rec = median_us(bench, G, dev, 1 << 20, 200, "fused")
+    assert rec["roofline"]["algorithmic_bytes_per_env_step"] == 234.0 and us <= 38.0, us
+
+
+def test_step_pipeline_one_launch_per_ply(env):
+    bench, G, dev = env
+    us, rec = median_us(bench, G, dev, 1 << 20, 200, "step")
+    assert rec["roofline"]["algorithmic_bytes_per_env_step"] == 234.0 and us <= STEP_CEILING, us
+    two, _ = median_us(bench, G, dev, 1 << 20, 200, "step2", passes=1)
+    assert us < two, (us, two)                                                    # the fused draw beats sample + step
+
+
+def test_greedy_config5(env):
+    bench, G, dev = env
+    us = statistics.median(bench.greedy_run(G, torch, dev)["us_per_step"] for _ in range(3))
+    assert us <= 12.5, us
