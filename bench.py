@@ -63,7 +63,7 @@ ALGO_BYTES_COLLECT_PLY, ALGO_BYTES_COLLECT_PLY_MASK_ONLY, ALGO_BYTES_COLLECT_LAU
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; max shader clock (MI355X_MICROARCH.md)
 TOTAL_BOARDS = 1 << 20
-COLLECT_KERNELS = {0: "k_collect", 1: "k_collect (plain stores)", 2: "k_collect2", 3: "k_collect3"}  # gbl_collect_variant()
+COLLECT_KERNELS = {0: "k_collect", 1: "k_collect (plain stores)", 2: "k_collect2", 4: "k_collect3"}  # gbl_collect_variant()
 
 
 def collect_kernel_name(variant):
@@ -369,7 +369,7 @@ class Pipeline:
         """Plies (counter + off) .. (counter + off + plies - 1) on `stream`; ev = (start, stop) events bracketing
         the dominant kernel.  by_value (mode collect, eager launches): the ply index goes in as an argument instead of being read
         from device memory, so no launch has to advance it afterwards (played(): 7 us of a one-launch span,
-        scripts/span_overhead.py)."""
+        scripts/experiments/span_overhead.py)."""
         P, lib, env, n = self.P, self.lib, self.env, self.boards
         assert not by_value or (self.mode == "collect" and self.host_ply is not None)
         if self.mode == "step":
@@ -879,25 +879,21 @@ def keep_stdout_for_the_line():
 
 
 def gpus_of_this_node():
-    """GPUs of this node counted WITHOUT torch or HIP (the launcher parent must not initialise the GPU before it starts its
-    children): the KFD topology's nodes with SIMDs.  None when /sys has no KFD topology (the ranks' own check then fires)."""
-    import glob
-    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
-    if not nodes:
-        return None if os.path.exists("/dev/kfd") else 0  # (no compute device node at all: no ROCm GPU)
-    count = 0
-    for path in nodes:
-        try:
-            props = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
-        except OSError:
-            return None
-        count += int(props.get("simd_count", "0")) > 0
-    return count
+    """GPUs this process tree can use, counted in a CHILD process (torch.cuda.device_count() there: exactly what the ranks will
+    see, container device filters and *_VISIBLE_DEVICES included) so that the launcher parent itself imports neither torch nor
+    HIP before it starts its children.  None when the count cannot be had (the ranks' own check then fires)."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                             text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves -- torch.distributed.run as a
-    CHILD process; this parent imports neither torch nor HIP (the devices are counted from /sys) -- and pass its exit code on.
+    CHILD process; this parent imports neither torch nor HIP (the devices are counted by a child too) -- and pass its exit code on.
     Rank 0's JSON line is the child's stdout, i.e. ours."""
     import socket
     import subprocess
@@ -975,7 +971,7 @@ def main():
 
     # A timed run of ONE launch (the driver's 20 plies) is launched eagerly: a graph of one kernel node + the counter node starts
     # no sooner and carries the counter node inside the timed span (131 072 boards x 20 plies: 90 vs 99 us of wall clock,
-    # scripts/launch_overhead.py); several launches are replayed as one hipGraph.  Either way the K plies are played ONCE untimed
+    # scripts/experiments/launch_overhead.py); several launches are replayed as one hipGraph.  Either way the K plies are played ONCE untimed
     # through the very same code path first (the first launch of an instantiated graph carries one-off costs, and so does the first
     # pass of the host code: 30 us on a 560 us region), then timed.
     use_graph = bool(args.graph) and nlaunch > 1
@@ -984,7 +980,7 @@ def main():
     stream = p.nat.current_stream(dev)
 
     # eager gbl_collect launches take the ply index by value (what BatchedGobblet.collect does without device_ply()): the launch
-    # that would move a device-resident index on is not needed, and not in the span (scripts/span_overhead.py: 7 of its 22 us)
+    # that would move a device-resident index on is not needed, and not in the span (scripts/experiments/span_overhead.py: 7 of its 22 us)
     by_value = graph is None and args.mode == "collect"
 
     def play_k():

@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import fcntl
 import os
+import platform
 import shutil
 import subprocess
 
@@ -21,7 +22,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libgobblet_hip.so")
 _FOREIGN = False  # use_library() was called: LIB_PATH is somebody's own build, never rebuilt from here
 SOURCES = [os.path.join(CSRC, "gobblet_hip.hip"), os.path.join(CSRC, "gobblet_device.h"), os.path.join(CSRC, "gobblet_diag.h"),
-           os.path.join(_HERE, "..", "include", "gobblet_hip.h")]
+           os.path.join(CSRC, "gobblet_knobs.h"), os.path.join(_HERE, "..", "include", "gobblet_hip.h")]
 # -amdgpu-kernarg-preload-count: the first 16 dwords of a kernel's arguments arrive in SGPRs with the wave
 # launch (the kernels order their arguments for that), so a wavefront's first loads do not wait for a
 # kernel-argument fetch; firmware without the feature runs the compiler's fallback prologue
@@ -191,7 +192,8 @@ def current_stream(device):
 CPU_LIB_PATH = os.path.join(CSRC, "libgobblet_cpu.so")
 CPU_SOURCES = [os.path.join(CSRC, "gobblet_cpu.cpp"), os.path.join(CSRC, "gobblet_device.h"),
                os.path.join(_HERE, "..", "include", "gobblet_cpu.h"), os.path.join(_HERE, "..", "include", "gobblet_hip.h")]
-CPU_CXX_FLAGS = ["-O3", "-std=c++17", "-mpopcnt", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", "-Wno-attributes"]
+CPU_CXX_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", "-Wno-attributes"] + \
+                (["-mpopcnt"] if platform.machine() in ("x86_64", "AMD64") else [])
 _NO_HOST_FLAVOUR = ("gbl_pinned_alloc", "gbl_pinned_free", "gbl_block_alloc", "gbl_block_free", "gbl_device_memory",
                     "gbl_placement_probe", "gbl_collect_variant")
 CPU_SIGNATURES = {"gbl_cpu_" + k[4:]: v for k, v in SIGNATURES.items() if k not in _NO_HOST_FLAVOUR}
@@ -204,7 +206,9 @@ def build_cpu(force: bool = False) -> str:
         return not os.path.exists(CPU_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(CPU_LIB_PATH) for s in CPU_SOURCES)
     if not force and not stale():
         return CPU_LIB_PATH
-    cxx = shutil.which("g++") or shutil.which("c++")
+    # (a box with the GPU toolchain but no g++: ROCm's clang++ compiles the host flavour just as well)
+    cxx = shutil.which("g++") or shutil.which("c++") or shutil.which("clang++") or shutil.which("amdclang++") or \
+        next((p for p in ("/opt/rocm/lib/llvm/bin/clang++", "/opt/rocm/bin/amdclang++") if os.path.exists(p)), None)
     if not cxx:
         raise GobbletHipError("no C++ compiler found: cannot build csrc/libgobblet_cpu.so")
     with open(CPU_LIB_PATH + ".lock", "w") as lock:

@@ -184,7 +184,7 @@ int gbl_cpu_set_threads(int threads)  // 0 = the hardware's (host flavour only)
 int gbl_cpu_layout_info(int32_t out[6])
 {
     if (!out) return fail(GBL_ERR_ARG, "out must not be NULL");
-    out[0] = 1; out[1] = kCells; out[2] = kActions; out[3] = kObs; out[4] = kTile; out[5] = 1;  // (no alignment asked of host buffers)
+    out[0] = GBL_ABI_VERSION; out[1] = kCells; out[2] = kActions; out[3] = kObs; out[4] = kTile; out[5] = 1;  // (no alignment asked of host buffers)
     return GBL_OK;
 }
 

@@ -10,6 +10,7 @@
 
 #include "../../include/gobblet_hip.h"
 #include "gobblet_diag.h"
+#include "gobblet_knobs.h"  // the product's constants -- or, in an experiment build (-DGBL_AB_BUILD), the A/B knobs of gobblet_ab.h
 
 using namespace gbl;
 
@@ -63,20 +64,16 @@ constexpr int kStepWaves = 1;  // (128- and 256-thread workgroups: +-1-2 %, roun
 
 // Non-temporal store policy of the step kernels (see store_rows): stream the observation always, the
 // mask too once one ply's footprint exceeds the 256 MiB Infinity Cache.  A pure function of the batch size: the
-// library reads no environment and keeps no state; A/B builds pin a policy with -DGBL_FORCE_NT=1|3
-// (scripts/build_variant.sh).
+// library reads no environment and keeps no state (experiment builds pin a policy: gobblet_ab.h).
 inline int nt_policy(int64_t n)
 {
-#ifdef GBL_FORCE_NT
-    return (GBL_FORCE_NT) == 3 ? 3 : 1;
-#else
+    if (knob::kForcedNt) return knob::kForcedNt == 3 ? 3 : 1;
     return n * 234 > ((int64_t)256 << 20) ? 3 : 1;
-#endif
 }
 
 // gbl_collect always stores its trajectory rows non-temporally.  Plain (cached) stores win 5-12 % where the trajectory fits
 // the Infinity Cache AND the batch is 131 072 - 262 144 boards, but lose 15 % at 65 536 boards and 30 % once it does not fit
-// (see k_collect): the product build has no such path; A/B builds get it back with -DGBL_FORCE_COLLECT_NT=0.
+// (see k_collect): the product build has no such path (experiment builds: gobblet_ab.h).
 
 // Which kernel a gbl_collect call runs (also reported by gbl_collect_variant): GBL_COLLECT_PAIR = k_collect2 (grids of up
 // to kCollect2MaxTiles tiles that stream), GBL_COLLECT_STREAM / GBL_COLLECT_CACHED = k_collect with non-temporal / plain
@@ -87,11 +84,8 @@ inline int nt_policy(int64_t n)
 constexpr int64_t kCollect2MaxTiles = 2560;
 
 // Which form of the role kernel (k_collect_small<LA, KO, MERGE>, see there) a batch of n boards runs, as 100 LA + 10 KO + MERGE;
-// 0 = none (k_collect2 / k_collect).  Measured, us per ply, FULL outputs, 32 plies per launch (scripts/ab_roles.sh, round 5):
+// 0 = none (k_collect2 / k_collect).  Measured, us per ply, FULL outputs, 32 plies per launch (scripts/experiments/ab_roles.sh, round 5):
 // see the table in DESIGN.md 5.2.
-#ifdef GBL_AB_COLLECT_CFG
-int g_ab_collect_cfg = -1;  // A/B builds only: gbl_ab_collect_cfg() picks the form at run time (one library, many forms)
-#endif
 
 // k_collect's occupancy, pinned: FOUR wavefronts per SIMD.  Until round 5 that was an accident of the register allocation (111
 // VGPRs, most of them the ragged tile's byte loop's); when the ragged paths were rewritten the kernel needed 83, a fifth wavefront
@@ -99,20 +93,13 @@ int g_ab_collect_cfg = -1;  // A/B builds only: gbl_ab_collect_cfg() picks the f
 // 27.21 / 26.81; profiles/r05/collect_occupancy.txt) -- more tiles open at once is more write streams for the same DRAM pages.
 constexpr int64_t kTrioHandMaxTiles = 8192;  // k_collect3<..., HAND>: the first row wavefront stores the scalars up to 524 288 boards
 
-#ifndef GBL_COLLECT_WAVES_PER_EU
-#define GBL_COLLECT_WAVES_PER_EU 4, 4
-#endif
 
 inline int small_cfg(int64_t n, bool with_mask, bool with_obs)
 {
     (void)with_mask;
-#ifdef GBL_AB_COLLECT_CFG
-    if (g_ab_collect_cfg >= 0) return g_ab_collect_cfg;
-#endif
-#ifdef GBL_FORCE_COLLECT_SMALL  // A/B builds: 0 = never, else the form
-    return (GBL_FORCE_COLLECT_SMALL);
-#else
-    // (round 5, scripts/ab_roles.sh; DESIGN.md 5.2 has the table; 3 = k_collect3)
+    if (knob::collect_cfg_override() >= 0) return knob::collect_cfg_override();  // (experiment builds only)
+    if (knob::kForcedCollectSmall >= 0) return knob::kForcedCollectSmall;
+    // (round 5, scripts/experiments/ab_roles.sh; DESIGN.md 5.2 has the table; 3 = k_collect3)
     // MASK_ONLY is bound by what ONE wavefront issues, so the player + mask-row pair of k_collect3 keeps paying far
     // into the HBM regime: 163 840 boards 1.79 against k_collect's 2.19 us per ply, 2^20: 10.39 against 10.93, 2^21: 19.9 against
     // 20.7; 2^22: 45.1 against 44.5 (profiles/r05/ab_roles_long_launches.txt)
@@ -122,22 +109,14 @@ inline int small_cfg(int64_t n, bool with_mask, bool with_obs)
     // (late round 5: with its scalars stored by the first row wavefront k_collect3 runs 0.634 us per ply at 8 192 ... 16 384 boards,
     //  256 plies per launch -- <1,2>: 0.643 at 12 288, 0.72 at 16 384; <2,2>: 0.558 at 8 192: profiles/r05/ab_trio_scalars.txt)
     return n <= 8192 ? 220 : n <= 45056 ? 3 : 0;
-#endif
 }
 
 inline int collect_variant(int64_t n, uint32_t plies, bool with_mask, bool with_obs)
 {
     (void)plies;
-#ifdef GBL_FORCE_COLLECT_NT
-    const bool nt = (GBL_FORCE_COLLECT_NT) != 0;
-#else
-    const bool nt = true;
-#endif
-#ifdef GBL_FORCE_COLLECT_PAIR  // 0 / 1: A/B builds
-    const bool pair = (GBL_FORCE_COLLECT_PAIR) != 0;
-#else
-    const bool pair = (n + kTile - 1) / kTile <= kCollect2MaxTiles && nt && (with_mask || with_obs);
-#endif
+    const bool nt = knob::kForcedCollectNt != 0;
+    const bool pair = knob::kForcedCollectPair >= 0 ? knob::kForcedCollectPair != 0
+                                                    : (n + kTile - 1) / kTile <= kCollect2MaxTiles && nt && (with_mask || with_obs);
     const int cfg = nt ? small_cfg(n, with_mask, with_obs) : 0;
     if (cfg == 3) return (with_mask || with_obs) ? GBL_COLLECT_TRIO : GBL_COLLECT_STREAM;
     return cfg ? GBL_COLLECT_ROLES(cfg / 100, (cfg / 10) % 10, cfg % 10) : pair ? GBL_COLLECT_PAIR : nt ? GBL_COLLECT_STREAM : GBL_COLLECT_CACHED;
@@ -645,7 +624,7 @@ __global__ __launch_bounds__(64 * kStepWaves) void k_rollout(int8_t *__restrict_
 // plies 4.15 vs 4.76 us per ply, 262 144 x 4: 8.5 vs 9.5 -- but 65 536 x 16: 2.44 vs 2.12); the host decides by the
 // footprint in A/B builds only (gpurun_out/ab5, scripts/sweep_sizes.py with -DGBL_FORCE_COLLECT_NT=0|1); the product streams.
 template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY, bool NT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GBL_COLLECT_WAVES_PER_EU))) void k_collect(int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GBL_KNOB_COLLECT_WAVES_PER_EU))) void k_collect(int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n,
                                                 int64_t ntiles, uint64_t seed, uint64_t env_base,
                                                 const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies,
                                                 int8_t *__restrict__ done, int64_t ply_stride, int64_t tile_stride,
@@ -877,7 +856,7 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
 // its playing wavefront's serial path; a lone wavefront issues one instruction per 5-7 cycles whatever it is, so what counts is
 // the number of instructions ONE wavefront executes per ply.  The game itself -- sample, move, winner, auto-reset, next legal
 // mask: the CHAIN, ~250 instructions, every one depending on the ply before -- cannot be dealt out (0.72 us per ply with nothing
-// stored, scripts/ab_floor.sh); everything else can.  A role wavefront loads a SUB-TILE of 64 / LPB boards (LPB lanes per board,
+// stored, scripts/experiments/ab_floor.sh); everything else can.  A role wavefront loads a SUB-TILE of 64 / LPB boards (LPB lanes per board,
 // all playing alike), plays every ply, and materialises one share of the outputs, 1 / LPB of a row per lane --
 //   scalars: the five scalars of a ply, the tallies, and at the end the state (the only role that patches a state image);
 //   mask:    the mask rows (lane j: bytes [64 j / LPB, 64 (j + 1) / LPB) of its board's row);
@@ -886,7 +865,7 @@ __global__ __launch_bounds__(128) void k_collect2(int8_t *__restrict__ state, in
 // is read back into registers at the end of its iteration and stored in the NEXT one, behind the sample and the move: the LDS
 // round trip is off the chain.  Bit for bit the trajectories of k_collect (same sampler keys, same arithmetic).
 //
-// What a role costs a lone wavefront per ply (round 5, scripts/ab_roles.sh): the chain 0.72 us, + scalars ~0.05, + mask rows ~0.10
+// What a role costs a lone wavefront per ply (round 5, scripts/experiments/ab_roles.sh): the chain 0.72 us, + scalars ~0.05, + mask rows ~0.10
 // whatever LPB, + observation rows 0.15 / 0.30 / 0.58 at 16 / 32 / 64 boards per wavefront: the observation role is the long one,
 // and it alone gains from more lanes per board.  So a WORKGROUP is a group of 64 / LA boards with
 //   one scalars wavefront (which also builds the mask rows when MERGE) and, unless MERGE, one mask wavefront, LA lanes per board,
@@ -1328,12 +1307,12 @@ __global__ __launch_bounds__(64 * (1 + (WITH_MASK ? 1 : 0) + (WITH_OBS ? 1 : 0))
 }
 
 // wavefronts of a workgroup of the role kernel: the scalars wavefront, the mask wavefront unless merged, KO observation wavefronts
-// (KO = 0, MERGE: ONE wavefront per group holds all three roles -- A/B builds only, see scripts/ab_oneply.py)
+// (KO = 0, MERGE: ONE wavefront per group holds all three roles -- A/B builds only, see scripts/experiments/ab_oneply.py)
 template <bool WITH_MASK, bool WITH_OBS, int KO, bool MERGE>
 constexpr int small_waves() { return 1 + ((WITH_MASK && !MERGE) ? 1 : 0) + (WITH_OBS ? KO : 0); }
 
 // (The one-ply entry points -- gbl_rollout with plies = 1, gbl_step -- were routed here too and gained nothing: 3.34-3.47 us per
-// launch against k_rollout's 3.29-3.36 at 1 024 - 4 096 boards, scripts/ab_ply.sh: a one-ply launch is its tile load, the chain
+// launch against k_rollout's 3.29-3.36 at 1 024 - 4 096 boards, scripts/experiments/ab_ply.sh: a one-ply launch is its tile load, the chain
 // and the launch boundary, none of which a smaller tile shortens.  They stay on k_rollout / k_step.)
 template <bool WITH_MASK, bool WITH_OBS, bool DEV_PLY, int LA, int KO, bool MERGE>
 __global__ __launch_bounds__((64 * small_waves<WITH_MASK, WITH_OBS, KO, MERGE>())) void k_collect_small(
@@ -1592,17 +1571,13 @@ __device__ __forceinline__ void list_append2(uint16_t *list, uint16_t *listx, in
 // loop in closed form over the sets (greedy_replay_closed).
 // Safe to call in a loop: what the owners read last (replay) and write first (heads) is their own wavefront's business,
 // and everybody else's reads of an iteration lie before its last barrier.
-// FLOOR builds (scripts/greedy_floor.sh; results are WRONG, timing only): -DGBL_X_GREEDY_SKIP=bits leaves phases of the decision
-// out -- 1 the owners' tail (merge, replay), 2 the chunk phase (the evaluations), 4 the list phase, 8 the B phase (depth-1 walk,
-// root, nonplain set), 16 the candidate rows of gbl_greedy's output -- so that what a block cannot go below is measured, not argued.
-#ifndef GBL_X_GREEDY_SKIP
-#define GBL_X_GREEDY_SKIP 0
-#endif
+// (kSkip: 0 in the product.  The FLOOR builds of scripts/greedy_floor.sh -- experiment builds, gobblet_ab.h -- leave phases of the
+// decision out, with WRONG results, so that what a block cannot go below is measured, not argued.)
 template <int NT, int W>
 __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const Planes &p, int me, uint64_t mask, int depth,
                                                     bool deep, uint32_t prev3, TileStamps &ts)
 {
-    constexpr int kSkip = GBL_X_GREEDY_SKIP;
+    constexpr int kSkip = knob::kGreedySkip;
     const int lane = (int)(threadIdx.x & 63u), wave = wave_index();
     const bool owner = wave < NT;
     const int bi = (owner ? wave : wave - NT) * kTile + lane;  // the board this thread owns, or helps with (wave < 2 NT)
@@ -1725,7 +1700,12 @@ __device__ __forceinline__ GreedyResult greedy_tile(GreedyLds<NT, W> &S, const P
         // (E) the work in chunks of 64, handed out through a counter -- the ordered pairs first (an ordered evaluation is
         // twice a fast one), then the fast pairs, then the items: whoever is through takes the next chunk, so the oldest
         // wavefronts of a SIMD, which win the issue arbitration, simply take more
-        const int nfast = S.npairs & 0xFFFF, nslow = (int)((uint32_t)S.npairs >> 16), nitems = S.nitems;
+        int nfast = S.npairs & 0xFFFF, nslow = (int)((uint32_t)S.npairs >> 16);
+        const int nitems = S.nitems;
+        if constexpr (knob::kGreedyPairCap > 0) {  // (floor builds only: pairs beyond the cap are dropped -- WRONG results, timing only)
+            nslow = nslow < knob::kGreedyPairCap ? nslow : knob::kGreedyPairCap;
+            nfast = nfast < knob::kGreedyPairCap - nslow ? nfast : knob::kGreedyPairCap - nslow;
+        }
         const int jslow = (nslow + kTile - 1) / kTile, jfast = (nfast + kTile - 1) / kTile, jitem = (nitems + kTile - 1) / kTile;
         auto record = [&](uint32_t o, uint32_t a, uint32_t sum) {
             if (sum & 1u) {
@@ -1893,7 +1873,7 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
     GBL_STAMP_VAL(2, ts.t[1]);
     GBL_STAMP_VAL(3, ts.t[2]);
     if (!owner || L.rows == 0) return;
-    if (cand_out && !(GBL_X_GREEDY_SKIP & 16)) {
+    if (cand_out && !(knob::kGreedySkip & 16)) {
         mask_to_image<true>(s_mask, L.lane, g.cands);
         wave_lds_fence();
         tile_out<kActions>(cand_out + L.tile * (kTile * kActions), s_mask, L.lane, L.rows);
@@ -1927,11 +1907,8 @@ __global__ __launch_bounds__(64 * W) void k_greedy(const int8_t *__restrict__ st
 // The owner wavefronts do everything but the shared depth-2 work.
 // (Register budget: four wavefronts per SIMD = 128 VGPRs.  Left alone the compiler takes ~160 -- the ply loop keeps the
 // decision's literal constants live across iterations -- which costs a wavefront of occupancy for nothing.)
-#ifndef GBL_CP_WAVES_PER_EU
-#define GBL_CP_WAVES_PER_EU 4
-#endif
 template <int NT, int W>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 && NT == 1 ? GBL_CP_WAVES_PER_EU : 1, 8))) void k_collect_policy(
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 && NT == 1 ? GBL_KNOB_CP_WAVES_PER_EU : 1, 8))) void k_collect_policy(
     int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n, int64_t ntiles, uint64_t seed, uint64_t env_base,
     const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies, int8_t *__restrict__ done, int64_t ply_stride,
     int64_t tile_stride, int32_t *__restrict__ actions_t, int8_t *__restrict__ winner_t, int8_t *__restrict__ reward_t,
@@ -2098,7 +2075,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 &&
 }
 
 // k_collect_small for a checked call (see gbl_collect_from); cfg = 100 LA + 10 KO + MERGE (collect_variant)
-// (the product build instantiates the forms collect_variant() can return; an A/B build -- GBL_AB_COLLECT_CFG -- a whole menu)
+// (the product build instantiates the forms collect_variant() can return; an experiment build a whole menu: gobblet_ab.h)
 bool launch_small(int cfg, int8_t *state, int8_t *to_move, int8_t *done, const int32_t *first_actions, int8_t *first_status, int32_t *actions_t, int8_t *winner_t,
                   int8_t *reward_t, int8_t *done_t, int8_t *to_move_t, int8_t *mask_t, int8_t *obs_t, int64_t n, int64_t ply_stride,
                   int64_t tile_stride, uint64_t seed, uint64_t env_base, uint32_t ply0, const uint32_t *ply_dev, uint32_t plies,
@@ -2123,21 +2100,7 @@ bool launch_small(int cfg, int8_t *state, int8_t *to_move, int8_t *done, const i
     }
     GBL_SMALL_CFG(2, 2, false)
     GBL_SMALL_CFG(2, 1, false)
-#ifdef GBL_AB_COLLECT_CFG
-    GBL_SMALL_CFG(1, 2, false)  // (the product's form for 8 193 ... 16 384 boards until k_collect3's scalars left its playing wavefront)
-    GBL_SMALL_CFG(1, 1, false)
-    GBL_SMALL_CFG(4, 1, false)
-    GBL_SMALL_CFG(1, 4, false)
-    GBL_SMALL_CFG(1, 4, true)
-    GBL_SMALL_CFG(1, 2, true)
-    GBL_SMALL_CFG(1, 1, true)
-    GBL_SMALL_CFG(2, 2, true)
-    GBL_SMALL_CFG(2, 1, true)
-    GBL_SMALL_CFG(4, 1, true)
-    GBL_SMALL_CFG(4, 0, true)
-    GBL_SMALL_CFG(2, 0, true)
-    GBL_SMALL_CFG(1, 0, true)
-#endif
+    GBL_KNOB_SMALL_FORMS
 #undef GBL_SMALL_CFG
 #undef GBL_SMALL_D
 #undef GBL_SMALL_K
@@ -2180,7 +2143,7 @@ const char *gbl_last_error(void) { return g_err; }
 int gbl_layout_info(int32_t out[6])
 {
     if (!out) return fail(GBL_ERR_ARG, "out must not be NULL");
-    out[0] = 1; out[1] = kCells; out[2] = kActions; out[3] = kObs; out[4] = kTile; out[5] = 16;
+    out[0] = GBL_ABI_VERSION; out[1] = kCells; out[2] = kActions; out[3] = kObs; out[4] = kTile; out[5] = 16;
     return GBL_OK;
 }
 
@@ -2564,16 +2527,10 @@ int gbl_collect_from_ex(int8_t *state, int8_t *to_move, int8_t *done, const int3
             return fail(GBL_ERR_ARG, "gbl_collect: this build has no such form of the role kernel");
         GBL_LAUNCHED("gbl_collect");
     }
-#ifdef GBL_FORCE_COLLECT_NT  // (A/B builds: the plain-store instantiation exists only there)
+    // (the plain-store instantiation of k_collect exists in experiment builds only)
 #define GBL_COLLECT_K(M, O, D)                                  \
     if (pair) GBL_COLLECT_K2(M, O, D);                          \
-    else if (nt) GBL_COLLECT_KN(M, O, D, true);                 \
-    else GBL_COLLECT_KN(M, O, D, false)
-#else
-#define GBL_COLLECT_K(M, O, D)                                  \
-    if (pair) GBL_COLLECT_K2(M, O, D);                          \
-    else GBL_COLLECT_KN(M, O, D, true)
-#endif
+    else GBL_KNOB_COLLECT_STREAM_OR_PLAIN(M, O, D)
 #define GBL_COLLECT_K2(M, O, D)                                                                                         \
     hipLaunchKernelGGL((k_collect2<M, O, D>), dim3((uint32_t)g.ntiles), dim3(128), 0, s, state, to_move, n, g.ntiles, seed, \
                        env_base, ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj,        \
@@ -2647,24 +2604,11 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
     else if (shape == 26) GBL_CP(1, 16);
     else if (shape == 28) GBL_CP(2, 8);
     else if (shape == 14) GBL_CP(1, 4);
-#if defined(GBL_FORCE_GREEDY_SHAPE) && GBL_FORCE_GREEDY_SHAPE == 48
-    else if (shape == 48) GBL_CP(4, 8);
-#endif
-#if defined(GBL_FORCE_GREEDY_SHAPE) && GBL_FORCE_GREEDY_SHAPE == 18
-    else if (shape == 18) GBL_CP(1, 8);
-#endif
+    GBL_KNOB_CP_SHAPES
     else GBL_CP(1, 1);
 #undef GBL_CP
     GBL_LAUNCHED("gbl_collect_policy");
 }
-
-#ifdef GBL_AB_COLLECT_CFG
-int gbl_ab_collect_cfg(int cfg)  // (A/B builds only, not part of the ABI: -1 = the library's own choice)
-{
-    g_ab_collect_cfg = cfg;
-    return GBL_OK;
-}
-#endif
 
 int gbl_collect_variant(int64_t n, uint32_t plies, int with_mask, int with_obs)
 {
@@ -2779,13 +2723,9 @@ namespace {
 
 int greedy_shape(int depth, int64_t n)
 {
-#ifdef GBL_FORCE_GREEDY_SHAPE  // A/B builds (scripts/build_variant.sh)
-    (void)n;
-    return depth == 1 ? 11 : GBL_FORCE_GREEDY_SHAPE;
-#else
+    if (knob::kForcedGreedyShape) return depth == 1 ? 11 : knob::kForcedGreedyShape;
     // (round 5, scripts/ab_greedy.py: at 262 144 boards <1,4> 39.8 us against <4,16>'s 40.8 since the depth-1 walk is a closed form)
     return depth == 1 ? 11 : n <= 16384 ? 26 : n <= 32768 ? 28 : n <= 65536 ? 56 : n <= 196608 && whole_generations(n) ? 56 : 14;
-#endif
 }
 
 // ... and of gbl_collect_policy's, whose ply loop keeps more registers live: blocks of tiles only where they stay inlined
@@ -2806,12 +2746,8 @@ int greedy_shape(int depth, int64_t n)
 //     <4,16> inlined                           12.6     12.9      25.2      49.9
 int policy_shape(int depth, int64_t n)
 {
-#ifdef GBL_FORCE_GREEDY_SHAPE
-    (void)n;
-    return depth <= 1 ? 11 : GBL_FORCE_GREEDY_SHAPE;
-#else
+    if (knob::kForcedGreedyShape) return depth <= 1 ? 11 : knob::kForcedGreedyShape;
     return depth <= 1 ? 11 : n <= 16384 ? 26 : n <= 32768 ? 28 : n <= 65536 ? 56 : n <= 262144 && whole_generations(n) ? 56 : 14;
-#endif
 }
 
 void launch_greedy(int shape, int64_t n, hipStream_t stream, const int8_t *state, const int8_t *to_move,
@@ -2831,12 +2767,7 @@ void launch_greedy(int shape, int64_t n, hipStream_t stream, const int8_t *state
     else if (shape == 28) GBL_GREEDY(2, 8);
     else if (shape == 26) GBL_GREEDY(1, 16);
     else if (shape == 14) GBL_GREEDY(1, 4);
-#if defined(GBL_FORCE_GREEDY_SHAPE) && GBL_FORCE_GREEDY_SHAPE == 48
-    else if (shape == 48) GBL_GREEDY(4, 8);
-#endif
-#if defined(GBL_FORCE_GREEDY_SHAPE) && GBL_FORCE_GREEDY_SHAPE == 18
-    else if (shape == 18) GBL_GREEDY(1, 8);
-#endif
+    GBL_KNOB_GREEDY_SHAPES
     else GBL_GREEDY(1, 1);
 #undef GBL_GREEDY
 }
@@ -2878,3 +2809,5 @@ int gbl_greedy_act_at(const int8_t *state, const int8_t *to_move, const int8_t *
 }
 
 }  // extern "C"
+
+GBL_KNOB_EXTRA_ENTRY_POINTS  // (nothing in the product; an experiment build's run-time form switch: gobblet_ab.h)

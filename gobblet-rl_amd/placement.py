@@ -1,6 +1,6 @@
 """Where the two large trajectory arrays of ``gbl_collect`` lie in HBM.
 
-Measured on MI355X (scripts/placement_map.py, placement_map2.py, placement_probe_check.py): the 288 GiB
+Measured on MI355X (scripts/experiments/placement_map.py, placement_map2.py, placement_probe_check.py): the 288 GiB
 of device memory fall into three classes of 96 GiB -- by the size, the three die groups of the 12-high HBM3E stacks --
 and two write streams inside ONE class do not overlap: ``gbl_collect`` then takes the sum of what its observation
 stream and its mask stream take alone (33-34 us per ply at 2^20 boards), against 27 us when the two arrays lie in

@@ -133,8 +133,8 @@ class BatchedGobblet:
         if self.turn is not None:
             self.turn.zero_()
         self.ply = 0
-        if getattr(self, "_staging", None):
-            self.release_staging()
+        # (collect()'s staging buffers are KEPT: a captured hipGraph may have their addresses baked in, and a reset-then-collect
+        #  loop must not re-run the placement search every episode -- release_staging() is the explicit way to drop them)
         self.refresh()
         return self.observe()
 
@@ -372,8 +372,11 @@ class BatchedGobblet:
         tensors are valid until the next ``collect`` of the same shape on this environment -- two successive calls return THE
         SAME tensors (clone what must outlive the next call, pass ``out``, or pass ``out="fresh"`` for buffers of your own made
         on the spot).  At most ``STAGING_SETS`` (2) sets are kept, least recently used dropped first (a set is several GiB at
-        2^20 boards); ``release_staging()`` / ``reset()`` drop them all.  Round 3 allocated fresh unplaced buffers per call,
-        which ran at 0.72-0.85 of the placed rate at 2^20 boards and paid an allocation per call.
+        2^20 boards); only ``release_staging()`` drops them all -- ``reset()`` keeps them.  hipGraph caveat: a graph captured around
+        ``collect(T)`` WITHOUT ``out=`` has the staging set's addresses baked in; a set that is used while a stream is capturing is
+        therefore pinned (exempt from the LRU eviction) and lives until ``release_staging()`` -- call that only once no such graph will
+        be replayed again (or capture with ``out=`` buffers of your own, whose lifetime you hold).  Round 3 allocated fresh unplaced
+        buffers per call, which ran at 0.72-0.85 of the placed rate at 2^20 boards and paid an allocation per call.
 
         ``first_actions`` (int (N,)): the first ply plays these actions -- an external policy's decision -- and the
         remaining plies are sampled (``gbl_collect_from``): ``collect(2, out, first_actions=a)`` is one decision of the
@@ -402,10 +405,14 @@ class BatchedGobblet:
             if made:
                 out = self.trajectory_buffers(T, layout=layout, policy_outputs=policies is not None, far=False)
             # (buffers made inside a graph capture belong to the graph's private pool: not kept beyond it)
-            if not (made and self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+            if not (made and capturing):
+                if capturing:
+                    out["_pinned"] = True            # a graph now replays into these addresses: never evicted (release_staging() only)
                 self._staging[key] = out             # most recently used last
-                while len(self._staging) > self.STAGING_SETS:
-                    self._staging.pop(next(iter(self._staging)))
+                loose = [k for k, v in self._staging.items() if not v.get("_pinned")]
+                while len(loose) > self.STAGING_SETS:
+                    self._staging.pop(loose.pop(0))
         if out["_plies"] != T:
             raise ValueError("trajectory buffers were made for %d plies" % out["_plies"])
         f, n = out["_full"], self.num_envs

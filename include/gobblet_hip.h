@@ -71,7 +71,10 @@ extern "C" {
 #define GBL_ILLEGAL_NOOP 0      /* raw_env.step: silent no-op, the turn still passes (gobblet.py:244-246, board.py:125-126) */
 #define GBL_ILLEGAL_TERMINATE 1 /* env(): TerminateIllegalWrapper(illegal_reward=-1) (gobblet.py:114, :50-51) */
 
-/* Version / layout query: writes {abi_version, cells, actions, obs_bytes, tile_boards, row_alignment}. */
+/* Version / layout query: writes {abi_version, cells, actions, obs_bytes, tile_boards, row_alignment}.
+ * abi_version 2 (round 6): + gbl_step_ex, gbl_collect_from_ex, GBL_STATUS_*; gbl_collect_variant reports GBL_COLLECT_TRIO as 4
+ * (3, once GBL_COLLECT_SMALL, is retired).  Every entry point of version 1 keeps its signature and meaning. */
+#define GBL_ABI_VERSION 2
 int gbl_layout_info(int32_t out[6]);
 
 /* Message of the last error on this thread ("" if none). */
@@ -338,7 +341,10 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
 #define GBL_COLLECT_STREAM 0
 #define GBL_COLLECT_CACHED 1
 #define GBL_COLLECT_PAIR 2
-#define GBL_COLLECT_TRIO 3
+#define GBL_COLLECT_TRIO 4
+/* (3 was GBL_COLLECT_SMALL until ABI version 1's role kernel got its forms; the code is retired, not reused: a consumer built
+ *  against that header never reads k_collect3 as the small-batch kernel.  The name stays as an alias of the form it stood for.) */
+#define GBL_COLLECT_SMALL GBL_COLLECT_ROLES(4, 1, 0) /* deprecated */
 #define GBL_COLLECT_ROLES(la, ko, merge) (1000 + 100 * (la) + 10 * (ko) + (merge))
 #define GBL_COLLECT_IS_ROLES(variant) ((variant) >= 1000)
 int gbl_collect_variant(int64_t n, uint32_t plies, int with_mask, int with_obs);

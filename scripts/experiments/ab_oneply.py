@@ -2,7 +2,7 @@
 """One ply per launch (the literal raw_env.step drop-in: a trainer with its policy outside the library): gbl_rollout_at(plies = 1)
 on k_rollout against gbl_collect(plies = 1) on the collect kernels' forms writing the SAME environment tensors, in-process on a
 library built with -DGBL_AB_COLLECT_CFG (build/lib_ab.so): 200 dependent launches as one hipGraph.
-    python scripts/ab_oneply.py BOARDS cfg cfg ...     cfg: -2 = k_rollout, 0 = k_collect2 / k_collect, 3 = k_collect3, 100 LA + 10 KO + MERGE"""
+    python scripts/experiments/ab_oneply.py BOARDS cfg cfg ...     cfg: -2 = k_rollout, 0 = k_collect2 / k_collect, 3 = k_collect3, 100 LA + 10 KO + MERGE"""
 import ctypes as C
 import os
 import statistics
@@ -10,7 +10,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import gobblet_rl_amd as G  # noqa: E402
 
 if os.environ.get("GOBBLET_HIP_LIB"):  # an experiment's own build of the library (scripts/build_variant.sh)

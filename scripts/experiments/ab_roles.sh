@@ -1,7 +1,7 @@
 #!/bin/bash
 # The role kernel's forms (k_collect_small<LA, KO, MERGE>: cfg = 100 LA + 10 KO + MERGE) against k_collect2 / k_collect (cfg 0),
 # one process per size (scripts/ab_cfg.py): T = 32 plies per launch, every ply materialised, FULL and MASK_ONLY.
-#   gpurun -- 'scripts/ab_roles.sh [outdir]'      SIZES="..." / CFGS="..." override the batch sizes / the forms
+#   gpurun -- 'scripts/experiments/ab_roles.sh [outdir]'      SIZES="..." / CFGS="..." override the batch sizes / the forms
 set -e -o pipefail
 O=${1:-gpurun_out/ab_roles}
 mkdir -p $O

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B sweep of library variants (scripts/build_variant.sh) over batch sizes, one GPU call:
-#   scripts/ab_sweep.sh OUTDIR "SIZES" "MODES" lib1.so lib2.so ...      (a leading "check:" on a lib also runs the GPU parity tests on it)
+#   scripts/experiments/ab_sweep.sh OUTDIR "SIZES" "MODES" lib1.so lib2.so ...      (a leading "check:" on a lib also runs the GPU parity tests on it)
 # extra arguments for scripts/sweep_sizes.py in $SWEEP_ARGS
 set -e -o pipefail
 export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What the driver's 20 timed plies cost beyond their kernel (one gbl_collect launch of 20 plies at 2^20 boards: ~545 us of
 kernel time): wall clock from a synchronised start to a synchronised end, for the ways of launching and of waiting.
-    python scripts/launch_overhead.py [BOARDS] [PLIES]"""
+    python scripts/experiments/launch_overhead.py [BOARDS] [PLIES]"""
 import os
 import statistics
 import sys
@@ -9,7 +9,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench  # noqa: E402
 import gobblet_rl_amd as G  # noqa: E402
 

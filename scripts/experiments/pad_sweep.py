@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """gbl_collect's time per ply against the padding of a trajectory slot (BatchedGobblet.trajectory_buffers(pad_boards=...)): do the
 ply slots of a large batch alias in HBM (their starts are 117 x 2^20 / 2^22 bytes apart: multiples of a large power of two)?
-    python scripts/pad_sweep.py BOARDS T"""
+    python scripts/experiments/pad_sweep.py BOARDS T"""
 import os
 import statistics
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import gobblet_rl_amd as G  # noqa: E402
 
 if os.environ.get("GOBBLET_HIP_LIB"):  # an experiment's own build of the library (scripts/build_variant.sh)

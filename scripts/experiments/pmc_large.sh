@@ -3,7 +3,7 @@
 # Counters, not sweeps: separate rocprofv3 --pmc passes -- the L2's write-request interface to the fabric
 # (requests, stalls, credit stalls, requests in flight), its per-channel spread, and the address-translation path (UTCL1 hits /
 # misses / stalls, UTCL2 busy) -- for k_collect (T = 8) at 2^20 and 2^22 boards and k_rollout (one ply) at 2^22.
-#   gpurun -- 'scripts/pmc_large.sh [outdir]'    then the summaries are under outdir/*.counters.csv
+#   gpurun -- 'scripts/experiments/pmc_large.sh [outdir]'    then the summaries are under outdir/*.counters.csv
 set -e -o pipefail
 export TMPDIR=/tmp
 O=${1:-gpurun_out/pmc_large}
@@ -29,4 +29,4 @@ collect_4194304_T8 traj 4194304 3 8
 collect_4194304_T2 traj 4194304 6 2
 rollout_4194304 full 4194304 6 1
 EOT
-python scripts/pmc_large_reduce.py $O
+python scripts/experiments/pmc_large_reduce.py $O

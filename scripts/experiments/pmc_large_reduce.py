@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs on the GPU box at the end of scripts/pmc_large.sh: every rocprofv3 database DIR/p_results.db under the given directory ->
+"""Runs on the GPU box at the end of scripts/experiments/pmc_large.sh: every rocprofv3 database DIR/p_results.db under the given directory ->
 DIR.counters.csv (per kernel and counter: dispatches, mean per dispatch of the sum over the counter's instances, and -- for
 counters collected per instance -- the mean per dispatch of the smallest and the largest instance), databases deleted."""
 import os

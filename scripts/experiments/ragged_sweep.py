@@ -2,14 +2,14 @@
 """Does a ragged last tile (a batch that is not a multiple of 64 boards) cost more than its share?  Times every batched entry
 point whose launch can wait for one slow tile at N and N + 63 boards (hipGraph replays, us per launch):
     gbl_greedy depth 2 | gbl_step (FULL) | gbl_rollout(1) (FULL) | gbl_legal_mask | gbl_observe | gbl_collect_policy (16 plies)
-  python scripts/ragged_sweep.py"""
+  python scripts/experiments/ragged_sweep.py"""
 import os
 import statistics
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import gobblet_rl_amd as G  # noqa: E402
 
 dev = torch.device("cuda:0")

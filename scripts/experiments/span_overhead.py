@@ -8,7 +8,7 @@ ply index, and how the host waits for the end.  Variants, wall clock around each
     no-advance+poll both
     prebound args   no-advance with the 22 ctypes arguments converted once (nothing: the path is the two event records and the launch)
   SPAN_SPIN=1|2|4 sets hipDeviceScheduleSpin / Yield / BlockingSync first (nothing either: the wait already spins)
-  python scripts/span_overhead.py [BOARDS] [PLIES]"""
+  python scripts/experiments/span_overhead.py [BOARDS] [PLIES]"""
 import os
 import statistics
 import sys
@@ -16,10 +16,10 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import importlib.util  # noqa: E402
 
-spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "bench.py"))
 B = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(B)
 import gobblet_rl_amd as G  # noqa: E402

@@ -12,7 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    if os.environ.get("GOBBLET_HIP_LIB"):  # scripts/ab_sweep.sh: the suite against an experiment's own build of the library
+    if os.environ.get("GOBBLET_HIP_LIB"):  # scripts/experiments/ab_sweep.sh: the suite against an experiment's own build of the library
         import gobblet_rl_amd as G
         G._native.use_library(os.environ["GOBBLET_HIP_LIB"])
 

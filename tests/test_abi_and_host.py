@@ -68,7 +68,7 @@ def test_no_kernel_uses_scratch():
 def test_layout_info_and_host_side_argument_errors():
     L = nat.lib()
     info = (C.c_int32 * 6)()
-    assert L.gbl_layout_info(info) == 0 and list(info) == [1, 27, 54, 117, 64, 16]
+    assert L.gbl_layout_info(info) == 0 and list(info) == [2, 27, 54, 117, 64, 16]
     assert L.gbl_layout_info(None) == nat.ERR_ARG and b"NULL" in L.gbl_last_error()
     # n == 0 is a no-op, n < 0 and NULL pointers are argument errors -- all decided before any HIP call
     assert L.gbl_winner(None, None, 0, None) == 0
@@ -115,7 +115,7 @@ def test_host_flavour_header_symbols_all_exported():
         b = re.search(r"^(?:const char \*|int )" + name + r"\(([^;]*)\);", hdr, re.M).group(1)
         assert re.sub(r"\s+", " ", a) == re.sub(r"\s+", " ", b), name
     info = (C.c_int32 * 6)()
-    assert L.gbl_cpu_layout_info(info) == 0 and list(info)[:5] == [1, 27, 54, 117, 64]
+    assert L.gbl_cpu_layout_info(info) == 0 and list(info)[:5] == [2, 27, 54, 117, 64]
     assert L.gbl_cpu_winner(None, None, -1, None) == nat.ERR_ARG and L.gbl_cpu_winner(None, None, 0, None) == 0
     assert L.gbl_cpu_step(16, 16, 16, 16, None, None, None, None, None, 5, 7, 0, None) == nat.ERR_ARG and b"illegal_mode" in L.gbl_cpu_last_error()
 

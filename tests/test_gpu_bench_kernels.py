@@ -134,7 +134,7 @@ def test_collect_one_wavefront_kernel_vs_oracle(G, n, with_obs, layout, illegal,
     tiles); MASK_ONLY: k_collect3's playing + mask-row wavefronts up to 3 * 2^20 boards, k_collect beyond -- both layouts, both
     illegal modes, ply index by value and on the device; ragged last tiles at 163 841 and 3 145 729 boards."""
     variant = G._native.lib().gbl_collect_variant(n, 4, 1, int(with_obs))
-    assert variant == (0 if with_obs or n > 3 * (1 << 20) else 3)
+    assert variant == (0 if with_obs or n > 3 * (1 << 20) else 4)   # (4 = GBL_COLLECT_TRIO)
     T, seed, base, warm = 4, 17, 5_000_000_000, 9
     env, s, tm, dn = warm_pair(G, n, seed, base, warm, with_observation=with_obs, illegal_mode=illegal)
     if device_ply:
@@ -314,7 +314,7 @@ def test_small_batch_collect_vs_oracle(G, n, with_obs):
     directly against the oracle, FULL and MASK_ONLY, time- and tile-major slots, both illegal modes, ply index by value and on
     the device, tallies and turn counters; ragged last sub-tiles and whole ones of every form."""
     variant = G._native.lib().gbl_collect_variant(n, 7, 1, int(with_obs))
-    assert (variant >= 1000) if n <= 8192 else variant == 3  # GBL_COLLECT_ROLES(...) up to 8 192 boards, k_collect3 beyond
+    assert (variant >= 1000) if n <= 8192 else variant == 4  # GBL_COLLECT_ROLES(...) up to 8 192 boards, k_collect3 beyond
     small_batch_case(G, n, with_obs)
 
 
@@ -324,7 +324,7 @@ def test_trio_collect_vs_oracle(G, n, with_obs):
     """gbl_collect where k_collect3 runs (one playing wavefront per tile hands every ply's position to a mask-row and an
     observation-row wavefront: GBL_COLLECT_TRIO), against the oracle as above; ragged last tiles (1 and 63 rows) and whole ones."""
     variant = G._native.lib().gbl_collect_variant(n, 7, 1, int(with_obs))
-    assert variant == (3 if (n <= 45056 or not with_obs) else 2)  # (FULL beyond 45 056 boards: k_collect2, covered here too)
+    assert variant == (4 if (n <= 45056 or not with_obs) else 2)  # (FULL beyond 45 056 boards: k_collect2, covered here too)
     small_batch_case(G, n, with_obs)
 
 

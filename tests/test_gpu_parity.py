@@ -1298,8 +1298,33 @@ def test_placement_probe_and_spread_buffers(G):
     assert small.collect(4) is not fresh and small.collect(4, out="fresh") is not fresh and torch.equal(fresh["actions"], kept)
     with pytest.raises(ValueError):
         small.collect(4, out="new")
+    # reset() KEEPS the staging sets (a captured graph may hold their addresses, and a reset-then-collect loop must not
+    # search for a placement every episode); a set that is used while a stream is capturing is pinned against the LRU eviction
+    again = small.collect(4)
     small.reset()
-    assert not small._staging
+    assert small._staging and small.collect(4) is again
+    pinned_env = G.BatchedGobblet(64, DEV, auto_reset=True)
+    pinned_env.device_ply()
+    held = pinned_env.collect(3, refresh=False)          # made (and kept) outside the capture ...
+    side2 = torch.cuda.Stream()
+    side2.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side2):
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+            assert pinned_env.collect(3, refresh=False) is held   # ... used inside it: the graph replays into these addresses
+            pinned_env.advance_ply()
+    torch.cuda.current_stream().wait_stream(side2)
+    assert held.get("_pinned") is True
+    ptr = held["_full"]["observation"].data_ptr()
+    for T_other in (4, 5, 6, 7):
+        pinned_env.collect(T_other, refresh=False)       # four more shapes: the LRU evicts among the loose sets only
+    pinned_env.reset()
+    assert pinned_env.collect(3, refresh=False) is held and held["_full"]["observation"].data_ptr() == ptr
+    assert len([v for v in pinned_env._staging.values() if not v.get("_pinned")]) <= pinned_env.STAGING_SETS
+    g2.replay()
+    torch.cuda.synchronize()
+    pinned_env.release_staging()
+    assert not pinned_env._staging
     # place(): buffers made WITHOUT the search are probed, or re-homed, afterwards; their contents survive either
     e4 = G.BatchedGobblet(n, DEV, **kw)
     mine = e4.trajectory_buffers(T, placement="any")
