@@ -245,7 +245,7 @@ def auto_traj(boards, steps, requested=0, no_obs=False):
 def kernel_source_hash():
     """Identifies the kernel sources a committed profile was taken from (profiles/pmc_traffic.json records it)."""
     h = hashlib.sha256()
-    for f in ("gobblet_hip.hip", "gobblet_device.h"):
+    for f in ("gobblet_hip.hip", "gobblet_device.h", "gobblet_knobs.h"):
         h.update(open(os.path.join(ROOT, "gobblet-rl_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

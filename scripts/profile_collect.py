@@ -30,7 +30,7 @@ def capture(fn, *a):
 
 def kernel_source_hash():
     h = hashlib.sha256()
-    for f in ("gobblet_hip.hip", "gobblet_device.h"):
+    for f in ("gobblet_hip.hip", "gobblet_device.h", "gobblet_knobs.h"):
         h.update(open(os.path.join(ROOT, "gobblet-rl_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -68,7 +68,7 @@ def main():
     dst = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(dst, exist_ok=True)
     khash = kernel_source_hash()
-    for name in ("bench_default", "bench_driver_cmd", "bench_single_ply", "bench_stepmode", "bench_maskonly",
+    for name in ("bench_default", "bench_driver_cmd", "bench_single_ply", "bench_stepmode", "bench_step_two_launch", "bench_maskonly",
                  "bench_c4_shard_131072", "greedy_65536", "greedy_1048576", "greedy_policy", "playouts"):
         if not os.path.exists(os.path.join(SRC, name + ".json")):  # (a trimmed round: scripts/profile_round.sh r5a / r5b)
             continue
@@ -78,7 +78,7 @@ def main():
     for name in ("facade.txt", "valu_rates.txt", "winner_lanes.txt", "write_classes.txt", "placement_probe_check.txt",
                  "placement_ab.txt", "soak_parity.txt", "wave_placement.txt", "valu_mix.txt", "reply_rate.txt",
                  "greedy_wave_stamps.txt", "icache_cold.txt", "flag_sync.txt", "policy_wave_stamps.txt", "role_phase_stamps.txt",
-                 "greedy_floor.txt"):
+                 "greedy_floor.txt", "quad_split.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
     # instruction-cache counters of k_greedy at 65 536 and 2^20 boards: the kernel's rows only
@@ -120,7 +120,8 @@ def main():
             "fused_131072": ("fused:131072", "k_rollout<true, true"), "fused_4096": ("fused:4096", "k_rollout<true, true"),
             "fused_4194304": ("fused:4194304", "k_rollout<true, true"),
             "fused_noobs_1048576": ("fused-noobs:1048576", "k_rollout<true, false"),
-            "step_1048576": ("step:1048576", "k_step<true, true")}
+            "step_1048576": ("step:1048576", "k_step<true, true"), "step_131072": ("step:131072", "k_step<true, true"),
+            "step2_1048576": ("step2:1048576", "k_step<true, true")}
     for run, (key, kernel) in runs.items():
         if not os.path.exists(os.path.join(SRC, f"pmc_{run}_FETCH_SIZE.counters.csv")):
             continue

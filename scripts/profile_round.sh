@@ -15,6 +15,7 @@ for m in valu_rates valu_mix icache_cold winner_lanes write_classes wave_placeme
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scripts/microbench/$m scripts/microbench/$m.hip >> $O/build_$STAGE.log 2>&1   # always rebuilt: a stale binary must never publish numbers
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gobblet-rl_amd/csrc -o scripts/microbench/reply_rate scripts/microbench/reply_rate.hip >> $O/build_$STAGE.log 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -I gobblet-rl_amd/csrc -o scripts/microbench/quad_split scripts/microbench/quad_split.hip >> $O/build_$STAGE.log 2>&1
 [ "$STAGE" = b ] || scripts/build_variant.sh stamps -DGBL_STAMPS -DGBL_AB_COLLECT_CFG >> $O/build_$STAGE.log 2>&1   # (diagnostic build for the phase stamps)
 bench_lines() {
 # stdout of bench.py is the compact contract line; the full record (sub-records, per-rank lists) goes to --configs-out
@@ -22,6 +23,7 @@ python bench.py --configs-out $O/bench_default_full.json > $O/bench_default.json
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --configs-out $O/bench_driver_cmd_full.json > $O/bench_driver_cmd.json   # the driver's exact command
 python bench.py --mode fused --no-configs --no-cpu-baseline --configs-out $O/bench_single_ply_full.json > $O/bench_single_ply.json
 python bench.py --mode step --no-configs --no-cpu-baseline --configs-out $O/bench_stepmode_full.json > $O/bench_stepmode.json
+python bench.py --mode step2 --no-configs --no-cpu-baseline --configs-out $O/bench_step_two_launch_full.json > $O/bench_step_two_launch.json
 python bench.py --no-obs --no-configs --no-cpu-baseline --configs-out $O/bench_maskonly_full.json > $O/bench_maskonly.json
 python bench.py --boards 131072 --no-configs --no-cpu-baseline --configs-out $O/bench_c4_shard_131072_full.json > $O/bench_c4_shard_131072.json
 }
@@ -49,6 +51,7 @@ GOBBLET_HIP_LIB=build/lib_stamps.so python scripts/microbench/greedy_wave_stamps
 GOBBLET_HIP_LIB=build/lib_stamps.so python scripts/microbench/policy_wave_stamps.py 2> /dev/null > $O/policy_wave_stamps.txt || true
 for c in 220 120; do AB_LIB=build/lib_stamps.so python scripts/microbench/role_phase_stamps.py 4096 $c; done 2> /dev/null > $O/role_phase_stamps.txt || true
 scripts/microbench/winner_lanes > $O/winner_lanes.txt
+scripts/microbench/quad_split > $O/quad_split.txt
 timeout -k 5 60 scripts/microbench/flag_sync > $O/flag_sync.txt
 scripts/microbench/dpp_scan >> $O/flag_sync.txt
 scripts/microbench/wave_placement 1024 28672 > $O/wave_placement.txt
@@ -114,6 +117,8 @@ fused_4096 full 4096 20 1
 fused_4194304 full 4194304 10 1
 fused_noobs_1048576 mask 1048576 20 1
 step_1048576 step 1048576 12 1
+step_131072 step 131072 20 1
+step2_1048576 step2 1048576 12 1
 EOT
 while read name mode boards launches T; do
   for c in FETCH_SIZE WRITE_SIZE; do

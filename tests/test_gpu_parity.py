@@ -1075,9 +1075,11 @@ def test_bench_script_runs_and_reports(G):
         assert d["steps"] == 20 and d["n_gpus"] == 1 and d["config"]["total_boards"] == 16384 and d["scaling"] == "strong"
         assert all(not isinstance(v, (list, dict)) for v in d["config"].values())     # a workload string + scalars
         r = d["roofline"]
-        assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
+        # (the compact line carries six significant digits of everything but `value` / `ms_per_step`)
+        assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-5
         assert abs(d["value"] - 16384 * 20 / (d["ms_per_step"] * 20 / 1e3)) / d["value"] < 1e-6
-        assert full["value"] == d["value"] and full["roofline"]["frac"] == r["frac"]
+        assert full["value"] == d["value"] and abs(full["roofline"]["frac"] - r["frac"]) < 1e-5
+        assert r["algorithmic_bytes_survey"] in (234, 117) and r["frac_on_survey_bytes"] >= r["frac"] - 1e-5 and r["accounting"]
     # the RCCL path of an N > 1 run -- process group on the device, barriers around the timed region, MAX-reduce of the elapsed
     # time, all-gather of the per-rank numbers -- rehearsed at world size 1 (an 8-GPU node is the driver's to launch)
     env = dict(os.environ, GBL_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1",
@@ -1089,7 +1091,8 @@ def test_bench_script_runs_and_reports(G):
     assert d["config"]["rccl_ranks"] == 1 and d["config"]["dist_backend"] == "nccl" and len(full["detail"]["kernel_us_per_rank"]) == 1
     assert d["config"]["span_barrier"] == "node-local shared memory"
     assert full["detail"]["trajectory_placement_per_rank"][0]["probes"]
-    assert d["config"]["kernel_us_max"] == full["detail"]["kernel_us_per_rank"][0] and d["ms_per_step"] >= d["config"]["ms_per_step_own_span"] > 0
+    assert abs(d["config"]["kernel_us_max"] / full["detail"]["kernel_us_per_rank"][0] - 1) < 1e-5
+    assert d["ms_per_step"] >= d["config"]["ms_per_step_own_span"] * (1 - 1e-5) > 0
 
 
 def test_bench_driver_command_prints_a_compact_line(G):
@@ -1146,7 +1149,7 @@ def test_bench_script_two_ranks_rehearsal(G):
         assert d["config"]["boards_per_gpu"] == 16384 and len(full["detail"]["kernel_us_per_rank"]) == 2
         assert len(full["detail"]["trajectory_placement_per_rank"]) == 2 and d["config"]["dist_backend"] == "gloo"
         assert d["config"]["rccl_ranks"] == 0                   # (gloo rehearsal; under RCCL this is the world size)
-        assert d["config"]["kernel_us_max"] == max(full["detail"]["kernel_us_per_rank"])
+        assert abs(d["config"]["kernel_us_max"] / max(full["detail"]["kernel_us_per_rank"]) - 1) < 1e-5
         assert "configs" not in full and "cpu_baseline" not in d  # N = 1 only
 
 
@@ -1167,7 +1170,7 @@ def test_bench_script_c4_shape_rehearsal(G):
     assert d["roofline"]["kernel"].startswith("k_collect2 (20 plies per launch)"), d["roofline"]["kernel"]
     assert len(full["detail"]["kernel_us_per_rank"]) == ranks and all(u > 0 for u in full["detail"]["kernel_us_per_rank"])
     assert d["config"]["kernel_us_max"] >= d["config"]["kernel_us_min"] > 0
-    assert d["ms_per_step"] >= d["config"]["ms_per_step_own_span"] > 0
+    assert d["ms_per_step"] >= d["config"]["ms_per_step_own_span"] * (1 - 1e-5) > 0
     assert all(pl is not None and pl.get("ratio", 0) > 0 for pl in full["detail"]["trajectory_placement_per_rank"])
 
 
