@@ -76,6 +76,9 @@ def collect_kernel_name(variant):
 # The sub-records of an N = 1 run: name -> (boards, timed plies, MASK_ONLY, mode).  tests/test_gpu_bench_kernels.py compares
 # the kernel instantiation each one times with the oracle, at the same batch size and through the same entry point.
 CONFIG_RECORDS = {
+    # BASELINE.md's own recipe for the headline -- 64 warm-up plies (the run's W), >= 1 000 timed plies, 8 plies per launch as one
+    # hipGraph -- whatever --steps the caller asked for: the driver's command times ONE 20-ply launch, this record rides in its line
+    "headline_recipe_1048576": (1 << 20, 1000, False, "collect"),
     # (the latency-bound sizes replay 2 048 / 1 024 plies: a graph's first launch costs ~10 us, 5 % of a 256-ply replay at 4 096 boards
     #  -- profiles/r05/burst_length.txt: 0.737 us per ply at 256 plies per replay, 0.703 at 2 048, 0.687 at 16 384)
     "c2_4096": (4096, 2048, False, "collect"), "c_16384": (16384, 1024, False, "collect"), "c_32768": (32768, 1024, False, "collect"),
@@ -735,7 +738,7 @@ ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffi
 # The sub-records every driver-parsed line carries as [value, us per step, fraction of the bound's peak]: the
 # other BASELINE configs (C2, C3, C4's shard, C5), the SURVEY-8(d)-clean one-ply kernel (234 B per env-step) and the externally
 # stepped pipeline.  The full records stay in the configs file.
-COMPACT_CONFIGS = ("c2_4096", "c3_262144", "c4_shard_131072", "c5_greedy_65536", "single_ply_1048576", "step_pipeline_1048576",
+COMPACT_CONFIGS = ("headline_recipe_1048576", "c2_4096", "c3_262144", "c4_shard_131072", "c5_greedy_65536", "single_ply_1048576", "step_pipeline_1048576",
                    "step_pipeline_131072", "greedy_collect_65536", "maskonly_1048576")
 
 
@@ -1090,8 +1093,8 @@ def main():
         if world == 1 and not args.no_configs:
             cfg = {}
             for name, (n, k, noobs, mode) in CONFIG_RECORDS.items():
-                cfg[name] = short_run(G, torch, dev, n, k, W, no_obs=noobs, mode=mode, traj=auto_traj(n, k, no_obs=noobs),
-                                      placement=args.placement)
+                cfg[name] = short_run(G, torch, dev, n, k, max(W, 64) if name == "headline_recipe_1048576" else W, no_obs=noobs,
+                                      mode=mode, traj=auto_traj(n, k, no_obs=noobs), placement=args.placement)
             # an external policy's ply + the masked-random reply in one launch, at the C3 / C4-shard sizes (against single_ply_*)
             for n in (131072, 262144):
                 cfg[f"step_reply_{n}"] = step_reply_run(G, torch, dev, n, 200, W)

@@ -86,8 +86,26 @@ int main(int argc, char **argv)
         GBL_OK_(gbl_step(state, to_move, done, actions, winner, reward, mask, obs, nullptr, n, GBL_ILLEGAL_NOOP,
                          /*auto_reset*/ 1, s));
     }
-    GBL_OK_(gbl_rollout(state, to_move, done, actions, winner, reward, mask, obs, n, 0, 0, plies, plies,  // the same,
-                        GBL_ILLEGAL_NOOP, counters, nullptr, s));                                       // fused, counted
+    // ... the same in ONE launch per ply (gbl_step_ex, ABI version 2): the step draws the next mover's action from the mask it stores,
+    // over the action array itself, and flags what became of every action -- here a garbage index on board 0 first
+    int8_t *status;
+    HIP_OK(hipMalloc(&status, n));
+    GBL_OK_(gbl_sample(mask, actions, n, 0, 0, plies, s));
+    const int32_t garbage = 1000;
+    HIP_OK(hipMemcpyAsync(actions, &garbage, 4, hipMemcpyHostToDevice, s));
+    for (uint32_t t = plies; t < plies + 4; ++t)
+        GBL_OK_(gbl_step_ex(state, to_move, done, actions, winner, reward, mask, obs, nullptr, nullptr, nullptr, nullptr,
+                            t == plies ? status : nullptr, /*next_actions_out = */ actions, 0, 0, t + 1, nullptr, n,
+                            GBL_ILLEGAL_NOOP, 1, s));
+    int8_t status0 = -1;
+    HIP_OK(hipMemcpyAsync(&status0, status, 1, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    if (status0 != (GBL_STATUS_ILLEGAL | GBL_STATUS_OUT_OF_RANGE)) { fprintf(stderr, "status byte of a garbage index: %d\n", status0); return 8; }
+    int32_t info[6];
+    GBL_OK_(gbl_layout_info(info));
+    if (info[0] != GBL_ABI_VERSION) return 9;
+    GBL_OK_(gbl_rollout(state, to_move, done, actions, winner, reward, mask, obs, n, 0, 0, plies + 4, plies,  // the same,
+                        GBL_ILLEGAL_NOOP, counters, nullptr, s));                                           // fused, counted
     HIP_OK(hipStreamSynchronize(s));
 
     std::vector<int64_t> c(GBL_COUNTER_STRIPES * GBL_COUNTER_STRIDE);
@@ -110,7 +128,7 @@ int main(int argc, char **argv)
     const double ratio = place_pair(T * slot * GBL_OBS_BYTES, T * slot * GBL_ACTIONS, slot, (int)T, &obs_traj, &mask_traj, s);
     if (ratio < 0) { fprintf(stderr, "placement: not enough free device memory\n"); return 6; }
     GBL_OK_(gbl_collect(state, to_move, done, act_traj, nullptr, nullptr, nullptr, nullptr, (int8_t *)mask_traj, (int8_t *)obs_traj, n,
-                        slot, 64, 0, 0, 2 * plies, nullptr, T, GBL_ILLEGAL_NOOP, counters, nullptr, s));
+                        slot, 64, 0, 0, 2 * plies + 4, nullptr, T, GBL_ILLEGAL_NOOP, counters, nullptr, s));
     HIP_OK(hipStreamSynchronize(s));
     std::vector<int32_t> a0(T * slot);
     std::vector<int8_t> m0(GBL_ACTIONS * 2);

@@ -52,8 +52,16 @@ while time.time() < t_end:
         a = oracle.batch_sample(m, seed, base, 1000 + k)
         wild = master.random(n) < 0.1
         a = np.where(wild | (a < 0), master.integers(-2, 57, n), a).astype(np.int32)
+        exp_status = oracle.batch_action_status(s, tm, dn, a, auto_reset=auto)   # (of the position before the step)
         oo = oracle.batch_step(s, tm, dn, a, illegal_mode=0 if illegal == "noop" else 1, auto_reset=auto, threads=8)
-        obs, rew, done, win = env.step(t(a))
+        if k == 1:   # gbl_step_ex: the status byte of every action and the next mover's draw from the mask this launch stores
+            st8, nxt = torch.full((n,), 9, dtype=torch.int8, device=DEV), torch.full((n,), 9, dtype=torch.int32, device=DEV)
+            ply_next = env.ply + 1
+            obs, rew, done, win = env.step(t(a), status=st8, next_actions=nxt)
+            assert np.array_equal(st8.cpu().numpy(), exp_status)
+            assert np.array_equal(nxt.cpu().numpy(), oracle.batch_sample(oo["mask"], seed, base, ply_next))
+        else:
+            obs, rew, done, win = env.step(t(a))
         assert np.array_equal(env.squares.cpu().numpy(), s) and np.array_equal(done.cpu().numpy(), dn)
         assert np.array_equal(obs["action_mask"].cpu().numpy(), oo["mask"]) and np.array_equal(win.cpu().numpy(), oo["winner"])
         assert np.array_equal(rew.cpu().numpy(), oo["reward"])

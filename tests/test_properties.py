@@ -81,3 +81,46 @@ def test_greedy_matches_oracle(data):
         o = oracle.batch_greedy(sq, tm, depth=depth)
         for x, y in zip(e, o):
             assert np.array_equal(x, y)
+
+
+@settings(max_examples=25, **RELAXED)
+@given(valid_boards(), st.sampled_from(["noop", "terminate"]), st.booleans(), st.integers(0, 2 ** 40), st.integers(0, 1000))
+def test_step_ex_status_and_fused_draw(data, illegal_mode, auto_reset, seed, ply):
+    """gbl_step_ex (host flavour: the device header's own lane functions) on ARBITRARY contract boards: the status byte is 0 exactly
+    for actions inside the mover's legal mask, carries bit 1 exactly for indices outside [0, 54), is 0 on frozen boards whatever the
+    action; the fused draw is gbl_sample's rule on the mask the step stores (-1 where nobody is to move)."""
+    import torch
+
+    import gobblet_rl_amd as G
+    sq, tm, rng = data
+    n = len(sq)
+    dn = (oracle.batch_winner(sq) != 0).astype(np.int8) if not auto_reset else np.zeros(n, np.int8)
+    a = rng.integers(-3, 58, n).astype(np.int32)
+    legal_before = oracle.batch_legal_mask(sq, tm)
+    env = G.BatchedGobblet(n, "cpu", illegal_mode=illegal_mode, auto_reset=auto_reset, seed=seed)
+    env.board.squares = torch.from_numpy(sq.copy()); env.to_move.copy_(torch.from_numpy(tm)); env.done.copy_(torch.from_numpy(dn))
+    env.refresh()
+    env.ply = ply
+    status = torch.full((n,), 9, dtype=torch.int8)
+    nxt = torch.full((n,), 9, dtype=torch.int32)
+    acts = torch.from_numpy(a.copy())
+    exp_status = oracle.batch_action_status(sq, tm, dn, a, auto_reset=auto_reset)
+    obs, rew, done, win = env.step(acts, status=status, next_actions=nxt)
+    st8 = status.numpy()
+    assert np.array_equal(st8, exp_status)
+    frozen = (dn != 0) & (not auto_reset)
+    in_range = (a >= 0) & (a < 54)
+    legal = in_range & (legal_before[np.arange(n), np.clip(a, 0, 53)] != 0)
+    assert np.array_equal(st8 == 0, legal | frozen) and np.array_equal((st8 & 2) != 0, ~in_range & ~frozen)
+    s1, t1, d1 = sq.copy(), tm.copy(), dn.copy()
+    o = oracle.batch_step(s1, t1, d1, a, illegal_mode=0 if illegal_mode == "noop" else 1, auto_reset=auto_reset)
+    assert np.array_equal(env.squares.numpy(), s1) and np.array_equal(obs["action_mask"].numpy(), o["mask"])
+    exp_next = oracle.batch_sample(o["mask"], seed, 0, ply + 1)
+    assert np.array_equal(nxt.numpy(), exp_next) and ((exp_next == -1) == (o["mask"].sum(1) == 0)).all()
+    # the draw over the action array itself: same result
+    env2 = G.BatchedGobblet(n, "cpu", illegal_mode=illegal_mode, auto_reset=auto_reset, seed=seed)
+    env2.board.squares = torch.from_numpy(sq.copy()); env2.to_move.copy_(torch.from_numpy(tm)); env2.done.copy_(torch.from_numpy(dn))
+    env2.refresh()
+    env2.ply = ply
+    env2.step(acts, next_actions=acts)
+    assert np.array_equal(acts.numpy(), exp_next)
