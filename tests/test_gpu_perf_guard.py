@@ -5,11 +5,11 @@ than that.  Parity is not checked here: tests/test_gpu_bench_kernels.py compares
 
     record (bench.py)          kernel                                  measured r05/r06       ceiling
     headline 2^20 x 8 plies    k_collect<mask, obs>                    27.1-27.4 us per ply   29.5 (placed) / 36 (unplaced)
-    c2_4096                    k_collect_small<2 lanes, 2 obs waves>   0.52-0.55              0.60
-    c4_shard_131072            k_collect2                              3.3-3.5                3.9
+    c2_4096                    k_collect_small<2 lanes, 2 obs waves>   0.52-0.55              0.62
+    c4_shard_131072            k_collect2                              3.3-3.6                4.1 (placed) / 5.0 (unplaced)
     single_ply_1048576         k_rollout (234 B per env-step)          35.8-36.3              38.0
     step_pipeline_1048576      k_step<EXT> (next draw fused)           see STEP_CEILING       --
-    c5_greedy_65536            k_greedy<4,16>                          11.4-11.8              12.5
+    c5_greedy_65536            k_greedy<4,16>                          11.3-11.8              12.8
 """
 import os
 import statistics
@@ -43,26 +43,32 @@ def median_us(bench, G, dev, boards, plies, mode, passes=3, **kw):
     return statistics.median(r["us_per_step"] for r in recs), recs[-1]
 
 
+def placed(rec):
+    """Did the record's trajectory arrays end up in different memory classes of HBM?  Arrays too small to probe count
+    as placed (they live in the Infinity Cache); a search that found nothing costs a write-bound record ~20 %: its ceiling moves."""
+    pl = rec.get("trajectory_placement") or {}
+    return pl.get("ratio", 0.0) <= 0.86
+
+
 def test_headline_collect_kernel(env):
     bench, G, dev = env
     # placement "auto" with the far candidates bench.py itself allows (Pipeline: far=True): the record says whether it was found
     us, rec = median_us(bench, G, dev, 1 << 20, 64, "collect", passes=2)
-    placed = (rec.get("trajectory_placement") or {}).get("ratio", 1.0) <= 0.86
     assert rec["roofline"]["kernel"].startswith("k_collect (8 plies per launch)")
-    assert us <= (29.5 if placed else 36.0), (us, rec.get("trajectory_placement"))
+    assert us <= (29.5 if placed(rec) else 36.0), (us, rec.get("trajectory_placement"))
     assert rec["roofline"]["frac_on_survey_bytes"] > rec["roofline"]["frac"]       # (both accountings are in every record)
 
 
 def test_c2_small_batch(env):
     bench, G, dev = env
     us, rec = median_us(bench, G, dev, 4096, 2048, "collect")
-    assert "k_collect_small" in rec["roofline"]["kernel"] and us <= 0.60, us
+    assert "k_collect_small" in rec["roofline"]["kernel"] and us <= 0.62, us
 
 
 def test_c4_shard(env):
     bench, G, dev = env
     us, rec = median_us(bench, G, dev, 131072, 256, "collect")
-    assert rec["roofline"]["kernel"].startswith("k_collect2") and us <= 3.9, us
+    assert rec["roofline"]["kernel"].startswith("k_collect2") and us <= (4.1 if placed(rec) else 5.0), (us, rec.get("trajectory_placement"))
 
 
 def test_single_ply_kernel_on_survey_bytes(env):
@@ -82,4 +88,4 @@ def test_step_pipeline_one_launch_per_ply(env):
 def test_greedy_config5(env):
     bench, G, dev = env
     us = statistics.median(bench.greedy_run(G, torch, dev)["us_per_step"] for _ in range(3))
-    assert us <= 12.5, us
+    assert us <= 12.8, us
