@@ -1125,6 +1125,16 @@ def test_bench_driver_command_prints_a_compact_line(G):
     full = json.load(open(os.path.join(root, d["config"]["configs_file"])))
     assert set(full["configs"]) == set(bench.CONFIG_RECORDS) | set(bench.EXTRA_RECORDS)
     assert d["config"]["configs_recorded"] == len(full["configs"]) and full["value"] == d["value"]
+    # every BASELINE config, both byte accountings and the predicted scaling curve ride in the parsed line
+    cc = d["configs_compact"]
+    for name in ("headline_recipe_1048576", "c2_4096", "c3_262144", "c4_shard_131072", "c5_greedy_65536", "single_ply_1048576",
+                 "step_pipeline_1048576"):
+        v, us, frac = cc[name]
+        assert v > 1e9 and us > 0 and (frac is None or 0.02 < frac < 1.0), (name, cc[name])
+        assert abs(v / full["configs"][name]["value"] - 1) < 1e-3
+    assert r["algorithmic_bytes_survey"] == 234 and r["frac_on_survey_bytes"] > r["frac"] and len(r["accounting"]) <= 128
+    sp = d["scale_prediction"]
+    assert set(sp) == {"2", "4", "8"} and all(0.3 < sp[k][1] < 1.15 for k in sp) and sp["8"][0] > d["value"]
     assert all("roofline" in rec and rec["value"] > 0 for rec in full["configs"].values())
     # N = 1 under a launcher: same workload string, same kernel
     lines, _, _ = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-configs", "--no-cpu-baseline"], launcher_ranks=1)
@@ -1167,6 +1177,9 @@ def test_bench_script_c4_shape_rehearsal(G):
     d = json.loads(lines[0])
     assert d["n_gpus"] == ranks and d["config"]["boards_per_gpu"] == 131072 and d["config"]["plies_per_launch"] == 20
     assert d["config"]["span_barrier"] == "node-local shared memory" and d["config"]["launch"] == "eager launches"
+    assert d["config"]["rccl_ranks"] == 0 and d["config"]["dist_backend"] == "gloo"   # (a gloo rehearsal; under RCCL: the world size)
+    assert d["config"]["value_contract_span"] <= d["config"]["value_own_span"] * (1 + 1e-5)   # (the barrier only adds to the span)
+    assert "scale_prediction" not in d and "configs_compact" not in d                 # (N = 1 only)
     assert d["roofline"]["kernel"].startswith("k_collect2 (20 plies per launch)"), d["roofline"]["kernel"]
     assert len(full["detail"]["kernel_us_per_rank"]) == ranks and all(u > 0 for u in full["detail"]["kernel_us_per_rank"])
     assert d["config"]["kernel_us_max"] >= d["config"]["kernel_us_min"] > 0
