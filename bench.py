@@ -63,7 +63,7 @@ ALGO_BYTES_COLLECT_PLY, ALGO_BYTES_COLLECT_PLY_MASK_ONLY, ALGO_BYTES_COLLECT_LAU
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; max shader clock (MI355X_MICROARCH.md)
 TOTAL_BOARDS = 1 << 20
-COLLECT_KERNELS = {0: "k_collect", 1: "k_collect (plain stores)", 2: "k_collect2", 4: "k_collect3"}  # gbl_collect_variant()
+COLLECT_KERNELS = {0: "k_collect", 1: "k_collect (plain stores)", 2: "k_collect2", 4: "k_collect3", 5: "k_collect5"}  # gbl_collect_variant()
 
 
 def collect_kernel_name(variant):

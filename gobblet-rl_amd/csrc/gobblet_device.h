@@ -705,6 +705,28 @@ __device__ __forceinline__ void apply_move(Planes &p, uint32_t (&r)[7], int move
     RegRow{r}.apply(move_planes(p, mover, a));
 }
 
+// The 27 state bytes of a board from its planes (the inverse of make_planes on contract states: a level-k cell holds 0 or
+// +-(2k+1), +-(2k+2)): a kernel that plays many plies on the planes alone writes the state back ONCE, from here, instead of
+// patching a byte row every ply (k_collect5).  r[6]'s top byte is 0.
+__device__ __forceinline__ void planes_to_row(const Planes &p, uint32_t (&r)[7])
+{
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = 4 * j + u;
+            if (c < kCells) {
+                const int k = c / 9;
+                const uint32_t nz = (p.nz >> c) & 1u, ng = (p.neg >> c) & nz, od = (p.odd >> c) & nz;
+                const uint32_t v = nz * (uint32_t)(2 * k + 2) - od;   // 2k+2, or 2k+1 where the piece number is odd; 0 where empty
+                w |= (ng ? (0u - v) & 0xFFu : v) << (8 * u);
+            }
+        }
+        r[j] = w;
+    }
+}
+
 // ---- row encoders ----------------------------------------------------------------------
 // 54 mask bits -> 54 bytes of 0/1 (14 dwords; bytes 54,55 are zero)
 __device__ __forceinline__ void mask_row(uint64_t m, uint32_t (&d)[14])

@@ -103,11 +103,17 @@ inline int small_cfg(int64_t n, bool with_mask, bool with_obs)
     // MASK_ONLY is bound by what ONE wavefront issues, so the player + mask-row pair of k_collect3 keeps paying far
     // into the HBM regime: 163 840 boards 1.79 against k_collect's 2.19 us per ply, 2^20: 10.39 against 10.93, 2^21: 19.9 against
     // 20.7; 2^22: 45.1 against 44.5 (profiles/r05/ab_roles_long_launches.txt)
-    if (!with_obs) return n <= 8192 ? 210 : n <= 3 * (int64_t)(1 << 20) ? 3 : 0;
+    // (round 6: k_collect5 -- 32-board groups behind a hand-over ring, cfg 6 -- wherever its wavefronts find a SIMD each: MASK_ONLY 4 096 /
+    //  8 192 boards 0.418 / 0.419 us per ply against the role kernel's 0.546 / 0.548, 16 384 ... 32 768: 0.50-0.55 against k_collect3's
+    //  0.58-0.65, 49 152: 0.81 against 0.73; it needs the mask rows' wavefront: profiles/r06/ab_group32.txt)
+    if (!with_obs) return n <= 32768 && with_mask ? 6 : n <= 8192 ? 210 : n <= 3 * (int64_t)(1 << 20) ? 3 : 0;
     // (with the trajectory arrays placed across HBM's memory classes: 40 960 boards k_collect3 1.31 against k_collect2's 1.40 us per
     //  ply, 49 152: 1.49 against 1.41 -- profiles/r05/placed_forms.txt)
     // (late round 5: with its scalars stored by the first row wavefront k_collect3 runs 0.634 us per ply at 8 192 ... 16 384 boards,
     //  256 plies per launch -- <1,2>: 0.643 at 12 288, 0.72 at 16 384; <2,2>: 0.558 at 8 192: profiles/r05/ab_trio_scalars.txt)
+    // (round 6: FULL 4 096 / 8 192 boards k_collect5 0.440 / 0.439 us per ply against the role kernel's 0.525 / 0.527, 9 216: 0.59 against
+    //  k_collect3's 0.63, 10 240: a tie -- from 257 groups on two of them share a CU)
+    if (with_mask && n <= 9216) return 6;
     return n <= 8192 ? 220 : n <= 45056 ? 3 : 0;
 }
 
@@ -119,6 +125,7 @@ inline int collect_variant(int64_t n, uint32_t plies, bool with_mask, bool with_
                                                     : (n + kTile - 1) / kTile <= kCollect2MaxTiles && nt && (with_mask || with_obs);
     const int cfg = nt ? small_cfg(n, with_mask, with_obs) : 0;
     if (cfg == 3) return (with_mask || with_obs) ? GBL_COLLECT_TRIO : GBL_COLLECT_STREAM;
+    if (cfg == 6) return with_mask ? GBL_COLLECT_GROUP32 : with_obs ? GBL_COLLECT_TRIO : GBL_COLLECT_STREAM;  // k_collect5 (needs the mask rows' wavefront)
     return cfg ? GBL_COLLECT_ROLES(cfg / 100, (cfg / 10) % 10, cfg % 10) : pair ? GBL_COLLECT_PAIR : nt ? GBL_COLLECT_STREAM : GBL_COLLECT_CACHED;
 }
 
@@ -1354,6 +1361,222 @@ __global__ __launch_bounds__((64 * small_waves<WITH_MASK, WITH_OBS, KO, MERGE>()
                                        group * KO + (wave - NA));
 }
 
+// gbl_collect for batches that do not fill the chip, round 6: the role kernel's GEOMETRY -- groups of 32 boards, four wavefronts, each
+// alone on a SIMD -- with k_collect3's HAND-OVER instead of redundant chains.  In the role kernel every role wavefront replays the
+// whole game (150 instructions per ply) before it builds its share of the rows; here ONE wavefront plays a group -- two lanes per
+// board, the winner test split over the pair -- and does nothing else: it leaves every ply's position, legal mask, action and results
+// in an LDS ring of 2 x 4 plies and meets the row wavefronts once per four plies.  They take it from there:
+//   wave 1   the mask rows (two lanes per board), the ply's five scalars dealt over the pair, the tallies and turn counters, and the
+//            sampler's generator (one Philox block per board and group of four plies into a four-block ring, three ahead);
+//   wave 2,3 the observation rows of 16 boards each, four lanes per board.
+// The boards live in the player's planes for the whole launch; the 27-byte rows are rebuilt from them once, at the end
+// (planes_to_row: bytes outside the state contract are not preserved).  Bit for bit the trajectories of k_collect.
+constexpr int kGroupBoards = 32, kGroupRing = 4;
+
+template <bool WITH_OBS, bool DEV_PLY>
+__global__ __launch_bounds__(64 * (WITH_OBS ? 4 : 2)) void k_collect5(
+    int8_t *__restrict__ state, int8_t *__restrict__ to_move, int64_t n, int64_t ngroups, uint64_t seed, uint64_t env_base,
+    const uint32_t *__restrict__ ply_dev, uint32_t ply0, uint32_t plies, int8_t *__restrict__ done, int64_t ply_stride,
+    int64_t tile_stride, int32_t *__restrict__ actions_t, int8_t *__restrict__ winner_t, int8_t *__restrict__ reward_t,
+    int8_t *__restrict__ done_t, int8_t *__restrict__ to_move_t, int8_t *__restrict__ mask_t, int8_t *__restrict__ obs_t,
+    int illegal_mode, int64_t *__restrict__ counters, int32_t *__restrict__ turn, const int32_t *__restrict__ first_actions,
+    int8_t *__restrict__ first_status)
+{
+    constexpr int GB = kGroupBoards, OBB = 16;
+    static_assert(kGroupRing == 4, "slot = t & 7, one generator block per group of plies");
+    __shared__ uint32_t s_state[GB * kCells / 4 + 4];
+    __shared__ uint32_t s_mask[GB * kActions / 4 + 4];
+    __shared__ uint32_t s_obs[WITH_OBS ? 2 : 1][WITH_OBS ? OBB * kObs / 4 + 4 : 4];
+    __shared__ uint4 s_hand[2 * kGroupRing][GB];   // per ply slot and board: nz, neg, odd, next mover
+    __shared__ uint4 s_legal[2 * kGroupRing][GB];  // ... the next mover's legal mask (x, y), the action played (z), and in w: winner | r0 << 8 |
+                                                   //     r1 << 16 | done << 24 | next mover << 25 | stepped << 26
+    __shared__ uint4 s_draw[4][GB];                // the sampler's words: block m of board b (plies 4 m ... 4 m + 3) at [m & 3][b]
+    if (DEV_PLY) ply0 += *ply_dev;
+    const int role = wave_index();
+    const int lane = (int)(threadIdx.x & 63u);
+    const int64_t group = (int64_t)blockIdx.x;
+    if (group >= ngroups) return;  // (the same for every wavefront of the workgroup)
+    const int64_t left = n - group * GB;
+    const int rows = left < GB ? (int)left : GB;
+    constexpr int kPolicy = kStoreStreamDrop;
+    const int64_t cell0 = (group >> 1) * tile_stride + (group & 1) * GB;  // the group's first cell of ply 0 (a tile is two groups)
+    const uint32_t m0 = ply0 >> 2;
+    const uint32_t groups_of_plies = (plies + kGroupRing - 1) / kGroupRing;
+    if (role == 1) {
+        // ---- the mask rows, the scalars, the tallies, the turn counters, the generator: two lanes per board ----------------------
+        const int bq = lane >> 1, j = lane & 1;
+        const bool valid = bq < rows;
+        const int64_t b = group * GB + bq;
+        SubVecs<sub_vectors<kActions, GB>()> vm{};
+        int8_t *dst = nullptr, *row_at = mask_t + cell0 * kActions;
+        const int64_t row_step = ply_stride * kActions;
+        const int mbytes = rows * kActions;
+        // the five scalars of a board dealt over its pair (as the role kernel's scalars role): lane 0 action + next mover + winner,
+        // lane 1 reward + done; per-lane array pointers fixed here, no branch on the lane's index inside the loop
+        int32_t *sc_act = nullptr;
+        uint16_t *sc_rw = nullptr;
+        int8_t *sc_b0 = nullptr, *sc_b1 = nullptr;
+        if (valid) {
+            const int64_t at0 = cell0 + bq;
+            if (j == 0 && actions_t) sc_act = actions_t + at0;
+            if (j == 1 && reward_t) sc_rw = reinterpret_cast<uint16_t *>(reward_t) + at0;
+            int8_t *const arr = j == 0 ? to_move_t : done_t;
+            if (arr) sc_b0 = arr + at0;
+            if (j == 0 && winner_t) sc_b1 = winner_t + at0;
+        }
+        int64_t at = 0;
+        uint32_t games = 0, w1 = 0, w2 = 0;
+        int tcount = 0;
+        bool treset = false;
+        auto generate = [&](uint32_t m) {
+            const Draw4 d = draw_block(seed, env_base + (uint64_t)b, m << 2);
+            s_draw[m & 3u][bq] = uint4{d.w[0], d.w[1], d.w[2], d.w[3]};  // (both lanes of a board: the same words)
+        };
+        generate(m0);
+        generate(m0 + 1u);
+        generate(m0 + 2u);
+        pair_barrier();  // setup: the first draws are in LDS
+        for (uint32_t g = 0; g < groups_of_plies; ++g) {
+            pair_barrier();  // plies 4 g ... 4 g + 3 are in slots (g & 1) * 4 ... + 3 (and the player is free to play the next four)
+            // the generator, three blocks ahead of this wavefront's own consumption: block m0 + g + 3 replaces block m0 + g - 1, which
+            // the player (now in plies 4 g + 4 ...: blocks m0 + g + 1, m0 + g + 2) has left behind
+            generate(m0 + g + 3u);
+            const uint32_t t_end = (g + 1u) * kGroupRing < plies ? (g + 1u) * kGroupRing : plies;
+#pragma nounroll
+            for (uint32_t t = g * kGroupRing; t < t_end; ++t) {
+                const uint4 sc = s_legal[t & (2u * kGroupRing - 1u)][bq];
+                {
+                    const uint32_t winner = sc.w & 0xFFu, dn = (sc.w >> 24) & 1u, mv = (sc.w >> 25) & 1u;
+                    if (sc_act) sc_act[at] = (int32_t)sc.z;
+                    if (sc_rw) sc_rw[at] = (uint16_t)((sc.w >> 8) & 0xFFFFu);
+                    if (sc_b0) sc_b0[at] = (int8_t)(j == 0 ? mv : dn);
+                    if (sc_b1) sc_b1[at] = (int8_t)winner;
+                    at += ply_stride;
+                    const bool terminal = dn != 0;
+                    tcount = terminal ? 0 : tcount + (int)((sc.w >> 26) & 1u);  // raw_env.turn: + 1 per step, 0 after a reset (next_turn)
+                    treset = treset || terminal;
+                    if (counters) {  // (one lane per board counts)
+                        const int w = (int)(int8_t)winner;
+                        games += __popcll(__ballot(valid && j == 0 && terminal));
+                        w1 += __popcll(__ballot(valid && j == 0 && w == 1));
+                        w2 += __popcll(__ballot(valid && j == 0 && w == -1));
+                    }
+                }
+                if (t) sub_store<kActions, kPolicy, GB>(dst, vm, lane, mbytes & ~15);  // ply t - 1's rows (a ragged group's: the whole vectors)
+                mask_row_part<2>(reinterpret_cast<uint8_t *>(s_mask) + bq * kActions, ((uint64_t)sc.y << 32) | sc.x, j);
+                wave_lds_fence();
+                dst = row_at;
+                row_at += row_step;
+                sub_fetch<kActions, GB>(s_mask, lane, vm);
+                if (rows != GB) sub_tail(dst, s_mask, lane, mbytes);
+                wave_lds_fence();
+            }
+        }
+        if (plies) sub_store<kActions, kPolicy, GB>(dst, vm, lane, mbytes & ~15);
+        if (valid && j == 0 && turn) turn[b] = treset ? tcount : turn[b] + tcount;
+        if (counters && lane == 0) {
+            unsigned long long *c = reinterpret_cast<unsigned long long *>(counters) +
+                                    (size_t)((group >> 1) % GBL_COUNTER_STRIPES) * GBL_COUNTER_STRIDE;
+            atomicAdd(c + 0, (unsigned long long)rows * plies);
+            if (games) atomicAdd(c + 1, (unsigned long long)games);
+            if (w1) atomicAdd(c + 2, (unsigned long long)w1);
+            if (w2) atomicAdd(c + 3, (unsigned long long)w2);
+        }
+        return;
+    }
+    if (role >= 2) {
+        if constexpr (WITH_OBS) {
+            // ---- the observation rows of 16 boards: four lanes per board -------------------------------------------------------
+            const int ow = role - 2, oq = lane >> 2, oj = lane & 3;
+            const int orows_all = rows - ow * OBB, orows = orows_all < 0 ? 0 : orows_all > OBB ? OBB : orows_all;
+            const int obytes = orows * kObs;
+            uint32_t *const img = s_obs[ow];
+            SubVecs<sub_vectors<kObs, OBB>()> vo{};
+            int8_t *dst = nullptr, *row_at = obs_t + (cell0 + ow * OBB) * kObs;
+            const int64_t row_step = ply_stride * kObs;
+            pair_barrier();  // setup
+            for (uint32_t g = 0; g < groups_of_plies; ++g) {
+                pair_barrier();
+                const uint32_t t_end = (g + 1u) * kGroupRing < plies ? (g + 1u) * kGroupRing : plies;
+#pragma nounroll
+                for (uint32_t t = g * kGroupRing; t < t_end; ++t) {
+                    const uint4 h = s_hand[t & (2u * kGroupRing - 1u)][ow * OBB + oq];
+                    if (t) sub_store<kObs, kPolicy, OBB>(dst, vo, lane, obytes & ~15);
+                    sub_obs_zero<OBB>(img, lane);
+                    wave_lds_fence();
+                    obs_scatter_part<4>(reinterpret_cast<uint8_t *>(img) + oq * kObs, Planes{h.x, h.y, h.z}, (int)h.w, oj);
+                    wave_lds_fence();
+                    dst = row_at;
+                    row_at += row_step;
+                    sub_fetch<kObs, OBB>(img, lane, vo);
+                    if (orows != OBB) sub_tail(dst, img, lane, obytes);
+                    wave_lds_fence();
+                }
+            }
+            if (plies) sub_store<kObs, kPolicy, OBB>(dst, vo, lane, obytes & ~15);
+        }
+        return;
+    }
+    // ---- the playing wavefront: the game and the hand-over, nothing else; two lanes per board -----------------------------------
+    const int bq = lane >> 1, j = lane & 1;
+    const bool valid = bq < rows;
+    const int64_t b = group * GB + bq, bs = valid ? b : n - 1;
+    int mover = to_move[bs];
+    int given = first_actions ? first_actions[bs] : 0;  // (gbl_collect_from, see k_collect)
+    sub_in<kCells, GB>(state + group * (GB * kCells), s_state, lane, rows);
+    wave_lds_fence();
+    uint32_t r[7];
+    row_load<kCells>(s_state, bq, r);
+    r[6] &= 0x00FFFFFFu;
+    mover = valid && mover != 0;
+    Planes p = make_planes(r);
+    p.nz = valid ? p.nz : 0u;
+    int dn = 0;
+    uint64_t legal = legal54(p, mover);
+    if (first_status && valid && j == 0) first_status[b] = (int8_t)action_status_of(legal, given);  // (gbl_collect_from_ex)
+    pair_barrier();  // setup: the first draws are in LDS
+    const uint32_t *const my_draws = reinterpret_cast<const uint32_t *>(&s_draw[0][bq]);  // word w of block m: [(m & 3) * 4 GB + w]
+    uint32_t word = my_draws[(m0 & 3u) * (GB * 4) + (ply0 & 3u)];
+    for (uint32_t t = 0; t < plies; ++t) {
+        int action = pick54(legal, word);
+        {  // the next ply's word (its block was generated at least a group of plies ago): the LDS round trip hides behind this ply
+            const uint32_t nx = ply0 + t + 1u;
+            word = my_draws[((nx >> 2) & 3u) * (GB * 4) + (nx & 3u)];
+        }
+        Ply y;
+        if (first_actions && t == 0) {
+            action = given;
+            y = play_ply<false, true>(p, NoRow{}, mover, legal, action, illegal_mode, j);
+        } else {
+            y = play_ply<true, true>(p, NoRow{}, mover, legal, action, illegal_mode, j);  // (sampled: legal by construction)
+        }
+        dn = y.terminal ? 1 : 0;
+        legal = legal54(p, mover);  // the next mover's (beside the winner test, see small_role): stored now, sampled from next ply
+        if (y.terminal) {  // raw_env.reset, gobblet.py:275-290
+            p = Planes{0u, 0u, 0u};
+            mover = 0;
+            legal = kLegalEmpty;
+        }
+        const uint32_t slot = t & (2u * kGroupRing - 1u);
+        s_hand[slot][bq] = uint4{p.nz, p.neg, p.odd, (uint32_t)mover};  // (both lanes of a board: the same values)
+        s_legal[slot][bq] = uint4{(uint32_t)legal, (uint32_t)(legal >> 32), (uint32_t)action,
+                                  ((uint32_t)y.winner & 0xFFu) | (((uint32_t)y.r0 & 0xFFu) << 8) | (((uint32_t)y.r1 & 0xFFu) << 16) |
+                                      ((uint32_t)dn << 24) | ((uint32_t)mover << 25) | ((y.stepped ? 1u : 0u) << 26)};
+        if ((t & (kGroupRing - 1u)) == kGroupRing - 1u || t + 1u == plies) pair_barrier();  // four plies handed over
+    }
+    // the boards as they stand, rebuilt from the planes; lane 0 of every pair leaves its row in the image (27-byte rows: unaligned
+    // LDS stores, as ImageRow::reset), the image goes out as the load brought it in
+    planes_to_row(p, r);
+    wave_lds_fence();
+    if (j == 0) __builtin_memcpy(reinterpret_cast<uint8_t *>(s_state) + bq * kCells, r, kCells);
+    wave_lds_fence();
+    sub_out<kCells, kStorePlain, GB>(state + group * (GB * kCells), s_state, lane, rows);
+    if (valid && j == 0) {
+        to_move[b] = (int8_t)mover;
+        done[b] = (int8_t)dn;
+    }
+}
+
 // gbl_placement_probe: the write pattern of k_collect without the game -- tile i of `plies` slots stores 64 rows of
 // 117 bytes into a and 64 rows of 54 bytes into b (zeros, `nt sc1` like the trajectory stream), one wavefront per
 // tile, identity tile map.  Timed with both streams, with a alone and with b alone (see the header).
@@ -2518,6 +2741,22 @@ int gbl_collect_from_ex(int8_t *state, int8_t *to_move, int8_t *done, const int3
 #undef GBL_TRIO
 #undef GBL_TRIO_K
 #undef GBL_TRIO_KH
+        GBL_LAUNCHED("gbl_collect");
+    }
+    if (variant == GBL_COLLECT_GROUP32) {
+        const int64_t ngroups = (n + kGroupBoards - 1) / kGroupBoards;
+#define GBL_G32_K(O, D)                                                                                                            \
+    hipLaunchKernelGGL((k_collect5<O, D>), dim3((uint32_t)ngroups), dim3(64 * (O ? 4 : 2)), 0, s, state, to_move, n, ngroups, seed,    \
+                       env_base, ply_dev, ply0, plies, done, ply_stride, tile_stride, actions_traj, winner_traj, reward_traj,      \
+                       done_traj, to_move_traj, mask_traj, obs_traj, illegal_mode, counters, turn, first_actions, first_status)
+        if (obs_traj) {
+            if (ply_dev) { GBL_G32_K(true, true); }
+            else { GBL_G32_K(true, false); }
+        } else {
+            if (ply_dev) { GBL_G32_K(false, true); }
+            else { GBL_G32_K(false, false); }
+        }
+#undef GBL_G32_K
         GBL_LAUNCHED("gbl_collect");
     }
     if (GBL_COLLECT_IS_ROLES(variant)) {

@@ -332,6 +332,11 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
  *   GBL_COLLECT_PAIR    k_collect2, two wavefronts per tile (one plays, one stores): grids of up to 2560 tiles
  *   GBL_COLLECT_TRIO    k_collect3, three wavefronts per tile: one plays and hands every ply's position over (one barrier per
  *                       ply), one builds and stores the mask rows, one the observation rows
+ *   GBL_COLLECT_GROUP32 k_collect5 (round 6): batches that do not fill the chip and have a mask trajectory -- groups of 32 boards; ONE
+ *                       wavefront plays a group (two lanes per board) and leaves every ply's position, legal mask, action and results
+ *                       in an LDS ring of 2 x 4 plies; a second wavefront builds the mask rows, stores the scalars and runs the
+ *                       sampler's generator, two more the observation rows of 16 boards each; one rendezvous per four plies.
+ *                       FULL up to 9 216 boards, MASK_ONLY up to 32 768
  *   GBL_COLLECT_ROLES(la, ko, merge) = 1000 + 100 la + 10 ko + merge:  k_collect_small<la, ko, merge> -- batches that do
  *                       not fill the chip, whose launch lasts as long as ONE wavefront's serial path: role wavefronts that
  *                       share nothing, each playing the whole game and materialising one share of the outputs.  A workgroup
@@ -345,6 +350,7 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
 /* (3 was GBL_COLLECT_SMALL until ABI version 1's role kernel got its forms; the code is retired, not reused: a consumer built
  *  against that header never reads k_collect3 as the small-batch kernel.  The name stays as an alias of the form it stood for.) */
 #define GBL_COLLECT_SMALL GBL_COLLECT_ROLES(4, 1, 0) /* deprecated */
+#define GBL_COLLECT_GROUP32 5 /* k_collect5 (round 6): groups of 32 boards, one playing wavefront + row wavefronts behind a hand-over ring */
 #define GBL_COLLECT_ROLES(la, ko, merge) (1000 + 100 * (la) + 10 * (ko) + (merge))
 #define GBL_COLLECT_IS_ROLES(variant) ((variant) >= 1000)
 int gbl_collect_variant(int64_t n, uint32_t plies, int with_mask, int with_obs);

@@ -6,8 +6,8 @@ instantiation each one reaches.  Bit-exact (integer / byte work).
     bench record                  entry point (as bench.py calls it)        kernel instantiation
     ----------------------------  ----------------------------------------  -------------------------------------------
     headline (2^20, collect)      gbl_collect, ply index on the device      k_collect<mask, obs, DEV_PLY, NT>, 8 and 20 plies per launch
-    c2_4096                       gbl_collect                               k_collect_small<mask, obs, DEV_PLY, 2, 2, false>  (<= 8 192 boards)
-    c_16384, c_32768              gbl_collect                               k_collect3<mask, obs, DEV_PLY, HAND>  (8 193 ... 45 056 boards)
+    c2_4096                       gbl_collect                               k_collect5<obs, DEV_PLY>  (FULL <= 9 216 boards, MASK_ONLY <= 32 768: 32-board groups, hand-over ring)
+    c_16384, c_32768              gbl_collect                               k_collect3<mask, obs, DEV_PLY, HAND>  (9 217 ... 45 056 boards)
     c_65536                       gbl_collect                               k_collect2<mask, obs, DEV_PLY>
     c3_262144                     gbl_collect                               k_collect<mask, obs, DEV_PLY, NT>
     c4_shard_131072               gbl_collect                               k_collect2<mask, obs, DEV_PLY>  (up to 2560 tiles)
@@ -146,11 +146,13 @@ def test_collect_one_wavefront_kernel_vs_oracle(G, n, with_obs, layout, illegal,
     check_trajectory(env, tr, T, warm, s, tm, dn, 0 if illegal == "noop" else 1, with_obs=with_obs)
 
 
-@pytest.mark.parametrize("n", [3000, 163841])
+@pytest.mark.parametrize("n", [33, 3000, 163841])
 @pytest.mark.parametrize("null", ["mask", "obs", "both", "scalars"])
 def test_collect_c_abi_null_outputs(G, n, null):
     """gbl_collect called through the C-ABI with mask_traj / obs_traj / both / every scalar array NULL (k_collect and
-    k_collect2 <false, *> and <*, false>): what IS written equals the oracle, the state after the launch too."""
+    k_collect2 <false, *> and <*, false>; at 33 and 3 000 boards: the role kernel k_collect_small, which serves the launches WITHOUT a
+    mask trajectory since round 6, with ragged groups, and k_collect5 with its scalar arrays NULL): what IS written equals the
+    oracle, the state after the launch too."""
     nat, L = G._native, G._native.lib()
     T, seed, base, warm = 5, 23, 77, 7
     env, s, tm, dn = warm_pair(G, n, seed, base, warm)
@@ -299,22 +301,31 @@ def test_collect_from_external_first_ply_vs_oracle(G, n, T, illegal, with_obs):
         env.collect(T, out=tr, first_actions=torch.zeros(n, dtype=torch.int32, device=DEV), policies=("random", "random"))
 
 
-# ---- the role kernel (k_collect_small<LA, KO, MERGE>: role wavefronts that share nothing, GBL_COLLECT_ROLES(la, ko, merge)) ----
+# ---- batches that do not fill the chip: k_collect5 (round 6: 32-board groups, a playing wavefront + row wavefronts behind a hand-over
+# ring; until then the role kernel k_collect_small, which still serves launches without a mask trajectory) and k_collect3 ----
 # every form the dispatch can pick, with ragged last groups (1, 15, 17, 33, 63 rows: observation wavefronts whose share of the
 # group is partial, or empty) and whole ones
-SMALL_SIZES = [1, 15, 16, 17, 31, 33, 63, 65, 4096, 4099, 8192,   # FULL <2,2>: groups of 32 boards, two observation wavefronts of 16; MASK_ONLY <2,1>
-               8193, 8209, 8241, 12321, 16384]                   # k_collect3 (until late round 5 FULL ran <1,2> here)
-TRIO_SIZES = [16385, 16447, 32768, 45056, 57344]                 # k_collect3 (FULL 8 193 ... 45 056 boards; MASK_ONLY 8 193 ... 3 * 2^20)
+SMALL_SIZES = [1, 15, 16, 17, 31, 33, 63, 65, 4096, 4099, 8192,   # k_collect5 (round 6): groups of 32 boards, a playing wavefront + row wavefronts
+               8193, 8209, 8241, 9216,                           #   ... FULL up to 9 216 boards (MASK_ONLY up to 32 768)
+               9217, 9249, 12321, 16384]                         # k_collect3 (FULL; MASK_ONLY still k_collect5)
+TRIO_SIZES = [16385, 16447, 32768, 32801, 45056, 57344]          # k_collect3 (FULL 9 217 ... 45 056 boards; MASK_ONLY 32 769 ... 3 * 2^20)
+
+
+def expected_small_variant(n, with_obs):
+    """gbl_collect_variant for a launch WITH a mask trajectory: 5 = GBL_COLLECT_GROUP32 (k_collect5), 4 = GBL_COLLECT_TRIO (k_collect3),
+    2 = GBL_COLLECT_PAIR (k_collect2)."""
+    if with_obs:
+        return 5 if n <= 9216 else 4 if n <= 45056 else 2
+    return 5 if n <= 32768 else 4
 
 
 @pytest.mark.parametrize("with_obs", [True, False], ids=["full", "maskonly"])
 @pytest.mark.parametrize("n", SMALL_SIZES)
 def test_small_batch_collect_vs_oracle(G, n, with_obs):
-    """gbl_collect on batches that do not fill the chip (the role kernel's forms, GBL_COLLECT_ROLES(la, ko, merge))
+    """gbl_collect on batches that do not fill the chip (k_collect5, GBL_COLLECT_GROUP32; k_collect3 beyond its range)
     directly against the oracle, FULL and MASK_ONLY, time- and tile-major slots, both illegal modes, ply index by value and on
     the device, tallies and turn counters; ragged last sub-tiles and whole ones of every form."""
-    variant = G._native.lib().gbl_collect_variant(n, 7, 1, int(with_obs))
-    assert (variant >= 1000) if n <= 8192 else variant == 4  # GBL_COLLECT_ROLES(...) up to 8 192 boards, k_collect3 beyond
+    assert G._native.lib().gbl_collect_variant(n, 7, 1, int(with_obs)) == expected_small_variant(n, with_obs)
     small_batch_case(G, n, with_obs)
 
 
@@ -323,8 +334,7 @@ def test_small_batch_collect_vs_oracle(G, n, with_obs):
 def test_trio_collect_vs_oracle(G, n, with_obs):
     """gbl_collect where k_collect3 runs (one playing wavefront per tile hands every ply's position to a mask-row and an
     observation-row wavefront: GBL_COLLECT_TRIO), against the oracle as above; ragged last tiles (1 and 63 rows) and whole ones."""
-    variant = G._native.lib().gbl_collect_variant(n, 7, 1, int(with_obs))
-    assert variant == (4 if (n <= 45056 or not with_obs) else 2)  # (FULL beyond 45 056 boards: k_collect2, covered here too)
+    assert G._native.lib().gbl_collect_variant(n, 7, 1, int(with_obs)) == expected_small_variant(n, with_obs)
     small_batch_case(G, n, with_obs)
 
 
