@@ -103,7 +103,7 @@ def main():
     rows = ["kernel,counter,dispatches,mean_value_KB"]
     # run name (scripts/profile_round.sh: pmc_runs.txt) -> (key bench.py looks up, kernel name substring)
     runs = {"collect_T8": ("collect:1048576:T8", "k_collect<true, true"), "collect_T20": ("collect:1048576:T20", "k_collect<true, true"),
-            "collect_4096_T1024": ("collect:4096:T1024", "k_collect_small<true, true"),
+            "collect_4096_T1024": ("collect:4096:T1024", "k_collect5<true"),
             "collect_16384_T512": ("collect:16384:T512", "k_collect3<true, true"),
             "collect_32768_T256": ("collect:32768:T256", "k_collect3<true, true"),
             "collect_65536_T256": ("collect:65536:T256", "k_collect2<true, true"),
