@@ -40,7 +40,11 @@
  *   turn    int32[n]          raw_env.turn (plies since reset), optional
  * Contract on `state`: a cell of level k holds 0 or +-(2k+1) or +-(2k+2) --
  * what legal play from reset can produce.  For such states every function is
- * bit-identical to the reference.
+ * bit-identical to the reference.  Outside it nothing is promised (gbl_validate
+ * flags such boards); in particular gbl_collect on small batches keeps the
+ * boards as bit planes and REBUILDS the state rows from them on return, so a
+ * cell that held a value its level cannot hold comes back as the contract's
+ * reading of it (sign and parity kept), where larger batches leave it as found.
  */
 #ifndef GOBBLET_HIP_H
 #define GOBBLET_HIP_H
