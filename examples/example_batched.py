@@ -2,6 +2,9 @@
 """The throughput path: N boards in lockstep on one MI355X.
 
     python examples/example_batched.py --boards 1048576 --plies 200 --policy random|greedy [--graph K] [--collect T]
+    python examples/example_batched.py --boards 65536 --plies 40 --policy greedy --opponent random
+        (a policy OUTSIDE the library against a masked-random opponent, one launch per ply: the step itself leaves the opponent's
+         next draw and a status byte per action behind -- gbl_step_ex)
     python examples/example_batched.py --boards 65536 --plies 64 --policy greedy --opponent random --collect 16
         (whole games greedy vs random inside the launches: the decisions are taken on the device, gbl_collect_policy)
 """
@@ -56,9 +59,25 @@ def main():
     pol = G.GreedyGobbletPolicy(depth=2) if args.policy == "greedy" else None
     p1 = torch.zeros((), dtype=torch.int64, device=env.device)
     p2 = torch.zeros((), dtype=torch.int64, device=env.device)
+    versus_random = pol is not None and args.opponent == "random" and not args.graph
+    if versus_random:
+        # the loop of the reference's trainers with a random opponent (MultiAgentPolicyManager([agent, RandomPolicy])): player_1's
+        # action comes from the policy, player_2's is the masked-uniform draw that the PREVIOUS step left in `draws` -- the step
+        # samples it from the mask it stores (next_actions=), so the opponent costs no launch; `status` says what became of every
+        # action (0 = played; 1 = illegal; 3 = outside [0, 54), where the reference's env() asserts)
+        draws = env.sample_actions().clone()
+        status = torch.zeros(args.boards, dtype=torch.int8, device=env.device)
+        bad = torch.zeros((), dtype=torch.int64, device=env.device)
+
     def one_ply():
         nonlocal p1, p2
-        if pol is None:
+        if versus_random:
+            nonlocal bad
+            mine = pol.compute_actions_from_state(env.squares, env.to_move)
+            actions = torch.where(env.to_move == 0, mine.to(torch.int32), draws)
+            obs, rewards, done, winner = env.step(actions, status=status, next_actions=draws)
+            bad += (status != 0).sum()
+        elif pol is None:
             obs, rewards, done, winner = env.rollout(1)          # action sampled on device, fused with the step
         else:
             actions = pol.compute_actions_from_state(env.squares, env.to_move)
@@ -105,7 +124,10 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     games = int(p1 + p2)
-    print(f"{args.boards} boards x {args.plies} plies ({args.policy}): {args.boards * args.plies / dt:.3e} env-steps/s, "
+    if versus_random:
+        assert int(bad) == 0, "a greedy choice or a masked-random draw was flagged illegal"
+    print(f"{args.boards} boards x {args.plies} plies ({args.policy}{' vs random, one launch per ply' if versus_random else ''}): "
+          f"{args.boards * args.plies / dt:.3e} env-steps/s, "
           f"{games} games finished, player_1 won {int(p1) / max(1, games):.1%}")
 
 

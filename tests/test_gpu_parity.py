@@ -712,7 +712,9 @@ def test_example_scripts_run(G):
             ["examples/example_batched.py", "--boards", "4096", "--plies", "12", "--policy", "greedy", "--graph", "4"],
             ["examples/example_batched.py", "--boards", "65536", "--plies", "48", "--policy", "random", "--collect", "16"],
             ["examples/example_batched.py", "--boards", "16384", "--plies", "32", "--policy", "greedy", "--opponent", "random",
-             "--collect", "16"]]
+             "--collect", "16"],
+            # an external policy against the masked-random draw the step itself leaves behind (gbl_step_ex)
+            ["examples/example_batched.py", "--boards", "8192", "--plies", "24", "--policy", "greedy", "--opponent", "random"]]
     for cmd in runs:
         r = subprocess.run([sys.executable] + cmd, cwd=root, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
