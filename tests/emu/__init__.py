@@ -58,6 +58,12 @@ def play_turn(state, agent, actions):
     lib().emu_play_turn(_p(state), _p(agent), _p(actions), C.c_int64(len(state)))
 
 
+def planes_roundtrip(state):
+    """state rows -> bit planes -> rows (planes_to_row: how k_collect5 writes a group's boards back at the end of a launch)."""
+    n = len(state); out = np.full((n, 27), 77, np.int8)
+    lib().emu_planes_roundtrip(_p(state), _p(out), C.c_int64(n)); return out
+
+
 def winner(state):
     n = len(state); out = np.full(n, 77, np.int8)
     lib().emu_winner(_p(state), _p(out), C.c_int64(n)); return out

@@ -130,6 +130,23 @@ void for_tiles(int64_t n, F f)
 
 extern "C" {
 
+// k_collect5's write-back: state rows -> planes -> rows (planes_to_row), through the kernels' load / stage path
+void emu_planes_roundtrip(const int8_t *state, int8_t *out, int64_t n)
+{
+    for_tiles(n, [&](TileCtx t) {
+        uint32_t r[64][7], d[64][7];
+        load_rows(state, t, r);
+        for (int l = 0; l < 64; ++l) {
+            Planes p = make_planes(r[l]);
+            if (l >= t.rows) p.nz = 0;  // (lanes past a ragged tile's rows hold empty boards; neg / odd keep whatever the image held)
+            planes_to_row(p, d[l]);
+        }
+        Image<kCells> img;
+        stage_all<kCells, 7>(img.p(), d);
+        out_all<kCells>(out + t.tile * (kTile * kCells), img.p(), t.rows);
+    });
+}
+
 void emu_legal_mask(const int8_t *state, const int8_t *to_move, int8_t *mask, int64_t n)
 {
     for_tiles(n, [&](TileCtx t) {

@@ -40,6 +40,9 @@ def test_board_functions_match_oracle(data):
     assert np.array_equal(emu.observe(sq, tm, -1), oracle.batch_observe(sq, tm, -1))
     # rules: a large piece is never covered, so an agent holding/showing one always has a move
     assert (m[:, 36:].sum(1) > 0).all() or (np.abs(sq[:, 18:]) > 0).sum(1).max() == 9
+    # planes_to_row(make_planes(row)) is the identity on contract states: k_collect5 keeps its boards as bit planes for a whole
+    # launch and rebuilds the 27-byte rows from them once, at the end
+    assert np.array_equal(emu.planes_roundtrip(sq), sq)
     # decode(observe(board)) is the identity (greedy_policy.py:43-71 inverts gobblet.py:179-208)
     st_, who = emu.decode_obs(oracle.batch_observe(sq, tm, -1))
     assert np.array_equal(st_, sq) and np.array_equal(who, tm)
