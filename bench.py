@@ -84,6 +84,9 @@ CONFIG_RECORDS = {
     "c2_4096": (4096, 2048, False, "collect"), "c_16384": (16384, 1024, False, "collect"), "c_32768": (32768, 1024, False, "collect"),
     "c_65536": (65536, 512, False, "collect"), "c3_262144": (262144, 128, False, "collect"),
     "c4_shard_131072": (131072, 256, False, "collect"), "large_4194304": (1 << 22, 64, False, "collect"),
+    # the same two shards at a trainer-realistic 32 plies per launch beside the tuned launch lengths above (a launch
+    # boundary costs 3-6 us, which 1 024-ply launches amortise and a collector that trains every 32 plies does not)
+    "c2_4096_T32": (4096, 2048, False, "collect"), "c4_shard_131072_T32": (131072, 256, False, "collect"),
     "maskonly_1048576": (1 << 20, 64, True, "collect"),
     # round 1's pipeline, one launch per ply (gbl_rollout, 234 algorithmic bytes per env-step)
     "single_ply_1048576": (1 << 20, 200, False, "fused"), "single_ply_262144": (262144, 200, False, "fused"),
@@ -1094,7 +1097,8 @@ def main():
             cfg = {}
             for name, (n, k, noobs, mode) in CONFIG_RECORDS.items():
                 cfg[name] = short_run(G, torch, dev, n, k, max(W, 64) if name == "headline_recipe_1048576" else W, no_obs=noobs,
-                                      mode=mode, traj=auto_traj(n, k, no_obs=noobs), placement=args.placement)
+                                      mode=mode, traj=32 if name.endswith("_T32") else auto_traj(n, k, no_obs=noobs),
+                                      placement=args.placement)
             # an external policy's ply + the masked-random reply in one launch, at the C3 / C4-shard sizes (against single_ply_*)
             for n in (131072, 262144):
                 cfg[f"step_reply_{n}"] = step_reply_run(G, torch, dev, n, 200, W)

@@ -404,6 +404,7 @@ def test_bench_config_keys_are_all_covered(G):
     keys = set(bench.CONFIG_RECORDS) | set(bench.EXTRA_RECORDS)
     covered = set(COLLECT_RECORDS) | set(SINGLE_PLY_RECORDS) | {
         "headline_recipe_1048576",   # = headline_1048576 above: 2^20 boards, 8 plies per launch, ply index on the device
+        "c2_4096_T32", "c4_shard_131072_T32",   # = c2_4096 / c4_shard_131072 above (same kernel instantiations), 32 plies per launch
         "step_pipeline_1048576", "step_pipeline_131072", "step_two_launch_1048576",   # test_bench_step_mode_vs_oracle
         "c5_greedy_65536",         # test_gpu_parity.py::test_greedy_config5_full_size
         "greedy_collect_65536",    # test_gpu_policy_collect.py::test_policy_collect_config5_size_selfplay
