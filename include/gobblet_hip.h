@@ -346,7 +346,9 @@ int gbl_collect_policy(int8_t *state, int8_t *to_move, int8_t *done, int8_t *his
  *                       share nothing, each playing the whole game and materialising one share of the outputs.  A workgroup
  *                       is a group of 64 / la boards: one scalars wavefront (which also builds the mask rows when merge = 1),
  *                       unless merged one mask wavefront, both with la lanes per board, and ko observation wavefronts of
- *                       la * ko lanes per board over 1 / ko of the group each.  Round 4's small-batch kernel is (4, 1, 0). */
+ *                       la * ko lanes per board over 1 / ko of the group each.  Round 4's small-batch kernel is (4, 1, 0).  Since
+ *                       round 6 only launches WITHOUT a mask trajectory (up to 8 192 boards) run it; with one: GBL_COLLECT_GROUP32.
+ * (abi_version 2 added GBL_COLLECT_GROUP32; a consumer that switches on the code should treat unknown values as "another kernel".) */
 #define GBL_COLLECT_STREAM 0
 #define GBL_COLLECT_CACHED 1
 #define GBL_COLLECT_PAIR 2
